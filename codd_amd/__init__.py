@@ -1,0 +1,12 @@
+"""codd_amd: MI355X-native implementation of CODD's per-frame stereo -> motion -> fusion path.
+
+Importing the package registers the plug-in classes (reference registry surface:
+ConsistentOnlineDynamicDepth, HITNetMF, HITUNet, TileInitialization, TilePropagation, Motion,
+RAFT3D, Fusion) in ``codd_amd.registry.MODELS``.
+"""
+from . import registry  # noqa: F401
+from . import stereo  # noqa: F401
+from . import estimator  # noqa: F401
+from .registry import MODELS, build_estimator  # noqa: F401
+
+__all__ = ["MODELS", "build_estimator"]

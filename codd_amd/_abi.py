@@ -1,0 +1,105 @@
+"""ctypes binding of libcodd_hip.so (include/codd_hip.h).
+
+The product path has NO fallback: if the library is missing or a call fails, this raises.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class View(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("ctot", C.c_int), ("coff", C.c_int)]
+
+
+class ConvParams(C.Structure):
+    _fields_ = [
+        ("in0", View), ("in1", View), ("C0", C.c_int), ("C1", C.c_int),
+        ("B", C.c_int), ("Hin", C.c_int), ("Win", C.c_int),
+        ("wpacked", C.c_void_p), ("bias", C.c_void_p),
+        ("res1", View), ("res2", View), ("post", View),
+        ("out", C.c_void_p), ("out_ctot", C.c_int), ("out_coff", C.c_int),
+        ("Cout", C.c_int), ("Hout", C.c_int), ("Wout", C.c_int),
+        ("kh", C.c_int), ("kw", C.c_int), ("sy", C.c_int), ("sx", C.c_int),
+        ("pad_t", C.c_int), ("pad_l", C.c_int), ("dil_y", C.c_int), ("dil_x", C.c_int),
+        ("act", C.c_int), ("store_mode", C.c_int), ("mb", C.c_int), ("npb", C.c_int), ("ck", C.c_int),
+    ]
+
+
+ACT = dict(none=0, lrelu=1, relu=2, sigmoid=3, tanh=4, mish=5, relu_ch0=6)
+
+_i, _f, _p, _ll = C.c_int, C.c_float, C.c_void_p, C.c_longlong
+
+# name -> (restype, argtypes); must list every function declared in include/codd_hip.h
+SIGNATURES = {
+    "codd_abi_version": (_i, []),
+    "codd_conv2d": (_i, [C.POINTER(ConvParams), _p]),
+    "codd_conv2d_packed_size": (_ll, [_i] * 6),
+    "codd_conv2d_pack_weights": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "codd_tile_costvol_argmin": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _i, _p]),
+    "codd_tile_warp_cost": (_i, [_p, _p, _i, _i, _i, _i, View, View, _i, _p, _p, _p]),
+    "codd_hyp_upsample": (_i, [View, _i, _i, _i, _f, _p, _i, _i, _p]),
+    "codd_hyp_select": (_i, [_p, View, View, _i, _i, _i, _p, _i, _i, _p]),
+    "codd_instnorm": (_i, [_p, _i, _i, _i, _p, _p, _i, _p, _p]),
+    "codd_allpairs_corr": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "codd_corr_lookup": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "codd_raft_geometry": (_i, [_p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p]),
+    "codd_se3_gn_step": (_i, [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f, _p, _p]),
+    "codd_cvx_upsample": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "codd_disp_to_depth": (_i, [_p, _ll, _f, _p, _p]),
+    "codd_splat": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f,
+                        _p, _p, _p, _p, _p]),
+    "codd_resize_bilinear": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p]),
+    "codd_add_relu": (_i, [_p, _p, _ll, _i, _p, _p]),
+    "codd_gru_rh": (_i, [_p, _p, _i, _i, _p, _p]),
+    "codd_gru_out": (_i, [_p, _p, _p, _i, _i, _p, _p]),
+    "codd_fusion_cues_lr": (_i, [_p] * 6 + [_i] * 5 + [_p, _p, _i, _i, _p]),
+    "codd_fusion_cues_fr": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
+    "codd_fusion_blend": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
+}
+
+_lib = None
+MISSING = []
+
+
+class CoddHipError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Load (building if the sources are newer) libcodd_hip.so; raises if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path) or _build.needs_build():
+        try:
+            _build.build(verbose=False)
+        except Exception as e:  # pragma: no cover
+            if not os.path.exists(path):
+                raise CoddHipError(f"libcodd_hip.so missing and cannot be built: {e}") from e
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            # recorded; tests/test_abi.py asserts this list is empty, and calling the symbol raises
+            MISSING.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    if lib.codd_abi_version() != 1:
+        raise CoddHipError("ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise CoddHipError(f"{what} failed with code {rc}")

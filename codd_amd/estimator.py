@@ -1,0 +1,86 @@
+"""ConsistentOnlineDynamicDepth: the per-frame stereo -> motion -> fusion driver.
+
+reference model/codd.py:22-126 (build + consistent_online_depth_estimation), :128-141 (forward),
+:269-288 (forward_test), :290-398 (inference), :400-433 (reset_inference_state).  Training code
+(forward_train, losses, train_step) is out of scope.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .registry import MODELS, register
+
+
+@register
+class ConsistentOnlineDynamicDepth(nn.Module):
+    def __init__(self, stereo=None, motion=None, fusion=None, train_cfg=None, test_cfg=None, init_cfg=None,
+                 **kwargs):
+        super().__init__()
+        self.fp16_enabled = False
+        self.train_cfg = train_cfg
+        self.test_cfg = test_cfg
+        self.build_model(stereo, motion, fusion)
+        self.inference_state = OrderedDict()
+
+    def build_model(self, stereo, motion, fusion):
+        assert stereo is not None
+        self.stereo = MODELS.build(stereo)
+        self.motion = MODELS.build(motion) if motion is not None else None
+        self.fusion = MODELS.build(fusion) if fusion is not None else None
+
+    # -- hot path ---------------------------------------------------------------------------
+    def consistent_online_depth_estimation(self, left_img, right_img, img_metas, state):
+        """reference model/codd.py:80-126 (eval: everything under no_grad)."""
+        with torch.no_grad():
+            outputs = self.stereo.stereo_matching(left_img, right_img, img_metas, state)
+            if self.motion is not None:
+                self.motion(state, outputs, img_metas=img_metas, train_mode=False)
+            if self.fusion is not None:
+                self.fusion.memory_query(outputs, state, img_metas=img_metas)
+                self.fusion.memory_update(outputs, state, img_metas=img_metas)
+        return outputs
+
+    def forward(self, img, img_metas, return_loss=True, **kwargs):
+        if return_loss:
+            raise NotImplementedError("training is out of scope of the MI355X inference path")
+        return self.forward_test(img, img_metas, **kwargs)
+
+    def forward_test(self, img, img_metas, r_img=None, **kwargs):
+        """reference model/codd.py:269-288."""
+        for var, name in [(img, "img"), (img_metas, "img_metas")]:
+            if not isinstance(var, list):
+                raise TypeError(f"{name} must be a list, but got {type(var)}")
+        img = img[0]
+        r_img = r_img[0] if r_img is not None else r_img
+        with torch.no_grad():
+            pred = self.inference(img, r_img, img_metas[0], **kwargs)
+        return [pred]
+
+    def reset_inference_state(self):
+        """reference model/codd.py:400-433 (metric meters live in codd_amd.metrics)."""
+        self.inference_state = OrderedDict(pred_disp=[])
+
+    def inference(self, img, r_img, img_meta, reciprocal=False, evaluate=False, rescale=True, **kwargs):
+        """reference model/codd.py:290-398.  img, r_img: [B, MF, 3, H, W].  With evaluate=False
+        returns disparities [B, MF, h, w] cropped to ``img_shape``."""
+        if evaluate:
+            raise NotImplementedError("use codd_amd.metrics.evaluate_sequence for on-device metrics")
+        self.reset_inference_state()
+        img_h, img_w = img_meta[0]["img_shape"][:2]
+        outputs = []
+        for l_img, r in zip(torch.unbind(img, 1), torch.unbind(r_img, 1)):
+            out = self.consistent_online_depth_estimation(l_img.contiguous(), r.contiguous(), img_meta,
+                                                          self.inference_state)
+            pred = out["pred_disp"]
+            if reciprocal:
+                pred = img_meta[0]["calib"] / pred
+            self.inference_state["pred_disp"].append(pred)
+            outputs.append(pred[:, :, :img_h, :img_w])
+        outputs = torch.cat(outputs, 1)
+        assert outputs.dim() == 4, "Output shape is wrong"
+        return outputs
+
+    def train(self, mode=True):
+        """reference model/codd.py:601-612 overrides train(); kept chainable here."""
+        return super().train(mode)

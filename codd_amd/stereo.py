@@ -1,0 +1,314 @@
+"""HITNetMF on MI355X: parameter containers with the reference's attribute names (so published
+state dicts load by key) whose forward is a schedule of C-ABI kernel launches.
+
+reference: model/stereo/hitnet/{hitnet,backbone,initialization,propagation}.py.
+Registry names, constructor kwargs and the ``stereo_matching`` contract follow
+configs/models/codd.py:20-39 and model/codd.py:94-96.
+
+Differences from the reference's op schedule (results identical up to fp32 rounding):
+  * left and right images go through the U-Net as one batch of 2;
+  * torch.cat is never executed: producers write into channel slices of the consumer's input
+    buffer, or the conv kernel reads two sources;
+  * the tile cost volume is never materialised (fused arg-min), TileWarping's three offsets,
+    the PixelUnshuffle and the ||fea_l||_1 feature are one kernel, for both hypothesis sets.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import Slice
+from .registry import MODELS, build_backbone, build_loss, register
+
+
+def _lrelu():
+    return nn.LeakyReLU(0.2, inplace=True)
+
+
+_PC = {}
+
+
+def packed(m, deconv=False, cout_keep=None):
+    """PackedConv of an nn.Conv2d / nn.ConvTranspose2d, rebuilt when its parameters change."""
+    key = (id(m), cout_keep)
+    ver = (m.weight.data_ptr(), m.weight._version, None if m.bias is None else m.bias._version)
+    ent = _PC.get(key)
+    if ent is None or ent[0] != ver:
+        ent = (ver, ops.PackedConv(m.weight, m.bias, deconv, cout_keep))
+        _PC[key] = ent
+    return ent[1]
+
+
+def cv(m, x, x2=None, act="none", **kw):
+    """Run nn.Conv2d ``m`` through the HIP conv kernel using the module's own geometry."""
+    return ops.conv2d(x, packed(m), x2=x2, stride=tuple(m.stride), pad=tuple(m.padding), dil=tuple(m.dilation),
+                      act=act, **kw)
+
+
+# ------------------------------------------------------------------------------------- backbone
+def _down(i, o):
+    return nn.Sequential(nn.Conv2d(i, o, 4, 2, 1), _lrelu(), nn.Conv2d(o, o, 3, 1, 1), _lrelu())
+
+
+def _up(i, o):
+    return nn.Sequential(nn.ConvTranspose2d(i, o, 2, 2, 0), _lrelu())
+
+
+def _merge(i, o):
+    return nn.Sequential(nn.Conv2d(i, o, 1), _lrelu(), nn.Conv2d(o, o, 3, 1, 1), _lrelu(),
+                         nn.Conv2d(o, o, 3, 1, 1), _lrelu())
+
+
+@register
+class HITUNet(nn.Module):
+    """reference backbone.py:42-88."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Sequential(nn.Conv2d(3, 16, 3, 1, 1), _lrelu())
+        self.down1 = _down(16, 16)
+        self.down2 = _down(16, 24)
+        self.down3 = _down(24, 24)
+        self.down4 = nn.Sequential(_down(24, 32), nn.Conv2d(32, 32, 3, 1, 1), _lrelu(),
+                                   nn.Conv2d(32, 32, 3, 1, 1), _lrelu())
+        self.up4 = _up(32, 24)
+        self.up3 = _up(24, 24)
+        self.up2 = _up(24, 16)
+        self.up1 = _up(16, 16)
+        self.merge4 = _merge(48, 24)
+        self.merge3 = _merge(48, 24)
+        self.merge2 = _merge(32, 16)
+        self.merge1 = _merge(32, 16)
+
+    def forward(self, x):
+        def seq(s, t):
+            for m in s:
+                if isinstance(m, nn.Conv2d):
+                    t = cv(m, t, act="lrelu")
+            return t
+
+        def up_merge(up, merge, skip, t):
+            u = ops.conv2d(t, packed(up[0], deconv=True), act="lrelu")
+            t = cv(merge[0], skip, x2=u, act="lrelu")
+            t = cv(merge[2], t, act="lrelu")
+            return cv(merge[4], t, act="lrelu")
+
+        x0 = seq(self.conv1, x)
+        x1 = seq(self.down1, x0)
+        x2 = seq(self.down2, x1)
+        x3 = seq(self.down3, x2)
+        x4 = seq(self.down4[0], x3)
+        x4 = cv(self.down4[1], x4, act="lrelu")
+        x4 = cv(self.down4[3], x4, act="lrelu")
+        u4 = up_merge(self.up4, self.merge4, x3, x4)
+        u3 = up_merge(self.up3, self.merge3, x2, u4)
+        u2 = up_merge(self.up2, self.merge2, x1, u3)
+        u1 = up_merge(self.up1, self.merge1, x0, u2)
+        return [x4, u4, u3, u2, u1]
+
+
+# ------------------------------------------------------------------------------------- tile init
+_LEVELS = ("16x", "8x", "4x", "2x", "1x")
+
+
+@register
+class TileInitialization(nn.Module):
+    """reference initialization.py:48-230."""
+
+    def __init__(self, max_disp, fea_c=[16, 16, 24, 24, 32]):
+        super().__init__()
+        self.maxdisp = max_disp
+        c1, c2, c4, c8, c16 = fea_c
+        for name, c in zip(_LEVELS, (c16, c8, c4, c2, c1)):
+            setattr(self, f"tile_conv{name}", nn.Sequential(nn.Conv2d(c, 16, 4, 4, 0), _lrelu(),
+                                                            nn.Conv2d(16, 16, 1, 1, 0), _lrelu()))
+        for name, c in zip(_LEVELS, (17, 17, 33, 25, 25)):
+            setattr(self, f"tile_fea_dscrpt{name}", nn.Sequential(nn.Conv2d(c, 13, 1), _lrelu()))
+
+    def forward(self, fea_l, fea_r):
+        """-> [None, hyps]: the cost volumes are not materialised at inference (the reference only
+        consumes them in the training loss, hitnet.py:84-85).  hyps[l] is a 16-channel Slice at
+        the head of the aug-hypothesis buffer TilePropagation consumes (32 ch at 1/16, else 64)."""
+        hyps = []
+        for lvl, name in enumerate(_LEVELS):
+            fl, fr = fea_l[lvl], fea_r[lvl]
+            tc = getattr(self, f"tile_conv{name}")
+            pc0, pc1 = packed(tc[0]), packed(tc[2])
+            tl = ops.conv2d(ops.conv2d(fl, pc0, stride=4, act="lrelu"), pc1, act="lrelu")
+            # right features: same weights, stride (4,1) on the image zero-padded 3 px on the right
+            tr = ops.conv2d(fr, pc0, stride=(4, 1), pad_tl=(0, 0, 0, 3), act="lrelu")
+            tr = ops.conv2d(tr, pc1, act="lrelu")
+            B, _, Ht, Wt = tl.shape
+            aug = torch.empty(B, 32 if lvl == 0 else 64, Ht, Wt, device=fl.device, dtype=torch.float32)
+            cost = torch.empty(B, 1, Ht, Wt, device=fl.device, dtype=torch.float32)
+            ops.tile_costvol_argmin(tl, tr, self.maxdisp // (16 >> lvl), cost, Slice(aug, 0, 3))
+            feat = tl if lvl < 2 else fea_l[lvl - 2]
+            cv(getattr(self, f"tile_fea_dscrpt{name}")[0], cost, x2=feat, act="lrelu", out=Slice(aug, 3, 13))
+            hyps.append(Slice(aug, 0, 16))
+        return [None, hyps]
+
+
+# ------------------------------------------------------------------------------------- propagation
+def _convbn(i, o, k, s, p, d):
+    return nn.Sequential(nn.Conv2d(i, o, k, s, d if d > 1 else p, d))
+
+
+class BasicBlock(nn.Module):
+    """reference propagation.py:103-121 (no BN)."""
+
+    def __init__(self, c1, c2, s, downsample, p, d):
+        super().__init__()
+        self.conv1 = nn.Sequential(_convbn(c1, c2, 3, s, p, d), _lrelu())
+        self.conv2 = _convbn(c2, c2, 3, 1, p, d)
+
+    def run(self, x):
+        """lrelu(conv2(lrelu(conv1(x))) + x): the trailing LeakyReLU of the enclosing Sequential is
+        fused into the second conv's epilogue."""
+        t = cv(self.conv1[0][0], x, act="lrelu")
+        return cv(self.conv2[0], t, res1=x, act="lrelu")
+
+
+def _resblock(c, d=1):
+    return nn.Sequential(BasicBlock(c, c, s=1, p=1, downsample=None, d=d), _lrelu())
+
+
+class TileUpdate0(nn.Module):
+    """reference propagation.py:124-172."""
+
+    def __init__(self, in_c, out_c, hid_c):
+        super().__init__()
+        self.decrease = nn.Sequential(nn.Conv2d(64, 16, 1), _lrelu())
+        self.conv0 = nn.Sequential(nn.Conv2d(in_c, hid_c, 1), _lrelu())
+        self.resblock0 = _resblock(32)
+        self.resblock1 = _resblock(32)
+        self.lastconv = nn.Conv2d(hid_c, out_c, 3, 1, 1)
+
+    def forward(self, fl, fr, hyp):
+        aug = hyp.buf  # [hyp 16 | local cv 16]
+        w, _ = ops.tile_warp_cost(fl, fr, hyp)
+        cv(self.decrease[0], w, act="lrelu", out=Slice(aug, 16, 16))
+        t = cv(self.conv0[0], aug, act="lrelu")
+        t = self.resblock0[0].run(t)
+        t = self.resblock1[0].run(t)
+        return [cv(self.lastconv, t, res1=hyp, act="relu_ch0")]
+
+
+class TileUpdate(nn.Module):
+    """reference propagation.py:175-248."""
+
+    def __init__(self):
+        super().__init__()
+        self.decrease = nn.Sequential(nn.Conv2d(64, 16, 1), _lrelu())
+        self.conv0 = nn.Sequential(nn.Conv2d(64, 32, 1), _lrelu())
+        self.resblock0 = _resblock(32)
+        self.resblock1 = _resblock(32)
+        self.lastconv = nn.Conv2d(32, 34, 3, 1, 1)
+
+    def forward(self, fl, fr, hyp, prev):
+        aug = hyp.buf  # [cur 16 | cv_cur 16 | up_prev 16 | cv_prev 16]
+        up = Slice(aug, 32, 16)
+        ops.hyp_upsample(prev, 2.0, up)
+        w0, w1 = ops.tile_warp_cost(fl, fr, hyp, up)
+        cv(self.decrease[0], w0, act="lrelu", out=Slice(aug, 16, 16))
+        cv(self.decrease[0], w1, act="lrelu", out=Slice(aug, 48, 16))
+        t = cv(self.conv0[0], aug, act="lrelu")
+        t = self.resblock0[0].run(t)
+        t = self.resblock1[0].run(t)
+        upd = cv(self.lastconv, t)
+        B, _, h, w = upd.shape
+        out = torch.empty(B, 16, h, w, device=upd.device, dtype=torch.float32)
+        return [ops.hyp_select(upd, hyp, up, out)]
+
+
+class PostTileUpdate(nn.Module):
+    """reference propagation.py:251-290."""
+
+    def __init__(self, in_c, out_c, hid_c, resblk_num, final=False):
+        super().__init__()
+        self.conv1 = nn.Sequential(nn.Conv2d(in_c, hid_c, 1), _lrelu(), nn.Conv2d(hid_c, hid_c, 3, 1, 1), _lrelu())
+        self.resblocks = nn.Sequential(*[_resblock(hid_c, 3 if (i == 1 and not final) else 1)
+                                         for i in range(resblk_num)])
+        self.lastconv = nn.Conv2d(hid_c, out_c, 3, padding=1)
+        self._final = final
+
+    def forward(self, fl, prev):
+        t = cv(self.conv1[0], fl, x2=prev, act="lrelu")
+        t = cv(self.conv1[2], t, act="lrelu")
+        for blk in self.resblocks:
+            t = blk[0].run(t)
+        if self._final:
+            # only channel 0 of the 3-channel output is consumed (propagation.py:372): compute that
+            # one, relu(prev_d + out0).
+            return ops.conv2d(t, packed(self.lastconv, cout_keep=1), pad=1, res1=Slice(_buf(prev), _off(prev), 1),
+                              act="relu")
+        return cv(self.lastconv, t, res1=prev, act="relu_ch0")
+
+
+class FinalTileUpdate(PostTileUpdate):
+    """reference propagation.py:293-333."""
+
+    def __init__(self, in_c, out_c, hid_c, resblk_num):
+        super().__init__(in_c, out_c, hid_c, resblk_num, final=True)
+
+
+def _buf(x):
+    return x.buf if isinstance(x, Slice) else x
+
+
+def _off(x):
+    return x.coff if isinstance(x, Slice) else 0
+
+
+def _up1(h):
+    B, _, hh, ww = h.shape
+    out = torch.empty(B, 16, 2 * hh, 2 * ww, device=h.device, dtype=torch.float32)
+    return ops.hyp_upsample(h, 1.0, out)
+
+
+@register
+class TilePropagation(nn.Module):
+    """reference propagation.py:336-454 (inference branch)."""
+
+    def __init__(self):
+        super().__init__()
+        self.tile_update0 = TileUpdate0(32, 16, 32)
+        self.tile_update1 = TileUpdate()
+        self.tile_update2 = TileUpdate()
+        self.tile_update3 = TileUpdate()
+        self.tile_update4 = TileUpdate()
+        self.tile_update4_1 = PostTileUpdate(40, 16, 32, 4)
+        self.tile_update5 = PostTileUpdate(32, 16, 32, 4)
+        self.tile_update6 = FinalTileUpdate(32, 3, 16, 2)
+
+    def forward(self, fea_l, fea_r, init):
+        h = self.tile_update0(fea_l[0], fea_r[0], init[0])[0]
+        for i, upd in enumerate((self.tile_update1, self.tile_update2, self.tile_update3, self.tile_update4), 1):
+            h = upd(fea_l[i], fea_r[i], init[i], h)[0]
+        r1 = self.tile_update4_1(fea_l[2], h)
+        r05 = self.tile_update5(fea_l[3], _up1(r1))
+        return self.tile_update6(fea_l[4], _up1(r05))
+
+
+@register
+class HITNetMF(nn.Module):
+    """reference hitnet.py:13-122."""
+
+    def __init__(self, backbone, initialization, propagation, loss=None):
+        super().__init__()
+        self.backbone = build_backbone(backbone)
+        self.tile_init = MODELS.build(initialization)
+        self.tile_update = MODELS.build(propagation)
+        self.freezed = False
+        self.loss = build_loss(loss) if loss is not None else None
+
+    def extract_feat(self, img):
+        return self.backbone(img)
+
+    def stereo_matching(self, left_img, right_img, img_metas=None, state=None):
+        """reference hitnet.py:75-100 (eval branch) -> dict(pred_disp, left_feat, right_feat, left_img)."""
+        B = left_img.shape[0]
+        pyr = self.extract_feat(torch.cat([left_img, right_img], 0))
+        fea_l = [p[:B] for p in pyr]
+        fea_r = [p[B:] for p in pyr]
+        _, init = self.tile_init(fea_l, fea_r)
+        disp = self.tile_update(fea_l, fea_r, init)
+        return dict(pred_disp=disp, left_feat=fea_l[2], right_feat=fea_r[2], left_img=left_img)

@@ -1,0 +1,221 @@
+/*
+ * codd_hip.h -- C ABI of libcodd_hip.so, the MI355X (gfx950) kernel library behind CODD's
+ * per-frame stereo -> motion -> fusion forward path.
+ *
+ * The reference (facebookresearch/CODD) has no FFI of its own: it is pure Python on torch ops
+ * plus three un-vendored CUDA dependencies (lietorch / lietorch_extras, pytorch3d, mmseg).  Each
+ * entry point below therefore replaces a *call site* of the reference (cited file:line, paths
+ * relative to the reference root) and is what a ctypes / pybind stub in the reference's plug-in
+ * classes would bind.
+ *
+ * Conventions
+ *   - all tensors are fp32, NCHW-contiguous device memory owned by the caller (PyTorch-ROCm);
+ *   - a "view" (ptr, ctot, coff) addresses channels [coff, coff+C) of a buffer that physically
+ *     holds `ctot` channels per batch item -- producers write straight into concatenated
+ *     buffers instead of torch.cat;
+ *   - every function enqueues on `stream` (hipStream_t as void*) and returns immediately:
+ *     0 on success, a negative CODD_E* code on bad arguments, a positive hipError_t otherwise;
+ *   - no global state, no allocation, no host synchronisation: safe under hipGraph capture and
+ *     callable concurrently on distinct streams.
+ */
+#ifndef CODD_HIP_H
+#define CODD_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CODD_ABI_VERSION 1
+
+#define CODD_OK 0
+#define CODD_EINVAL (-1)
+#define CODD_EUNSUPPORTED (-2)
+
+/* activation codes for the conv epilogue */
+enum { CODD_ACT_NONE = 0, CODD_ACT_LRELU02 = 1, CODD_ACT_RELU = 2, CODD_ACT_SIGMOID = 3,
+       CODD_ACT_TANH = 4, CODD_ACT_MISH = 5, CODD_ACT_RELU_CH0 = 6 };
+
+typedef struct {
+  const float* ptr;
+  int ctot; /* channels physically present per batch item */
+  int coff; /* first channel of the view */
+} codd_view;
+
+/* ---------------------------------------------------------------------------------------------
+ * Convolution family (MFMA implicit GEMM, v_mfma_f32_16x16x4_f32: exact fp32).
+ * Replaces every nn.Conv2d / nn.ConvTranspose2d call of the hot path: HITUNet (backbone.py:8-88),
+ * TileInitialization convs (initialization.py:60-156,186-190), TileUpdate* / PostTileUpdate /
+ * FinalTileUpdate (propagation.py:89-333), BasicEncoder (blocks/extractor.py:119-199),
+ * BasicUpdateBlock + ConvGRU (raft3d.py:44-106, blocks/gru.py:9-35), HRNet + ResizeConcatConv
+ * (raft3d.py:109-160), Fusion heads (fusion.py:74-138).
+ *
+ *   v   = sum_{ci,ky,kx} W[co,ci,ky,kx] * in[ci, oy*sy - pad_t + ky*dil_y, ox*sx - pad_l + kx*dil_x]
+ *   v  += bias[co] + res1 + res2          (each optional)
+ *   v   = act(v)
+ *   out = v + post                        (optional)
+ * The input is the channel concatenation of in0 (C0 channels) and in1 (C1 channels, may be 0).
+ * `wpacked` is the weight tensor re-laid-out by codd_conv2d_pack_weights for (mb, ck).
+ * store_mode 1 = ConvTranspose2d(k=2, s=2) expressed as a 1x1 conv with 4*Cout outputs
+ * (co' = (a*2+b)*Cout + co is scattered to out[co][2y+a][2x+b]).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+  codd_view in0, in1;
+  int C0, C1;
+  int B, Hin, Win;
+  const float* wpacked;
+  const float* bias; /* [Cout] or NULL */
+  codd_view res1, res2, post; /* ptr == NULL when absent */
+  float* out;
+  int out_ctot, out_coff;
+  int Cout, Hout, Wout;
+  int kh, kw, sy, sx, pad_t, pad_l, dil_y, dil_x;
+  int act;
+  int store_mode;
+  int mb;  /* 16-channel output blocks per workgroup (1, 2 or 4) */
+  int npb; /* 16-pixel blocks per wave (1, 2 or 4) */
+  int ck;  /* input channels staged per LDS chunk (multiple of 4) */
+} codd_conv_params;
+
+int codd_conv2d(const codd_conv_params* p, void* stream);
+
+/* number of floats of the packed weight buffer for (Cout, Cin, kh, kw, mb, ck) */
+long long codd_conv2d_packed_size(int Cout, int Cin, int kh, int kw, int mb, int ck);
+/* w: [Cout][Cin][kh][kw] device pointer -> wpacked (device).  Runs on `stream`. */
+int codd_conv2d_pack_weights(const float* w, float* wpacked, int Cout, int Cin, int kh, int kw,
+                             int mb, int ck, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stereo (HITNetMF)
+ * --------------------------------------------------------------------------------------------- */
+/* Tile cost volume + first arg-min, fused (never materialises cv):
+ *   cost[y,x] = min_d sum_c |L[c,y,x] - R~[c,y,4x-d]|, d in [0,D), R~ = 0 outside [0,Wr)
+ * replaces calc_init_disp + torch.min (initialization.py:18-45, 167-183).
+ * L [B,C,Ht,Wt], R [B,C,Ht,Wr]; cost -> view channel 0 of `cost` buffer, disparity (as float)
+ * -> channel 0 of `disp` buffer; dx, dy (channels 1,2 of the hypothesis) are zeroed when
+ * zero_dxdy != 0 (initialization.py:192-208). */
+int codd_tile_costvol_argmin(const float* L, const float* R, int B, int C, int Ht, int Wt, int Wr, int D,
+                             float* cost, int cost_ctot, int cost_coff,
+                             float* disp, int disp_ctot, int disp_coff, int zero_dxdy, void* stream);
+
+/* Local slanted-plane correlation (TileWarping.forward, propagation.py:61-86) fused with the
+ * ||fea_l||_1 unshuffle (propagation.py:157,207).  For each of `nhyp` (1 or 2) plane sets
+ * (d,dx,dy = channels 0..2 of hyp{0,1}) writes 64 channels [fea(16) | cv(k=-1,0,1)(48)] into
+ * out{0,1}.  fl, fr: [B,C,4Ht,4Wt]. */
+int codd_tile_warp_cost(const float* fl, const float* fr, int B, int C, int Ht, int Wt,
+                        codd_view hyp0, codd_view hyp1, int nhyp,
+                        float* out0, float* out1, void* stream);
+
+/* Plane up-sampling of a 16-channel hypothesis (propagation.py:10-32): channel 0 =
+ * (d + (j-(s-1)/2) dx + (i-(s-1)/2) dy) * scale on an s-times finer grid (s = 2), channels
+ * 1..15 nearest.  in [B,16,h,w] view -> out view [B,16,2h,2w]. */
+int codd_hyp_upsample(codd_view in, int B, int h, int w, float scale,
+                      float* out, int out_ctot, int out_coff, void* stream);
+
+/* Hypothesis selection of TileUpdate (propagation.py:225-240): upd [B,34,h,w] = lastconv output;
+ * cur / prev: 16-channel views; out [B,16,h,w] view. */
+int codd_hyp_select(const float* upd, codd_view cur, codd_view prev, int B, int h, int w,
+                    float* out, int out_ctot, int out_coff, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Motion (Motion + RAFT3D)
+ * --------------------------------------------------------------------------------------------- */
+/* InstanceNorm2d (affine=False, eps=1e-5) + optional residual + optional ReLU
+ * (blocks/extractor.py:9-58,119-199):  y = relu?( (x - mean_c)/sqrt(var_c + eps) [+ res] ).
+ * stats: scratch of 2*B*C floats. */
+int codd_instnorm(const float* x, int B, int C, int HW, float* stats, const float* res, int relu,
+                  float* y, void* stream);
+
+/* All-pairs correlation pyramid (CorrBlock.__init__/corr, blocks/corr.py:28-45,56-62):
+ * lvl0[n1,n2] = <f1[:,n1], f2[:,n2]> / 16, lvl_{i+1} = avg_pool2d(lvl_i, 2) over (y2,x2).
+ * f1,f2 [B,D,h,w]; lvl_i [B,h*w,(h>>i)*(w>>i)]. */
+int codd_allpairs_corr(const float* f1, const float* f2, int B, int D, int h, int w,
+                       float* lvl0, float* lvl1, float* lvl2, float* lvl3, void* stream);
+
+/* Pyramid lookup (lietorch_extras.corr_index_forward, call site blocks/corr.py:10-18,47-54):
+ * out[b, l*49 + i*7 + j, y, x] = bilinear(lvl_l[b,y,x,:,:], (cx/2^l - 3 + i, cy/2^l - 3 + j)), zero
+ * outside.  coords [B,h,w,3] (x,y,*) with stride `cstride` floats per pixel. */
+int codd_corr_lookup(const float* lvl0, const float* lvl1, const float* lvl2, const float* lvl3,
+                     const float* coords, int cstride, int B, int h, int w, float* out, void* stream);
+
+/* Per-iteration geometry (raft3d.py:225-240; projective_ops.py:11-52; sampler_ops.py:9-28;
+ * SE3.log): from T [B,h,w,7], depth1/depth2 [B,h,w] at 1/8 res and K8 = (fx,fy,cx,cy)/8:
+ *   xyz    [B,h,w,3] = project(T * inv_project(depth1))
+ *   minfo  [B,9,h,w] = clamp([xy - grid, 10*log(T), 10*(bilinear(1/depth2, xy) - xyz.z)], +-50)
+ */
+int codd_raft_geometry(const float* T, const float* depth1, const float* depth2, int B, int h, int w,
+                       float fx, float fy, float cx, float cy, float* xyz, float* minfo, void* stream);
+
+/* Dense SE3 Gauss-Newton step (se3_field.step_inplace, se3_field.py:150-170 =
+ * lietorch_extras.se3_build_inplace + damping + cholesky6x6_forward + SE3.exp(dx) * Ts).
+ * ae [B,32,h,w] (raw head output; /8 applied inside), delta/weight [B,3,h,w]; target = xyz + delta.
+ * T is updated in place.  Hb: scratch [B,h,w,27] floats. */
+int codd_se3_gn_step(float* T, const float* ae, int ae_c, const float* xyz, const float* delta,
+                     const float* weight, const float* depth1, int B, int h, int w,
+                     float fx, float fy, float cx, float cy, int radius, float lm, float ep,
+                     float* Hb, void* stream);
+
+/* Convex 8x up-sampling (se3_field.cvx_upsample, se3_field.py:173-186) of `dim` channels.
+ * mode 0: data [B,h,w,dim] -> out [B,8h,8w,dim]             (generic)
+ * mode 1: data = SE3 field [B,h,w,7]: out = exp(cvx(log(T)))  (upsample_se3, :189-192)
+ * mode 2: data [B,dim,h,w] -> out [B,dim,8h,8w]              (weight, raft3d.py:271-273) */
+int codd_cvx_upsample(const float* data, const float* mask, int B, int h, int w, int dim, int mode,
+                      float* out, void* stream);
+
+/* disparity -> depth (motion.py:154-165): depth = clip(bf / (disp + 1e-5), 0, 210). */
+int codd_disp_to_depth(const float* disp, long long n, float bf, float* depth, void* stream);
+
+/* Forward splat of the previous state into the current frame (Motion.transform_and_project,
+ * motion.py:82-130 = pytorch3d PointsRasterizer(K=8) + AlphaCompositor) fused with
+ * induced_flow (projective_ops.py:55-68) for the full-resolution call.
+ *   T [B,Hs,Ws,7] sampled at (oy + ds*y, ox + ds*x) of a [B,HT,WT,7] field, depth likewise;
+ *   feat channels = concat(featA [CA], flow(3, computed when with_flow), featB [CB]);
+ *   out [B,C,H,W], zout [B,1,H,W] (nearest z, 0 when empty) or disparity when bf > 0:
+ *   disp = bf/(z+1e-5), > W -> 0 (motion.py:190-193).
+ * scratch: (H*W*(1+8*2)) ints per batch item. */
+int codd_splat(const float* T, const float* depth, int HT, int WT, int oy, int ox, int ds,
+               const float* featA, int CA, const float* featB, int CB, int with_flow,
+               int B, int H, int W, float fx, float fy, float cx, float cy, float radius,
+               float bf, float* out, float* zout, float* flow_out, int* scratch, void* stream);
+
+/* bilinear resize (HRNet fuse layers, align_corners = 0; ResizeConcatConv, align_corners = 1):
+ * out view += / = resize(in).  accumulate: 0 overwrite, 1 add; relu applied after. */
+int codd_resize_bilinear(const float* in, int B, int C, int Hi, int Wi, int Ho, int Wo, int align_corners,
+                         float* out, int out_ctot, int out_coff, int accumulate, int relu, void* stream);
+
+/* y = relu?(a + b) elementwise (HRNet fuse sums), n floats. */
+int codd_add_relu(const float* a, const float* b, long long n, int relu, float* y, void* stream);
+
+/* ConvGRU gate fusions (blocks/gru.py:26-34): rh = r*h ; h' = (1-z)*h + z*q.
+ * zr [B,256,hw] (z | r), h [B,128,hw]. */
+int codd_gru_rh(const float* zr, const float* h, int B, int hw, float* rh, void* stream);
+int codd_gru_out(const float* zr, const float* q, const float* h, int B, int hw, float* hout, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fusion
+ * --------------------------------------------------------------------------------------------- */
+/* 1/4-resolution cues (fusion.py:200-241, 168-198, 243-318): corr_feat [B,31,h4,w4] =
+ * [feat cross (9) | feat self curr (8) | feat self warp (8) | cost_curr (3) | cost_warp (3)]
+ * and the sub-sampled disparities pc, pw (fuse(), fusion.py:331-342) written to channels
+ * (dsub_coff, dsub_coff+1) of dsub. */
+int codd_fusion_cues_lr(const float* pred_curr, const float* pred_warp, const float* feat_curr,
+                        const float* feat_warp, const float* fea_l, const float* fea_r,
+                        int B, int H, int W, int CF, int CS, float* corr_feat,
+                        float* dsub, int dsub_ctot, int dsub_coff, void* stream);
+
+/* Full-resolution cues (fusion.py:243-318): corr_feat_fr [B,32,H,W] = [|disp cross| (9) |
+ * |disp self curr| (8) | |disp self warp| (8) | flow_warp (3) | pred_warp>0 (1) | conf_warp (3)]. */
+int codd_fusion_cues_fr(const float* pred_curr, const float* pred_warp, const float* flow_warp,
+                        const float* conf_warp, int B, int H, int W, float* out, void* stream);
+
+/* Blend (fusion.py:383-394): wf = up4(wf_lr) * (pw>0); wr *= (pw>0);
+ * fused = pc*(1-wf*wr) + pw*wf*wr. */
+int codd_fusion_blend(const float* pred_curr, const float* pred_warp, const float* wf_lr,
+                      const float* wr_logit_sig, int B, int H, int W, int ds,
+                      float* fused, float* wf_out, float* wr_out, void* stream);
+
+int codd_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CODD_HIP_H */

@@ -1,0 +1,172 @@
+"""GPU parity of the conv family and the HITNet kernels against the CPU oracle (fp32).
+
+Tolerances: convs are fp32 MFMA fma chains vs MKL-DNN on CPU -> relative 1e-4 of the output
+scale; cost/warp kernels 1e-4 absolute on O(1..10) values; arg-min indices exact except where
+the two best costs differ by < 1e-5 (reported, bounded)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*s, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(s))
+    return torch.randn(*s, generator=g)
+
+
+CONV_CASES = [
+    # Cin, Cout, k, stride, pad, dil, H, W, act
+    (3, 16, 3, 1, 1, 1, 64, 128, "lrelu"),
+    (16, 16, 3, 1, 1, 1, 40, 72, "lrelu"),
+    (16, 24, 4, 2, 1, 1, 64, 96, "lrelu"),
+    (24, 24, 3, 1, 1, 1, 9, 15, "none"),
+    (32, 32, 3, 1, 3, 3, 36, 60, "relu"),
+    (32, 34, 3, 1, 1, 1, 18, 30, "none"),
+    (16, 16, 4, 4, 0, 1, 64, 128, "lrelu"),
+    (64, 16, 1, 1, 0, 1, 36, 60, "lrelu"),
+    (9, 128, 7, 1, 3, 1, 24, 40, "relu"),
+    (196, 256, 3, 1, 1, 1, 16, 24, "relu"),
+    (128, 128, 3, 1, 4, 4, 24, 40, "sigmoid"),
+    (64, 30, 7, 1, 3, 1, 36, 60, "relu"),
+    (3, 64, 7, 2, 3, 1, 64, 128, "none"),
+    (64, 96, 3, 2, 1, 1, 64, 96, "tanh"),
+    (32, 32, 3, 1, 1, 1, 144, 256, "mish"),
+    (270, 512, 1, 1, 0, 1, 16, 32, "relu"),
+]
+
+
+def _act(v, act):
+    return dict(none=lambda t: t, lrelu=lambda t: F.leaky_relu(t, 0.2), relu=F.relu, sigmoid=torch.sigmoid,
+                tanh=torch.tanh, mish=F.mish)[act](v)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(case):
+    from codd_amd import ops
+    cin, cout, k, s, p, d, H, W, act = case
+    x, w, b = rnd(2, cin, H, W), rnd(cout, cin, k, k, seed=1) / (cin * k * k) ** 0.5, rnd(cout, seed=2) * 0.1
+    ref = _act(F.conv2d(x, w, b, s, p, d), act)
+    pc = ops.PackedConv(w.to(dev()), b.to(dev()))
+    got = ops.conv2d(x.to(dev()), pc, stride=s, pad=p, dil=d, act=act).cpu()
+    assert got.shape == ref.shape
+    err = (got - ref).abs().max().item()
+    assert err < 2e-4 * max(1.0, ref.abs().max().item()), err
+
+
+def test_conv2d_views_residuals():
+    from codd_amd import ops
+    from codd_amd.ops import Slice
+    xa, xb = rnd(1, 24, 36, 60), rnd(1, 16, 36, 60, seed=3)
+    w, b = rnd(32, 40, 3, 3, seed=4) / 19.0, rnd(32, seed=5) * 0.1
+    r1, r2, post = rnd(1, 32, 36, 60, seed=6), rnd(1, 32, 36, 60, seed=7), rnd(1, 32, 36, 60, seed=8)
+    ref = F.relu(F.conv2d(torch.cat([xa, xb], 1), w, b, 1, 1) + r1 + r2) + post
+    big_in = torch.zeros(1, 40, 36, 60)
+    big_in[:, 8:32] = xa
+    out = torch.full((1, 48, 36, 60), -7.0, device=dev())
+    pc = ops.PackedConv(w.to(dev()), b.to(dev()))
+    ops.conv2d(Slice(big_in.to(dev()), 8, 24), pc, x2=xb.to(dev()), pad=1, act="relu", res1=r1.to(dev()),
+               res2=r2.to(dev()), post=post.to(dev()), out=Slice(out, 10, 32))
+    out = out.cpu()
+    assert (out[:, 10:42] - ref).abs().max().item() < 2e-4 * ref.abs().max().item()
+    assert (out[:, :10] == -7).all() and (out[:, 42:] == -7).all()
+
+
+def test_conv_right_pad_stride41_and_relu_ch0():
+    from codd_amd import ops
+    x, w, b = rnd(1, 16, 32, 64), rnd(16, 16, 4, 4, seed=1) / 16.0, rnd(16, seed=2) * 0.1
+    ref = F.leaky_relu(F.conv2d(F.pad(x, (0, 3, 0, 0)), w, b, (4, 1)), 0.2)
+    pc = ops.PackedConv(w.to(dev()), b.to(dev()))
+    got = ops.conv2d(x.to(dev()), pc, stride=(4, 1), pad_tl=(0, 0, 0, 3), act="lrelu").cpu()
+    assert got.shape == ref.shape == (1, 16, 8, 64)
+    assert (got - ref).abs().max().item() < 2e-4
+    w3 = rnd(16, 16, 3, 3, seed=3) / 12.0
+    res = rnd(1, 16, 32, 64, seed=4)
+    ref = F.conv2d(x, w3, b, 1, 1) + res
+    ref[:, :1] = F.relu(ref[:, :1])
+    got = ops.conv2d(x.to(dev()), ops.PackedConv(w3.to(dev()), b.to(dev())), pad=1, res1=res.to(dev()),
+                     act="relu_ch0").cpu()
+    assert (got - ref).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("cin,cout,H,W", [(32, 24, 9, 15), (16, 16, 72, 120), (24, 16, 36, 60)])
+def test_deconv2x2(cin, cout, H, W):
+    from codd_amd import ops
+    x, w, b = rnd(2, cin, H, W), rnd(cin, cout, 2, 2, seed=1) / cin ** 0.5, rnd(cout, seed=2) * 0.1
+    ref = F.leaky_relu(F.conv_transpose2d(x, w, b, stride=2), 0.2)
+    pc = ops.PackedConv(w.to(dev()), b.to(dev()), deconv=True)
+    got = ops.conv2d(x.to(dev()), pc, act="lrelu").cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("Ht,Wt,D", [(9, 15, 20), (18, 30, 40), (16, 32, 80), (36, 60, 320)])
+def test_tile_costvol_argmin(Ht, Wt, D):
+    from codd_amd import ops
+    from codd_amd.ops import Slice
+    from oracle import stereo as ost
+    tl, tr = rnd(1, 16, Ht, Wt), rnd(1, 16, Ht, 4 * Wt, seed=1)
+    cost_ref, d_ref = ost.tile_cost_volume_min(tl, tr, D)
+    cvfull = ost.tile_cost_volume(tl, tr, D)
+    cost = torch.empty(1, 1, Ht, Wt, device=dev())
+    hyp = torch.full((1, 16, Ht, Wt), 5.0, device=dev())
+    ops.tile_costvol_argmin(tl.to(dev()), tr.to(dev()), D, cost, Slice(hyp, 0, 3))
+    cost, hyp = cost.cpu(), hyp.cpu()
+    assert (cost - cost_ref).abs().max().item() < 1e-4
+    assert (hyp[:, 1:3] == 0).all() and (hyp[:, 3:] == 5).all()
+    mism = hyp[:, 0:1] != d_ref
+    if mism.any():  # only admissible where the two costs tie to rounding
+        alt = torch.gather(cvfull, 1, hyp[:, 0:1].long())
+        assert ((alt - cost_ref).abs()[mism] < 1e-5).all()
+        assert mism.float().mean().item() < 0.01
+    # systematic ties in the zero-padded region must resolve to the FIRST index exactly
+    x_idx = torch.arange(Wt).view(1, 1, 1, Wt).expand_as(d_ref)
+    padded = d_ref > 4 * x_idx
+    assert (hyp[:, 0:1][padded] == d_ref[padded]).all()
+
+
+@pytest.mark.parametrize("C,Ht,Wt,two", [(32, 9, 15, False), (24, 18, 30, True), (16, 36, 64, True)])
+def test_tile_warp_cost(C, Ht, Wt, two):
+    from codd_amd import ops
+    from codd_amd.ops import Slice
+    from oracle import stereo as ost
+    fl, fr = rnd(1, C, 4 * Ht, 4 * Wt), rnd(1, C, 4 * Ht, 4 * Wt, seed=1)
+
+    def plane(seed):
+        h = rnd(1, 16, Ht, Wt, seed=seed)
+        h[:, 0] = h[:, 0].abs() * 6
+        h[:, 1:3] *= 0.3
+        h[0, 0, 0, :4] = torch.tensor([0.0, 1.0, 2.5, 300.0])  # integer / far out-of-range samples
+        return h
+
+    h0, h1 = plane(2), plane(3)
+    ref0 = torch.cat([ost.unshuffle4(fl.abs().sum(1, keepdim=True)), ost.tile_warping(h0[:, :3], fl, fr)], 1)
+    ref1 = torch.cat([ost.unshuffle4(fl.abs().sum(1, keepdim=True)), ost.tile_warping(h1[:, :3], fl, fr)], 1)
+    big = torch.zeros(1, 64, Ht, Wt)
+    big[:, 32:48] = h1
+    bigd = big.to(dev())
+    o0, o1 = ops.tile_warp_cost(fl.to(dev()), fr.to(dev()), h0.to(dev()), Slice(bigd, 32, 16) if two else None)
+    assert (o0.cpu() - ref0).abs().max().item() < 2e-4
+    if two:
+        assert (o1.cpu() - ref1).abs().max().item() < 2e-4
+
+
+def test_hyp_upsample_select():
+    from codd_amd import ops
+    from oracle import stereo as ost
+    h = rnd(2, 16, 9, 15)
+    for scale in (1.0, 2.0):
+        out = torch.empty(2, 16, 18, 30, device=dev())
+        ops.hyp_upsample(h.to(dev()), scale, out)
+        assert (out.cpu() - ost.upsample_hyp(h, scale, 2)).abs().max().item() < 1e-6
+    upd, cur, prev = rnd(2, 34, 9, 15, seed=1), rnd(2, 16, 9, 15, seed=2), rnd(2, 16, 9, 15, seed=3)
+    upd[0, 1, 0, :5] = upd[0, 0, 0, :5]  # conf ties -> previous
+    sel = upd[:, :2].argmax(1, keepdim=True).float()
+    ref = sel * ost._relu_d(cur + upd[:, 18:34]) + (1 - sel) * ost._relu_d(prev + upd[:, 2:18])
+    out = torch.empty(2, 16, 9, 15, device=dev())
+    ops.hyp_select(upd.to(dev()), cur.to(dev()), prev.to(dev()), out)
+    assert (out.cpu() - ref).abs().max().item() < 1e-6
