@@ -2,10 +2,13 @@
 
 Importing the package registers the plug-in classes (reference registry surface:
 ConsistentOnlineDynamicDepth, HITNetMF, HITUNet, TileInitialization, TilePropagation, Motion,
-RAFT3D, Fusion) in ``codd_amd.registry.MODELS``.
+RAFT3D, HRNet, Fusion) in ``codd_amd.registry.MODELS``.
 """
 from . import registry  # noqa: F401
 from . import stereo  # noqa: F401
+from . import hrnet  # noqa: F401
+from . import motion  # noqa: F401
+from . import fusion  # noqa: F401
 from . import estimator  # noqa: F401
 from .registry import MODELS, build_estimator  # noqa: F401
 

@@ -43,14 +43,20 @@ SIGNATURES = {
     "codd_hyp_upsample": (_i, [View, _i, _i, _i, _f, _p, _i, _i, _p]),
     "codd_hyp_select": (_i, [_p, View, View, _i, _i, _i, _p, _i, _i, _p]),
     "codd_instnorm": (_i, [_p, _i, _i, _i, _p, _p, _i, _p, _p]),
-    "codd_allpairs_corr": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p]),
+    "codd_conv2d_pack_weights_ex": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _ll, _ll, _f, _p]),
+    "codd_allpairs_corr": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "codd_allpairs_corr_scratch": (_ll, [_i, _i, _i, _i]),
+    "codd_avgpool2": (_i, [_p, _i, _i, _i, _p, _p]),
+    "codd_induced_flow": (_i, [_p, _p, _i, _i, _i, _f, _f, _f, _f, _p, _p]),
+    "codd_context_split": (_i, [_p, _i, _i, _p, _p, _p]),
+    "codd_se3_identity": (_i, [_p, _ll, _p]),
     "codd_corr_lookup": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "codd_raft_geometry": (_i, [_p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p]),
     "codd_se3_gn_step": (_i, [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f, _p, _p]),
     "codd_cvx_upsample": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "codd_disp_to_depth": (_i, [_p, _ll, _f, _p, _p]),
     "codd_splat": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f,
-                        _p, _p, _p, _p, _p]),
+                        _p, _p, _p, _i, _p]),
     "codd_resize_bilinear": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p]),
     "codd_add_relu": (_i, [_p, _p, _ll, _i, _p, _p]),
     "codd_gru_rh": (_i, [_p, _p, _i, _i, _p, _p]),

@@ -13,6 +13,7 @@
 // LDS image is padded to 16 (mod 32) floats so that the two ci-groups of a 32-lane half hit
 // disjoint banks.
 #include "common.h"
+#include <string.h>
 
 struct ConvK {
   codd_conv_params p;
@@ -149,7 +150,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK k) {
 }
 
 __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int ntaps,
-                                 int mb, int ck, int wrow, int nchunks, long long total) {
+                                 int mb, int ck, int wrow, int nchunks, long long total, long long co_stride,
+                                 long long ci_stride, float scale) {
   long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
   int col = (int)(e % wrow);
@@ -160,7 +162,7 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict_
   int cog = (int)(t / nchunks);
   int co = cog * 16 * mb + col, ci = chunk * ck + c;
   float v = 0.f;
-  if (col < 16 * mb && co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * ntaps + tap];
+  if (col < 16 * mb && co < Cout && ci < Cin) v = w[(size_t)co * co_stride + (size_t)ci * ci_stride + tap] * scale;
   wp[e] = v;
 }
 
@@ -172,15 +174,23 @@ extern "C" long long codd_conv2d_packed_size(int Cout, int Cin, int kh, int kw, 
   return ncog * nchunks * (long long)(kh * kw) * ck * wrow_of(mb);
 }
 
-extern "C" int codd_conv2d_pack_weights(const float* w, float* wpacked, int Cout, int Cin, int kh, int kw, int mb,
-                                        int ck, void* stream) {
+extern "C" int codd_conv2d_pack_weights_ex(const float* w, float* wpacked, int Cout, int Cin, int kh, int kw, int mb,
+                                           int ck, long long co_stride, long long ci_stride, float scale,
+                                           void* stream) {
   long long total = codd_conv2d_packed_size(Cout, Cin, kh, kw, mb, ck);
   if (total <= 0 || !w || !wpacked) return CODD_EINVAL;
   int nchunks = cdiv(Cin, ck);
   conv_pack_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(w, wpacked, Cout, Cin, kh * kw, mb, ck,
-                                                                      wrow_of(mb), nchunks, total);
+                                                                      wrow_of(mb), nchunks, total, co_stride,
+                                                                      ci_stride, scale);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
+}
+
+extern "C" int codd_conv2d_pack_weights(const float* w, float* wpacked, int Cout, int Cin, int kh, int kw, int mb,
+                                        int ck, void* stream) {
+  return codd_conv2d_pack_weights_ex(w, wpacked, Cout, Cin, kh, kw, mb, ck, (long long)Cin * kh * kw,
+                                     (long long)kh * kw, 1.f, stream);
 }
 
 template <int NPB, int MB>
@@ -237,4 +247,63 @@ extern "C" int codd_conv2d(const codd_conv_params* pp, void* stream) {
   CASE(4, 1); CASE(4, 2); CASE(4, 4);
 #undef CASE
   return CODD_EUNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------------
+// All-pairs correlation pyramid (reference blocks/corr.py:28-45,56-62) as four 1x1 "convolutions":
+// output channel = source pixel n1 (weights = f1^T / 16, re-packed every frame), image = f2 pooled
+// i times.  avg_pool2d commutes with the inner product, so level i never reads level i-1.
+// ------------------------------------------------------------------------------------------------
+extern "C" int codd_avgpool2(const float* in, int BC, int h, int w, float* out, void* stream);
+
+#define CORR_MB 4
+#define CORR_CK 32
+extern "C" long long codd_allpairs_corr_scratch(int B, int D, int h, int w) {
+  long long packed = codd_conv2d_packed_size(h * w, D, 1, 1, CORR_MB, CORR_CK);
+  long long pooled = 0;
+  int hh = h, ww = w;
+  for (int i = 1; i < 4; ++i) { hh >>= 1; ww >>= 1; pooled += (long long)D * hh * ww; }
+  return (long long)B * (packed + pooled);
+}
+
+extern "C" int codd_allpairs_corr(const float* f1, const float* f2, int B, int D, int h, int w, float* lvl0,
+                                  float* lvl1, float* lvl2, float* lvl3, float* scratch, void* stream) {
+  if (!f1 || !f2 || !lvl0 || !lvl1 || !lvl2 || !lvl3 || !scratch || (h >> 3) < 1 || (w >> 3) < 1) return CODD_EINVAL;
+  const int N = h * w;
+  const long long packed = codd_conv2d_packed_size(N, D, 1, 1, CORR_MB, CORR_CK);
+  float* lv[4] = {lvl0, lvl1, lvl2, lvl3};
+  for (int b = 0; b < B; ++b) {
+    float* wp = scratch + (size_t)b * packed;
+    // weights[co = n1][ci = d] = f1[b, d, n1] / 16
+    int rc = codd_conv2d_pack_weights_ex(f1 + (size_t)b * D * N, wp, N, D, 1, 1, CORR_MB, CORR_CK, 1, N, 1.f / 16.f,
+                                         stream);
+    if (rc) return rc;
+  }
+  float* pool = scratch + (size_t)B * packed;
+  const float* src = f2;
+  int hh = h, ww = w;
+  for (int i = 0; i < 4; ++i) {
+    if (i > 0) {
+      int rc = codd_avgpool2(src, B * D, hh, ww, pool, stream);
+      if (rc) return rc;
+      src = pool;
+      hh >>= 1; ww >>= 1;
+      pool += (size_t)B * D * hh * ww;
+    }
+    for (int b = 0; b < B; ++b) {
+      codd_conv_params p;
+      memset(&p, 0, sizeof(p));
+      p.in0.ptr = src + (size_t)b * D * hh * ww; p.in0.ctot = D; p.in0.coff = 0;
+      p.C0 = D; p.C1 = 0; p.B = 1; p.Hin = hh; p.Win = ww;
+      p.wpacked = scratch + (size_t)b * packed;
+      p.out = lv[i] + (size_t)b * N * hh * ww; p.out_ctot = N; p.out_coff = 0;
+      p.Cout = N; p.Hout = hh; p.Wout = ww;
+      p.kh = p.kw = 1; p.sy = p.sx = 1; p.dil_y = p.dil_x = 1;
+      p.act = CODD_ACT_NONE; p.mb = CORR_MB; p.ck = CORR_CK;
+      p.npb = (hh * ww >= 4096) ? 4 : 1;
+      int rc = codd_conv2d(&p, stream);
+      if (rc) return rc;
+    }
+  }
+  return CODD_OK;
 }

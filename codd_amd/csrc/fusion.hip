@@ -1,0 +1,174 @@
+// Fusion cue / blend kernels (reference model/fusion/fusion.py:168-318, 383-394).  HBM-bound fp32.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// 1/4-resolution cues.  Thread = low-res pixel.  corr_feat [B,31,h,w]:
+//   0..8   feature cross correlation   <feat_curr, feat_warp(y+2(ky-1), x+2(kx-1))> / sqrt(CF)
+//   9..16  self correlation of feat_curr (centre tap dropped), 17..24 the same for feat_warp
+//   25..27 cost_curr(k=-1,0,1) = sum_c |fea_l - warp(fea_r, pc/4 + k)|,  28..30 cost_warp
+// and the sub-sampled disparities pc, pw (pred[.., 1::4, 1::4]).
+// ------------------------------------------------------------------------------------------------
+__global__ void fusion_cues_lr_kernel(const float* __restrict__ pred_curr, const float* __restrict__ pred_warp,
+                                      const float* __restrict__ feat_curr, const float* __restrict__ feat_warp,
+                                      const float* __restrict__ fea_l, const float* __restrict__ fea_r, int H, int W,
+                                      int CF, int CS, float* __restrict__ corr, float* __restrict__ dsub, int dsub_ctot,
+                                      int dsub_coff) {
+  const int h = H / 4, w = W / 4, N = h * w;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  if (x >= w) return;
+  const int pix = y * w + x;
+  const size_t fr_idx = (size_t)b * H * W + (size_t)(4 * y + 1) * W + (4 * x + 1);
+  const float pc = pred_curr[fr_idx], pw = pred_warp[fr_idx];
+  dsub[((size_t)b * dsub_ctot + dsub_coff) * N + pix] = pc;
+  dsub[((size_t)b * dsub_ctot + dsub_coff + 1) * N + pix] = pw;
+
+  float* out = corr + (size_t)b * 31 * N + pix;
+  // stereo matching costs: 4 taps serve the three offsets (xs_k = xs_0 - k)
+  const float disp[2] = {pc * 0.25f, pw * 0.25f};
+  const float* flb = fea_l + (size_t)b * CS * N + pix;
+  const float* frb = fea_r + (size_t)b * CS * N + (size_t)y * w;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const float xs = (float)x - disp[s];
+    float f0 = floorf(xs);
+    const float a = xs - f0;
+    f0 = fminf(fmaxf(f0, -4.f), (float)w + 4.f);
+    const int i0 = (int)f0;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    for (int c = 0; c < CS; ++c) {
+      const float lv = flb[(size_t)c * N];
+      const float* rr = frb + (size_t)c * N;
+      float t[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int xi = i0 - 1 + q; t[q] = ((unsigned)xi < (unsigned)w) ? rr[xi] : 0.f; }
+      const float w1 = a, w0 = 1.f - a;
+      c0 += fabsf(lv - (w0 * t[2] + w1 * t[3]));  // k = -1
+      c1 += fabsf(lv - (w0 * t[1] + w1 * t[2]));  // k = 0
+      c2 += fabsf(lv - (w0 * t[0] + w1 * t[1]));  // k = +1
+    }
+    const float sc = 1.f / ((float)CS / 24.f);
+    if (xs != xs) { c0 = c1 = c2 = xs; }
+    out[(size_t)(25 + 3 * s) * N] = c0 * sc;
+    out[(size_t)(26 + 3 * s) * N] = c1 * sc;
+    out[(size_t)(27 + 3 * s) * N] = c2 * sc;
+  }
+  // pixel-to-patch feature correlations, 3x3 taps with dilation 2, zero padding
+  float cross[9], selfc[9], selfw[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) cross[k] = selfc[k] = selfw[k] = 0.f;
+  const float* fc = feat_curr + (size_t)b * CF * N;
+  const float* fw = feat_warp + (size_t)b * CF * N;
+  for (int c = 0; c < CF; ++c) {
+    const float kc = fc[(size_t)c * N + pix], kw_ = fw[(size_t)c * N + pix];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int yy = y + 2 * (k / 3 - 1), xx = x + 2 * (k % 3 - 1);
+      if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) {
+        const float mc = fc[(size_t)c * N + yy * w + xx], mw = fw[(size_t)c * N + yy * w + xx];
+        cross[k] += kc * mw;
+        selfc[k] += kc * mc;
+        selfw[k] += kw_ * mw;
+      }
+    }
+  }
+  const float nrm = 1.f / sqrtf((float)CF);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    out[(size_t)k * N] = cross[k] * nrm;
+    if (k != 4) {
+      const int kk = k < 4 ? k : k - 1;
+      out[(size_t)(9 + kk) * N] = selfc[k] * nrm;
+      out[(size_t)(17 + kk) * N] = selfw[k] * nrm;
+    }
+  }
+}
+
+extern "C" int codd_fusion_cues_lr(const float* pred_curr, const float* pred_warp, const float* feat_curr,
+                                   const float* feat_warp, const float* fea_l, const float* fea_r, int B, int H, int W,
+                                   int CF, int CS, float* corr_feat, float* dsub, int dsub_ctot, int dsub_coff,
+                                   void* stream) {
+  if (!pred_curr || !pred_warp || !feat_curr || !feat_warp || !fea_l || !fea_r || !corr_feat || !dsub) return CODD_EINVAL;
+  if ((H & 3) || (W & 3)) return CODD_EINVAL;
+  dim3 grid(cdiv(W / 4, 64), H / 4, B);
+  fusion_cues_lr_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(pred_curr, pred_warp, feat_curr, feat_warp, fea_l, fea_r, H,
+                                                             W, CF, CS, corr_feat, dsub, dsub_ctot, dsub_coff);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Full-resolution cues: corr_feat_fr [B,32,H,W] =
+//   0..8 |pc - pw~(nb)|, 9..16 |pc - pc~(nb)| (centre dropped), 17..24 |pw - pw~(nb)|,
+//   25..27 flow_warp, 28 (pw > 0), 29..31 confidence_warp      (nb = 3x3 taps, dilation 2, zero pad)
+// ------------------------------------------------------------------------------------------------
+__global__ void fusion_cues_fr_kernel(const float* __restrict__ pc_, const float* __restrict__ pw_,
+                                      const float* __restrict__ flow_warp, const float* __restrict__ conf_warp, int H,
+                                      int W, float* __restrict__ out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  if (x >= W) return;
+  const size_t N = (size_t)H * W, pix = (size_t)y * W + x;
+  const float* pcb = pc_ + (size_t)b * N;
+  const float* pwb = pw_ + (size_t)b * N;
+  const float pc = pcb[pix], pw = pwb[pix];
+  float* o = out + (size_t)b * 32 * N + pix;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int yy = y + 2 * (k / 3 - 1), xx = x + 2 * (k % 3 - 1);
+    const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+    const float mc = in ? pcb[(size_t)yy * W + xx] : 0.f, mw = in ? pwb[(size_t)yy * W + xx] : 0.f;
+    o[(size_t)k * N] = fabsf(pc - mw);
+    if (k != 4) {
+      const int kk = k < 4 ? k : k - 1;
+      o[(size_t)(9 + kk) * N] = fabsf(pc - mc);
+      o[(size_t)(17 + kk) * N] = fabsf(pw - mw);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    o[(size_t)(25 + c) * N] = flow_warp[((size_t)b * 3 + c) * N + pix];
+    o[(size_t)(29 + c) * N] = conf_warp[((size_t)b * 3 + c) * N + pix];
+  }
+  o[(size_t)28 * N] = pw > 0.f ? 1.f : 0.f;
+}
+
+extern "C" int codd_fusion_cues_fr(const float* pred_curr, const float* pred_warp, const float* flow_warp,
+                                   const float* conf_warp, int B, int H, int W, float* out, void* stream) {
+  if (!pred_curr || !pred_warp || !flow_warp || !conf_warp || !out) return CODD_EINVAL;
+  dim3 grid(cdiv(W, 256), H, B);
+  fusion_cues_fr_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(pred_curr, pred_warp, flow_warp, conf_warp, H, W, out);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Blend (reference fusion.py:344-355 nearest x4 up-sampling of the fusion weights, :383-394).
+// ------------------------------------------------------------------------------------------------
+__global__ void fusion_blend_kernel(const float* __restrict__ pc_, const float* __restrict__ pw_,
+                                    const float* __restrict__ wf_lr, const float* __restrict__ wr_, int H, int W,
+                                    int ds, float* __restrict__ fused, float* __restrict__ wf_out,
+                                    float* __restrict__ wr_out, long long total) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int x = (int)(e % W);
+  long long t = e / W;
+  const int y = (int)(t % H);
+  const int b = (int)(t / H);
+  const float pc = pc_[e], pw = pw_[e];
+  const float valid = pw > 0.f ? 1.f : 0.f;
+  const float wf = wf_lr[((size_t)b * (H / ds) + y / ds) * (W / ds) + x / ds] * valid;
+  const float wr = wr_[e] * valid;
+  fused[e] = pc * (1.f - wf * wr) + pw * wf * wr;
+  wf_out[e] = wf;
+  wr_out[e] = wr;
+}
+
+extern "C" int codd_fusion_blend(const float* pred_curr, const float* pred_warp, const float* wf_lr,
+                                 const float* wr_logit_sig, int B, int H, int W, int ds, float* fused, float* wf_out,
+                                 float* wr_out, void* stream) {
+  if (!pred_curr || !pred_warp || !wf_lr || !wr_logit_sig || !fused || !wf_out || !wr_out || ds < 1) return CODD_EINVAL;
+  const long long total = (long long)B * H * W;
+  fusion_blend_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(pred_curr, pred_warp, wf_lr, wr_logit_sig, H, W,
+                                                                        ds, fused, wf_out, wr_out, total);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}

@@ -1,0 +1,695 @@
+// Motion / RAFT3D non-convolution kernels (fp32, HBM / LDS / VALU bound; the only MFMA use is the
+// all-pairs correlation, which is routed through the conv family as a 1x1 convolution).
+#include "common.h"
+#include "se3.h"
+
+#define MIN_DEPTH 0.05f  // reference projective_ops.py:7
+#define PEPS 1e-5f       // reference projective_ops.py:8
+
+// ------------------------------------------------------------------------------------------------
+// InstanceNorm2d (affine = False, eps = 1e-5, biased variance) + residual + ReLU.
+// Two-pass statistics (mean, then centred second moment) per (b, c) by one workgroup.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void instnorm_stats_kernel(const float* __restrict__ x, int HW, float* stats) {
+  __shared__ float red[4];
+  __shared__ float mean_s;
+  const float* p = x + (size_t)blockIdx.x * HW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float s = 0.f;
+  for (int i = tid; i < HW; i += 256) s += p[i];
+  s = wave_sum(s);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  if (tid == 0) mean_s = (red[0] + red[1] + red[2] + red[3]) / (float)HW;
+  __syncthreads();
+  const float m = mean_s;
+  float v = 0.f;
+  for (int i = tid; i < HW; i += 256) { const float d = p[i] - m; v += d * d; }
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  if (tid == 0) {
+    const float var = (red[0] + red[1] + red[2] + red[3]) / (float)HW;
+    stats[2 * blockIdx.x] = m;
+    stats[2 * blockIdx.x + 1] = 1.f / sqrtf(var + 1e-5f);
+  }
+}
+
+__global__ void instnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                      const float* __restrict__ res, int HW, int relu, float* __restrict__ y,
+                                      long long total) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const long long bc = e / HW;
+  float v = (x[e] - stats[2 * bc]) * stats[2 * bc + 1];
+  if (res) v += res[e];
+  if (relu) v = fmaxf(v, 0.f);
+  y[e] = v;
+}
+
+extern "C" int codd_instnorm(const float* x, int B, int C, int HW, float* stats, const float* res, int relu,
+                             float* y, void* stream) {
+  if (!x || !stats || !y || B < 1 || C < 1 || HW < 1) return CODD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  instnorm_stats_kernel<<<B * C, 256, 0, s>>>(x, HW, stats);
+  CODD_LAUNCH_CHECK();
+  const long long total = (long long)B * C * HW;
+  instnorm_apply_kernel<<<cdiv(total, 256), 256, 0, s>>>(x, stats, res, HW, relu, y, total);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// avg_pool2d(2) (floor sizes) -- used to build the pooled feature maps of the correlation pyramid.
+// ------------------------------------------------------------------------------------------------
+__global__ void avgpool2_kernel(const float* __restrict__ in, int h, int w, float* __restrict__ out, long long total) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int w2 = w >> 1, h2 = h >> 1;
+  const int x = (int)(e % w2);
+  long long t = e / w2;
+  const int y = (int)(t % h2);
+  const long long bc = t / h2;
+  const float* p = in + (size_t)bc * h * w + (size_t)(2 * y) * w + 2 * x;
+  out[e] = (p[0] + p[1] + p[w] + p[w + 1]) * 0.25f;
+}
+
+extern "C" int codd_avgpool2(const float* in, int BC, int h, int w, float* out, void* stream) {
+  if (!in || !out || h < 2 || w < 2) return CODD_EINVAL;
+  const long long total = (long long)BC * (h >> 1) * (w >> 1);
+  avgpool2_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(in, h, w, out, total);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Correlation pyramid lookup (lietorch_extras.corr_index_forward; call site blocks/corr.py:10-18,47-54).
+// Workgroup = 4 waves = 16 consecutive source pixels of one pyramid level.  A wave loads the 8x8 tap
+// window of one pixel (lane = ty*8 + tx), forms the 7x7 bilinear outputs with lane shuffles, and the
+// [49][16] result tile is written out through LDS as 64-byte runs.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restrict__ l0, const float* __restrict__ l1,
+                                                          const float* __restrict__ l2, const float* __restrict__ l3,
+                                                          const float* __restrict__ coords, int cstride, int h, int w,
+                                                          float* __restrict__ out) {
+  __shared__ float tile[49][17];
+  const int lvl = blockIdx.y, b = blockIdx.z;
+  const int N = h * w;
+  const int n0 = blockIdx.x * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h2 = h >> lvl, w2 = w >> lvl;
+  const float* vol = (lvl == 0 ? l0 : lvl == 1 ? l1 : lvl == 2 ? l2 : l3) + (size_t)b * N * h2 * w2;
+  const float inv = 1.f / (float)(1 << lvl);
+  const int tx = lane & 7, ty = lane >> 3;
+  for (int q = 0; q < 4; ++q) {
+    const int pi = wave * 4 + q, n = n0 + pi;
+    if (n >= N) break;
+    const float* cp = coords + ((size_t)b * N + n) * cstride;
+    const float x0 = cp[0] * inv, y0 = cp[1] * inv;
+    float fx = floorf(x0), fy = floorf(y0);
+    const float dx = x0 - fx, dy = y0 - fy;
+    // keep the int conversion defined for wild coordinates; everything is out of range then
+    fx = fminf(fmaxf(fx, -16.f), (float)w2 + 16.f);
+    fy = fminf(fmaxf(fy, -16.f), (float)h2 + 16.f);
+    const int ix = (int)fx - 3 + tx, iy = (int)fy - 3 + ty;
+    float v = 0.f;
+    if ((unsigned)ix < (unsigned)w2 && (unsigned)iy < (unsigned)h2 && x0 == x0 && y0 == y0)
+      v = vol[(size_t)n * h2 * w2 + (size_t)iy * w2 + ix];
+    const float vx = __shfl_down(v, 1, 64), vy = __shfl_down(v, 8, 64), vxy = __shfl_down(v, 9, 64);
+    if (tx < 7 && ty < 7) {
+      const float r = ((1.f - dx) * (1.f - dy)) * v + (dx * (1.f - dy)) * vx + ((1.f - dx) * dy) * vy + (dx * dy) * vxy;
+      tile[tx * 7 + ty][pi] = r;  // channel = i*7 + j, i = x offset, j = y offset
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < 49 * 16; e += 256) {
+    const int ch = e >> 4, pi = e & 15, n = n0 + pi;
+    if (n < N) out[((size_t)b * 196 + lvl * 49 + ch) * N + n] = tile[ch][pi];
+  }
+}
+
+extern "C" int codd_corr_lookup(const float* lvl0, const float* lvl1, const float* lvl2, const float* lvl3,
+                                const float* coords, int cstride, int B, int h, int w, float* out, void* stream) {
+  if (!lvl0 || !lvl1 || !lvl2 || !lvl3 || !coords || !out || cstride < 2) return CODD_EINVAL;
+  dim3 grid(cdiv(h * w, 16), 4, B);
+  corr_lookup_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(lvl0, lvl1, lvl2, lvl3, coords, cstride, h, w, out);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-iteration geometry (reference raft3d.py:225-240).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ V3 inv_project(float depth, int x, int y, float fx, float fy, float cx, float cy) {
+  return V3{depth * (((float)x - cx) / fx), depth * (((float)y - cy) / fy), depth};
+}
+__device__ __forceinline__ V3 project(V3 X, float fx, float fy, float cx, float cy) {
+  const float Z = X.z + PEPS;
+  return V3{fx * (X.x / Z) + cx, fy * (X.y / Z) + cy, 1.f / Z};
+}
+
+__global__ void raft_geometry_kernel(const float* __restrict__ T, const float* __restrict__ d1,
+                                     const float* __restrict__ d2, int B, int h, int w, float fx, float fy, float cx,
+                                     float cy, float* __restrict__ xyz, float* __restrict__ minfo) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int N = h * w;
+  if (n >= B * N) return;
+  const int b = n / N, pix = n - b * N, y = pix / w, x = pix - y * w;
+  const SE3T Ti = se3_load(T + (size_t)n * 7);
+  const V3 X1 = se3_act(Ti, inv_project(d1[n], x, y, fx, fy, cx, cy));
+  const V3 p = project(X1, fx, fy, cx, cy);
+  xyz[(size_t)n * 3] = p.x; xyz[(size_t)n * 3 + 1] = p.y; xyz[(size_t)n * 3 + 2] = p.z;
+  // bilinear sample of 1/depth2 at (p.x, p.y), zeros padding, align_corners = True
+  float zinv = 0.f;
+  if (p.x == p.x && p.y == p.y) {
+    float fx0 = floorf(p.x), fy0 = floorf(p.y);
+    const float ax = p.x - fx0, ay = p.y - fy0;
+    fx0 = fminf(fmaxf(fx0, -4.f), (float)w + 4.f);
+    fy0 = fminf(fmaxf(fy0, -4.f), (float)h + 4.f);
+    const int ix = (int)fx0, iy = (int)fy0;
+    const float* dp = d2 + (size_t)b * N;
+    auto tap = [&](int xx, int yy) -> float {
+      return ((unsigned)xx < (unsigned)w && (unsigned)yy < (unsigned)h) ? 1.f / dp[yy * w + xx] : 0.f;
+    };
+    zinv = (1.f - ax) * (1.f - ay) * tap(ix, iy) + ax * (1.f - ay) * tap(ix + 1, iy) +
+           (1.f - ax) * ay * tap(ix, iy + 1) + ax * ay * tap(ix + 1, iy + 1);
+  } else {
+    zinv = p.x + p.y;  // propagate NaN like grid_sample would
+  }
+  V3 tau, phi;
+  se3_log(Ti, &tau, &phi);
+  const float vals[9] = {p.x - (float)x, p.y - (float)y, 10.f * tau.x, 10.f * tau.y, 10.f * tau.z,
+                         10.f * phi.x, 10.f * phi.y, 10.f * phi.z, 10.f * (zinv - p.z)};
+  float* mp = minfo + (size_t)b * 9 * N + pix;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) mp[(size_t)c * N] = fminf(fmaxf(vals[c], -50.f), 50.f);
+}
+
+extern "C" int codd_raft_geometry(const float* T, const float* depth1, const float* depth2, int B, int h, int w,
+                                  float fx, float fy, float cx, float cy, float* xyz, float* minfo, void* stream) {
+  if (!T || !depth1 || !depth2 || !xyz || !minfo) return CODD_EINVAL;
+  raft_geometry_kernel<<<cdiv((long long)B * h * w, 128), 128, 0, (hipStream_t)stream>>>(T, depth1, depth2, B, h, w, fx,
+                                                                                        fy, cx, cy, xyz, minfo);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense SE3 Gauss-Newton step (reference se3_field.py:150-170).
+// One wave per pixel i; lanes sweep the (2r+1)^2 neighbourhood (consecutive lanes = consecutive
+// x_j, so every per-neighbour load is a coalesced row segment), accumulate the 21 + 6 normal
+// equation sums, butterfly-reduce them, and lane 0 damps, solves (Cholesky) and retracts.
+// ------------------------------------------------------------------------------------------------
+#define GN_AE 32
+__global__ __launch_bounds__(256) void se3_gn_kernel(float* __restrict__ T, const float* __restrict__ ae, int ae_c,
+                                                     const float* __restrict__ xyz, const float* __restrict__ delta,
+                                                     const float* __restrict__ wgt, const float* __restrict__ d1, int h,
+                                                     int w, float fx, float fy, float cx, float cy, int radius,
+                                                     float lm, float ep, float* __restrict__ Tout) {
+  const int N = h * w;
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int b = blockIdx.y;
+  if (i >= N) return;
+  const int yi = i / w, xi = i - yi * w;
+  const SE3T Ti = se3_load(T + ((size_t)b * N + i) * 7);
+  const float* aeb = ae + (size_t)b * ae_c * N;
+  float ai[GN_AE];
+#pragma unroll
+  for (int c = 0; c < GN_AE; ++c) ai[c] = c < ae_c ? aeb[(size_t)c * N + i] * 0.125f : 0.f;
+  float Hs[21], bs[6];
+#pragma unroll
+  for (int k = 0; k < 21; ++k) Hs[k] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) bs[k] = 0.f;
+  const int y0 = max(yi - radius, 0), y1 = min(yi + radius, h - 1);
+  const int x0 = max(xi - radius, 0), x1 = min(xi + radius, w - 1);
+  const int ww = x1 - x0 + 1, cnt = ww * (y1 - y0 + 1);
+  const float* xb = xyz + (size_t)b * N * 3;
+  const float* db = delta + (size_t)b * 3 * N;
+  const float* wb = wgt + (size_t)b * 3 * N;
+  const float* dd = d1 + (size_t)b * N;
+  for (int e = lane; e < cnt; e += 64) {
+    const int ry = e / ww, yj = y0 + ry, xj = x0 + (e - ry * ww);
+    const int j = yj * w + xj;
+    float d2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < GN_AE; ++c) {
+      if (c < ae_c) { const float df = ai[c] - aeb[(size_t)c * N + j] * 0.125f; d2 += df * df; }
+    }
+    const V3 X = inv_project(dd[j], xj, yj, fx, fy, cx, cy);
+    const V3 Y = se3_act(Ti, X);
+    if (!(X.z >= MIN_DEPTH) || !(Y.z >= MIN_DEPTH)) continue;
+    const float a = 1.f / (1.f + expf(d2));  // sigmoid(-d2)
+    const float d = 1.f / Y.z;
+    const float xn = Y.x * d, yn = Y.y * d;
+    // rows of J = dp/dxi (tau, phi)
+    const float Jx[6] = {fx * d, 0.f, -fx * xn * d, -fx * xn * yn, fx * (1.f + xn * xn), -fx * yn};
+    const float Jy[6] = {0.f, fy * d, -fy * yn * d, -fy * (1.f + yn * yn), fy * xn * yn, fy * xn};
+    const float Jz[6] = {0.f, 0.f, -d * d, -yn * d, xn * d, 0.f};
+    const float rx = (xb[(size_t)j * 3] + db[j]) - (fx * xn + cx);
+    const float ry_ = (xb[(size_t)j * 3 + 1] + db[N + j]) - (fy * yn + cy);
+    const float rz = (xb[(size_t)j * 3 + 2] + db[2 * N + j]) - d;
+    const float wx = a * wb[j], wy = a * wb[N + j], wz = a * wb[2 * N + j];
+    int k = 0;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+#pragma unroll
+      for (int q = p; q < 6; ++q) { Hs[k] += wx * Jx[p] * Jx[q] + wy * Jy[p] * Jy[q] + wz * Jz[p] * Jz[q]; ++k; }
+      bs[p] += wx * rx * Jx[p] + wy * ry_ * Jy[p] + wz * rz * Jz[p];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 21; ++k) Hs[k] = wave_sum(Hs[k]);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) bs[k] = wave_sum(bs[k]);
+  if (lane != 0) return;
+  // damping H += (lm*H + ep) on the diagonal, then Cholesky solve (fp64 for the 6x6 system)
+  double A[6][6], L[6][6], rhs[6];
+  {
+    int k = 0;
+    for (int p = 0; p < 6; ++p)
+      for (int q = p; q < 6; ++q) { A[p][q] = A[q][p] = (double)Hs[k]; ++k; }
+  }
+  for (int p = 0; p < 6; ++p) {
+    const float hd = (float)A[p][p];
+    A[p][p] = (double)(hd + (lm * hd + ep));
+    rhs[p] = (double)bs[p];
+  }
+  bool ok = true;
+  for (int p = 0; p < 6; ++p) {
+    for (int q = 0; q <= p; ++q) {
+      double s = A[p][q];
+      for (int r = 0; r < q; ++r) s -= L[p][r] * L[q][r];
+      if (p == q) { if (!(s > 0.0)) { ok = false; s = 1.0; } L[p][p] = sqrt(s); }
+      else L[p][q] = s / L[q][q];
+    }
+  }
+  double yv[6], xv[6];
+  for (int p = 0; p < 6; ++p) { double s = rhs[p]; for (int r = 0; r < p; ++r) s -= L[p][r] * yv[r]; yv[p] = s / L[p][p]; }
+  for (int p = 5; p >= 0; --p) { double s = yv[p]; for (int r = p + 1; r < 6; ++r) s -= L[r][p] * xv[r]; xv[p] = s / L[p][p]; }
+  SE3T Tn = Ti;
+  if (ok) {
+    const SE3T dT = se3_exp(V3{(float)xv[0], (float)xv[1], (float)xv[2]}, V3{(float)xv[3], (float)xv[4], (float)xv[5]});
+    Tn = se3_compose(dT, Ti);
+  }
+  se3_store(Tout + ((size_t)b * N + i) * 7, Tn);
+}
+
+extern "C" int codd_se3_gn_step(float* T, const float* ae, int ae_c, const float* xyz, const float* delta,
+                                const float* weight, const float* depth1, int B, int h, int w, float fx, float fy,
+                                float cx, float cy, int radius, float lm, float ep, float* Hb, void* stream) {
+  (void)Hb;
+  if (!T || !ae || !xyz || !delta || !weight || !depth1 || ae_c < 1 || ae_c > GN_AE || radius < 0) return CODD_EINVAL;
+  dim3 grid(cdiv(h * w, 4), B);
+  se3_gn_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(T, ae, ae_c, xyz, delta, weight, depth1, h, w, fx, fy, cx, cy,
+                                                       radius, lm, ep, T);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Convex 8x up-sampling (reference se3_field.py:173-192).  Workgroup = one coarse row segment of 64
+// pixels; thread = coarse pixel, waves split the 64 sub-pixels (i, j).  mask reads are coalesced
+// along x; the 3x3 neighbourhood of the (log-)data lives in registers.
+// ------------------------------------------------------------------------------------------------
+template <int MODE, int DIM>
+__global__ __launch_bounds__(256) void cvx_upsample_kernel(const float* __restrict__ data,
+                                                           const float* __restrict__ mask, int h, int w,
+                                                           float* __restrict__ out) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int wave = threadIdx.x >> 6;
+  const int y = blockIdx.y, b = blockIdx.z;
+  if (x >= w) return;
+  const int N = h * w;
+  constexpr int D = (MODE == 1) ? 6 : DIM;
+  float nb[9][D];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+    const bool in = (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w;
+    if (MODE == 1) {
+      V3 tau = V3{0, 0, 0}, phi = V3{0, 0, 0};
+      if (in) { const SE3T Tn = se3_load(data + ((size_t)b * N + yy * w + xx) * 7); se3_log(Tn, &tau, &phi); }
+      nb[k][0] = tau.x; nb[k][1] = tau.y; nb[k][2] = tau.z; nb[k][3] = phi.x; nb[k][4] = phi.y; nb[k][5] = phi.z;
+    } else if (MODE == 0) {
+#pragma unroll
+      for (int c = 0; c < D; ++c) nb[k][c] = in ? data[((size_t)b * N + yy * w + xx) * D + c] : 0.f;
+    } else {
+#pragma unroll
+      for (int c = 0; c < D; ++c) nb[k][c] = in ? data[((size_t)b * D + c) * N + yy * w + xx] : 0.f;
+    }
+  }
+  const float* mb = mask + (size_t)b * 576 * N + (size_t)y * w + x;
+  const int H8 = 8 * h, W8 = 8 * w;
+  for (int s = wave * 16; s < wave * 16 + 16; ++s) {
+    float m[9], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { m[k] = mb[(size_t)(k * 64 + s) * N]; mx = fmaxf(mx, m[k]); }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { m[k] = expf(m[k] - mx); den += m[k]; }
+    float acc[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float wk = m[k] / den;
+#pragma unroll
+      for (int c = 0; c < D; ++c) acc[c] += wk * nb[k][c];
+    }
+    const int oy = 8 * y + (s >> 3), ox = 8 * x + (s & 7);
+    if (MODE == 1) {
+      const SE3T To = se3_exp(V3{acc[0], acc[1], acc[2]}, V3{acc[3], acc[4], acc[5]});
+      se3_store(out + ((size_t)b * H8 * W8 + (size_t)oy * W8 + ox) * 7, To);
+    } else if (MODE == 0) {
+#pragma unroll
+      for (int c = 0; c < D; ++c) out[((size_t)b * H8 * W8 + (size_t)oy * W8 + ox) * D + c] = acc[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < D; ++c) out[((size_t)b * D + c) * H8 * W8 + (size_t)oy * W8 + ox] = acc[c];
+    }
+  }
+}
+
+extern "C" int codd_cvx_upsample(const float* data, const float* mask, int B, int h, int w, int dim, int mode,
+                                 float* out, void* stream) {
+  if (!data || !mask || !out) return CODD_EINVAL;
+  dim3 grid(cdiv(w, 64), h, B);
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == 1) cvx_upsample_kernel<1, 6><<<grid, 256, 0, s>>>(data, mask, h, w, out);
+  else if (mode == 0 && dim == 6) cvx_upsample_kernel<0, 6><<<grid, 256, 0, s>>>(data, mask, h, w, out);
+  else if (mode == 0 && dim == 3) cvx_upsample_kernel<0, 3><<<grid, 256, 0, s>>>(data, mask, h, w, out);
+  else if (mode == 0 && dim == 2) cvx_upsample_kernel<0, 2><<<grid, 256, 0, s>>>(data, mask, h, w, out);
+  else if (mode == 2 && dim == 3) cvx_upsample_kernel<2, 3><<<grid, 256, 0, s>>>(data, mask, h, w, out);
+  else return CODD_EUNSUPPORTED;
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// disparity -> depth (reference motion.py:154-165)
+// ------------------------------------------------------------------------------------------------
+__global__ void disp_to_depth_kernel(const float* __restrict__ disp, long long n, float bf, float* __restrict__ depth) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const float v = bf / (disp[e] + 1e-5f);
+  depth[e] = fminf(fmaxf(v, 0.f), 210.f);
+}
+
+extern "C" int codd_disp_to_depth(const float* disp, long long n, float bf, float* depth, void* stream) {
+  if (!disp || !depth || n < 1) return CODD_EINVAL;
+  disp_to_depth_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(disp, n, bf, depth);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward splat (Motion.transform_and_project, reference motion.py:82-130).
+//   pass 1 (per source point): project, append the point id to the candidate list of every covered
+//           pixel (atomic slot counter; the slot ORDER is irrelevant, see pass 2);
+//   pass 2 (per output pixel): re-project the candidates, keep the 8 nearest by (z, id) --
+//           deterministic regardless of the append order -- and composite front to back.
+// Pixel centres sit at +0.5 (pytorch3d NDC convention); R = radius * min(H,W) / (2H) pixels.
+// ------------------------------------------------------------------------------------------------
+struct SplatP {
+  const float* T; const float* depth; int HT, WT, oy, ox, ds;
+  const float* featA; int CA; const float* featB; int CB; int with_flow;
+  int H, W; float fx, fy, cx, cy, R; float bf;
+  float* out; float* zout; int* cnt; int* list; int cap;
+};
+
+__device__ __forceinline__ bool splat_point(const SplatP& p, int b, int n, float* u, float* v, float* z,
+                                            V3* flow) {
+  const int py = n / p.W, px = n - py * p.W;
+  const size_t src = (size_t)b * p.HT * p.WT + (size_t)(p.oy + p.ds * py) * p.WT + (p.ox + p.ds * px);
+  const SE3T Ti = se3_load(p.T + src * 7);
+  const V3 X0 = inv_project(p.depth[src], px, py, p.fx, p.fy, p.cx, p.cy);
+  const V3 X1 = se3_act(Ti, X0);
+  *z = X1.z;
+  if (!(X1.z > 0.f)) return false;
+  *u = p.fx * X1.x / X1.z + p.cx;
+  *v = p.fy * X1.y / X1.z + p.cy;
+  if (flow) {
+    const V3 a = project(X1, p.fx, p.fy, p.cx, p.cy), c = project(X0, p.fx, p.fy, p.cx, p.cy);
+    *flow = V3{a.x - c.x, a.y - c.y, a.z - c.z};
+  }
+  return fabsf(*u) < 1e7f && fabsf(*v) < 1e7f;  // also rejects NaN / inf
+}
+
+__global__ void splat_scatter_kernel(const SplatP p) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (n >= p.H * p.W) return;
+  float u, v, z;
+  if (!splat_point(p, b, n, &u, &v, &z, nullptr)) return;
+  const int span = (int)(p.R + 1.5f);
+  const int bx = (int)floorf(u - 0.5f), by = (int)floorf(v - 0.5f);
+  const float R2 = p.R * p.R;
+  for (int oy = -span + 1; oy <= span; ++oy) {
+    const int yy = by + oy;
+    if ((unsigned)yy >= (unsigned)p.H) continue;
+    for (int ox = -span + 1; ox <= span; ++ox) {
+      const int xx = bx + ox;
+      if ((unsigned)xx >= (unsigned)p.W) continue;
+      const float du = u - ((float)xx + 0.5f), dv = v - ((float)yy + 0.5f);
+      const float d2 = du * du + dv * dv;
+      if (!(d2 < R2)) continue;
+      const size_t pix = (size_t)b * p.H * p.W + (size_t)yy * p.W + xx;
+      const int slot = atomicAdd(&p.cnt[pix], 1);
+      if (slot < p.cap) p.list[pix * p.cap + slot] = n;
+    }
+  }
+}
+
+__global__ void splat_gather_kernel(const SplatP p) {
+  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  const int HW = p.H * p.W;
+  if (pix >= HW) return;
+  const int py = pix / p.W, px = pix - py * p.W;
+  const size_t gp = (size_t)b * HW + pix;
+  const int cnt = min(p.cnt[gp], p.cap);
+  float kz[8], ka[8];
+  int kid[8];
+  int nk = 0;
+  const float R2 = p.R * p.R;
+  for (int s = 0; s < cnt; ++s) {
+    const int n = p.list[gp * p.cap + s];
+    float u, v, z;
+    splat_point(p, b, n, &u, &v, &z, nullptr);
+    const float du = u - ((float)px + 0.5f), dv = v - ((float)py + 0.5f);
+    const float al = 1.f - (du * du + dv * dv) / R2;
+    // insertion into the sorted (z, id) top-8
+    int pos = nk;
+    while (pos > 0 && (z < kz[pos - 1] || (z == kz[pos - 1] && n < kid[pos - 1]))) --pos;
+    if (pos >= 8) continue;
+    const int last = nk < 8 ? nk : 7;
+    for (int q = last; q > pos; --q) { kz[q] = kz[q - 1]; ka[q] = ka[q - 1]; kid[q] = kid[q - 1]; }
+    kz[pos] = z; ka[pos] = al; kid[pos] = n;
+    if (nk < 8) ++nk;
+  }
+  const int C = p.CA + (p.with_flow ? 3 : 0) + p.CB;
+  float wk[8];
+  float tr = 1.f;
+  for (int k = 0; k < nk; ++k) { wk[k] = tr * ka[k]; tr *= (1.f - ka[k]); }
+  float* op = p.out + (size_t)b * C * HW + pix;
+  for (int c = 0; c < p.CA; ++c) {
+    float acc = 0.f;
+    for (int k = 0; k < nk; ++k) acc += wk[k] * p.featA[((size_t)b * p.CA + c) * HW + kid[k]];
+    op[(size_t)c * HW] = acc;
+  }
+  int co = p.CA;
+  if (p.with_flow) {
+    float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+    for (int k = 0; k < nk; ++k) {
+      float u, v, z; V3 fl;
+      splat_point(p, b, kid[k], &u, &v, &z, &fl);
+      f0 += wk[k] * fl.x; f1 += wk[k] * fl.y; f2 += wk[k] * fl.z;
+    }
+    op[(size_t)co * HW] = f0; op[(size_t)(co + 1) * HW] = f1; op[(size_t)(co + 2) * HW] = f2;
+    co += 3;
+  }
+  for (int c = 0; c < p.CB; ++c) {
+    float acc = 0.f;
+    for (int k = 0; k < nk; ++k) acc += wk[k] * p.featB[((size_t)b * p.CB + c) * HW + kid[k]];
+    op[(size_t)(co + c) * HW] = acc;
+  }
+  if (p.zout) {
+    const float zn = nk > 0 ? fmaxf(kz[0], 0.f) : 0.f;
+    float o = zn;
+    if (p.bf > 0.f) { o = p.bf / (zn + 1e-5f); if (o > (float)p.W) o = 0.f; }
+    p.zout[gp] = o;
+  }
+}
+
+extern "C" int codd_splat(const float* T, const float* depth, int HT, int WT, int oy, int ox, int ds,
+                          const float* featA, int CA, const float* featB, int CB, int with_flow, int B, int H, int W,
+                          float fx, float fy, float cx, float cy, float radius, float bf, float* out, float* zout,
+                          int* scratch, int cap, void* stream) {
+  if (!T || !depth || !out || !scratch || cap < 8 || CA < 0 || CB < 0 || (CA > 0 && !featA) || (CB > 0 && !featB))
+    return CODD_EINVAL;
+  if (oy + ds * (H - 1) >= HT || ox + ds * (W - 1) >= WT) return CODD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  SplatP p;
+  p.T = T; p.depth = depth; p.HT = HT; p.WT = WT; p.oy = oy; p.ox = ox; p.ds = ds;
+  p.featA = featA; p.CA = CA; p.featB = featB; p.CB = CB; p.with_flow = with_flow;
+  p.H = H; p.W = W; p.fx = fx; p.fy = fy; p.cx = cx; p.cy = cy;
+  p.R = radius * (float)(H < W ? H : W) / (2.f * (float)H);
+  p.bf = bf; p.out = out; p.zout = zout;
+  p.cnt = scratch; p.list = scratch + (size_t)B * H * W; p.cap = cap;
+  hipError_t e = hipMemsetAsync(p.cnt, 0, (size_t)B * H * W * sizeof(int), s);
+  if (e != hipSuccess) return (int)e;
+  dim3 grid(cdiv(H * W, 256), B);
+  splat_scatter_kernel<<<grid, 256, 0, s>>>(p);
+  CODD_LAUNCH_CHECK();
+  splat_gather_kernel<<<grid, 256, 0, s>>>(p);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+// induced flow (reference projective_ops.py:55-68), full resolution: out [B,H,W,3]
+__global__ void induced_flow_kernel(const float* __restrict__ T, const float* __restrict__ depth, int H, int W,
+                                    float fx, float fy, float cx, float cy, float* __restrict__ out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (n >= H * W) return;
+  const int y = n / W, x = n - y * W;
+  const size_t g = (size_t)b * H * W + n;
+  const V3 X0 = inv_project(depth[g], x, y, fx, fy, cx, cy);
+  const V3 X1 = se3_act(se3_load(T + g * 7), X0);
+  const V3 a = project(X1, fx, fy, cx, cy), c = project(X0, fx, fy, cx, cy);
+  out[g * 3] = a.x - c.x; out[g * 3 + 1] = a.y - c.y; out[g * 3 + 2] = a.z - c.z;
+}
+
+extern "C" int codd_induced_flow(const float* T, const float* depth, int B, int H, int W, float fx, float fy, float cx,
+                                 float cy, float* out, void* stream) {
+  if (!T || !depth || !out) return CODD_EINVAL;
+  dim3 grid(cdiv(H * W, 256), B);
+  induced_flow_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(T, depth, H, W, fx, fy, cx, cy, out);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// HRNet helpers: bilinear resize (torch F.interpolate semantics) and add(+relu).
+// ------------------------------------------------------------------------------------------------
+__global__ void resize_bilinear_kernel(const float* __restrict__ in, int C, int Hi, int Wi, int Ho, int Wo, int ac,
+                                       float* __restrict__ out, int out_ctot, int out_coff, int accumulate, int relu,
+                                       long long total) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int x = (int)(e % Wo);
+  long long t = e / Wo;
+  const int y = (int)(t % Ho); t /= Ho;
+  const int c = (int)(t % C);
+  const int b = (int)(t / C);
+  float sy, sx;
+  if (ac) {
+    sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) * (float)y : 0.f;
+    sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) * (float)x : 0.f;
+  } else {
+    sy = fmaxf(((float)Hi / (float)Ho) * ((float)y + 0.5f) - 0.5f, 0.f);
+    sx = fmaxf(((float)Wi / (float)Wo) * ((float)x + 0.5f) - 0.5f, 0.f);
+  }
+  const int y0 = min((int)sy, Hi - 1), x0 = min((int)sx, Wi - 1);
+  const int y1 = min(y0 + 1, Hi - 1), x1 = min(x0 + 1, Wi - 1);
+  const float ly = sy - (float)y0, lx = sx - (float)x0;
+  const float* p = in + ((size_t)b * C + c) * Hi * Wi;
+  float v = (1.f - ly) * ((1.f - lx) * p[y0 * Wi + x0] + lx * p[y0 * Wi + x1]) +
+            ly * ((1.f - lx) * p[y1 * Wi + x0] + lx * p[y1 * Wi + x1]);
+  float* o = out + ((size_t)b * out_ctot + out_coff + c) * Ho * Wo + (size_t)y * Wo + x;
+  if (accumulate) v += *o;
+  if (relu) v = fmaxf(v, 0.f);
+  *o = v;
+}
+
+extern "C" int codd_resize_bilinear(const float* in, int B, int C, int Hi, int Wi, int Ho, int Wo, int align_corners,
+                                    float* out, int out_ctot, int out_coff, int accumulate, int relu, void* stream) {
+  if (!in || !out) return CODD_EINVAL;
+  const long long total = (long long)B * C * Ho * Wo;
+  resize_bilinear_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(in, C, Hi, Wi, Ho, Wo, align_corners, out,
+                                                                            out_ctot, out_coff, accumulate, relu, total);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+__global__ void add_relu_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, int relu,
+                                float* __restrict__ y) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float v = a[e] + (b ? b[e] : 0.f);
+  if (relu) v = fmaxf(v, 0.f);
+  y[e] = v;
+}
+
+extern "C" int codd_add_relu(const float* a, const float* b, long long n, int relu, float* y, void* stream) {
+  if (!a || !y) return CODD_EINVAL;
+  add_relu_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(a, b, n, relu, y);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ConvGRU gate fusions (reference blocks/gru.py:26-34) and the context split (raft3d.py:183-186).
+// ------------------------------------------------------------------------------------------------
+__global__ void gru_rh_kernel(const float* __restrict__ zr, const float* __restrict__ h, int hw, float* __restrict__ rh,
+                              long long total) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const long long b = e / (128LL * hw), r = e - b * 128LL * hw;
+  rh[e] = zr[b * 256LL * hw + 128LL * hw + r] * h[e];
+}
+__global__ void gru_out_kernel(const float* __restrict__ zr, const float* __restrict__ q, const float* __restrict__ h,
+                               int hw, float* __restrict__ ho, long long total) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const long long b = e / (128LL * hw), r = e - b * 128LL * hw;
+  const float z = zr[b * 256LL * hw + r];
+  ho[e] = (1.f - z) * h[e] + z * q[e];
+}
+extern "C" int codd_gru_rh(const float* zr, const float* h, int B, int hw, float* rh, void* stream) {
+  if (!zr || !h || !rh) return CODD_EINVAL;
+  const long long total = (long long)B * 128 * hw;
+  gru_rh_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(zr, h, hw, rh, total);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+extern "C" int codd_gru_out(const float* zr, const float* q, const float* h, int B, int hw, float* hout, void* stream) {
+  if (!zr || !q || !h || !hout) return CODD_EINVAL;
+  const long long total = (long long)B * 128 * hw;
+  gru_out_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(zr, q, h, hw, hout, total);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+// net = tanh(x[:, :128]), inp = relu(x[:, 128:512])  (reference raft3d.py:183-186)
+__global__ void context_split_kernel(const float* __restrict__ x, int hw, float* __restrict__ net,
+                                     float* __restrict__ inp, long long total) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const long long b = e / (512LL * hw), r = e - b * 512LL * hw;
+  const float v = x[e];
+  if (r < 128LL * hw) net[b * 128LL * hw + r] = tanhf(v);
+  else inp[b * 384LL * hw + (r - 128LL * hw)] = fmaxf(v, 0.f);
+}
+extern "C" int codd_context_split(const float* x, int B, int hw, float* net, float* inp, void* stream) {
+  if (!x || !net || !inp) return CODD_EINVAL;
+  const long long total = (long long)B * 512 * hw;
+  context_split_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(x, hw, net, inp, total);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+// SE3 identity field
+__global__ void se3_identity_kernel(float* T, long long n) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  T[e] = (e % 7 == 6) ? 1.f : 0.f;
+}
+extern "C" int codd_se3_identity(float* T, long long npix, void* stream) {
+  if (!T) return CODD_EINVAL;
+  se3_identity_kernel<<<cdiv(npix * 7, 256), 256, 0, (hipStream_t)stream>>>(T, npix * 7);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}

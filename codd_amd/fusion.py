@@ -1,0 +1,90 @@
+"""Fusion on MI355X (reference model/fusion/fusion.py:41-425).
+
+The reference's "fusion" has no GRU: it is key projection, pixel-to-patch
+correlation cues, two small conv heads and a blend.  The cue tensors are produced by two fused
+kernels (csrc/fusion.hip); the heads run on the MFMA conv family.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import Slice
+from .registry import build_loss, register
+from .stereo import cv
+
+
+class BasicBlock(nn.Module):
+    """reference fusion.py:17-38 (Mish)."""
+
+    def __init__(self, c1, c2, s, p, d):
+        super().__init__()
+        self.conv1 = nn.Sequential(nn.Conv2d(c1, c2, 3, s, d if d > 1 else p, d), nn.Mish(inplace=True))
+        self.conv2 = nn.Conv2d(c2, c2, 3, 1, d if d > 1 else p, d)
+
+
+@register
+class Fusion(nn.Module):
+    def __init__(self, in_channels, fusion_channel, loss=None, corr_cfg=dict(), ds_scale=4):
+        super().__init__()
+        self.loss = build_loss(loss) if loss is not None else None
+        self.fusion_channel, self.ds_scale, self.in_channels = fusion_channel, ds_scale, in_channels
+        self.patch_size = corr_cfg.get("patch_size", 3)
+        if self.patch_size != 3 or ds_scale != 4:
+            raise NotImplementedError("the HIP cue kernels implement patch_size=3, ds_scale=4 "
+                                      "(configs/models/codd.py:82-86)")
+        fc = fusion_channel
+        self.key_layer = nn.Sequential(nn.Conv2d(in_channels, fc, 1), nn.ReLU(inplace=True),
+                                       BasicBlock(fc, fc, s=1, p=1, d=1), nn.ReLU(inplace=True), nn.Conv2d(fc, fc, 1))
+        self.conv_corr = nn.Sequential(nn.Conv2d(16 + 9 + 6, fc * 2, 1), nn.ReLU(inplace=True),
+                                       nn.Conv2d(fc * 2, fc, 1), nn.ReLU(inplace=True))
+        self.conv_disp = nn.Sequential(nn.Conv2d(2, fc, 7, padding=3), nn.ReLU(inplace=True),
+                                       nn.Conv2d(fc, fc, 3, padding=1), nn.ReLU(inplace=True))
+        self.motion_conv = nn.Sequential(nn.Conv2d(fc * 2, fc - 2, 7, padding=3), nn.ReLU(inplace=True))
+        self.weight_head = nn.Sequential(nn.Conv2d(fc, fc, 3, padding=1), nn.Conv2d(fc, 1, 1), nn.Identity(),
+                                         nn.Sigmoid())
+        self.forget_head = nn.Sequential(nn.Conv2d(6 + 16 + 9 + 1, 16, 1), nn.Conv2d(16, 8, 3, padding=1),
+                                         nn.Conv2d(8, 1, 1), nn.Identity(), nn.Sigmoid())
+        self.residual_conv = nn.Sequential(nn.Conv2d(fc * 2, fc, 3, padding=1), nn.ReLU(inplace=True))
+
+    def _key(self, x):
+        """reference fusion.py:74-80."""
+        k = self.key_layer
+        t = cv(k[0], x, act="relu")
+        u = cv(k[2].conv1[0], t, act="mish")
+        u = cv(k[2].conv2, u, res1=t, act="relu")  # relu(block(t)) : key_layer[3] fused
+        return cv(k[4], u)
+
+    def memory_query(self, outputs, state, *args, **kwargs):
+        """reference fusion.py:357-402."""
+        left_feat, pred_curr = outputs["left_feat"], outputs["pred_disp"]
+        feat_curr = self._key(left_feat)
+        if "memory" not in state:
+            outputs["left_feat"] = feat_curr
+            return
+        _, feat_warp, conf_warp, pred_warp, flow_warp = [t.contiguous() for t in state["memory"]]
+        fea_l, fea_r = outputs["left_feat"].contiguous(), outputs["right_feat"].contiguous()
+        B, _, H, W = pred_curr.shape
+        fc = self.fusion_channel
+        # [mo (fc-2) | pc | pw] : second half of residual_conv's input (reference fuse(), :343-346)
+        tail = torch.empty(B, fc, H // 4, W // 4, device=pred_curr.device, dtype=torch.float32)
+        corr_feat = ops.fusion_cues_lr(pred_curr, pred_warp, feat_curr, feat_warp, fea_l, fea_r, Slice(tail, fc - 2, 2))
+        corr = cv(self.conv_corr[2], cv(self.conv_corr[0], corr_feat, act="relu"), act="relu")
+        disp = cv(self.conv_disp[0], Slice(tail, fc - 2, 2), act="relu")
+        disp = cv(self.conv_disp[2], disp, act="relu")
+        cv(self.motion_conv[0], corr, x2=disp, act="relu", out=Slice(tail, 0, fc - 2))
+        net = cv(self.residual_conv[0], feat_curr, x2=tail, act="relu", post=corr)
+        wf_lr = cv(self.weight_head[1], cv(self.weight_head[0], net), act="sigmoid")
+        cues_fr = ops.fusion_cues_fr(pred_curr, pred_warp, flow_warp, conf_warp)
+        t = cv(self.forget_head[1], cv(self.forget_head[0], cues_fr))
+        wr = cv(self.forget_head[2], t, act="sigmoid")
+        fused, wf, wr = ops.fusion_blend(pred_curr, pred_warp, wf_lr, wr, self.ds_scale)
+        outputs["pred_disp"] = fused
+        outputs["fusion_weights"] = wf
+        outputs["reset_weights"] = wr
+        outputs["pred_curr"] = pred_curr
+        outputs["pred_warp"] = pred_warp
+        outputs["left_feat"] = feat_curr
+
+    def memory_update(self, outputs, state, *args, **kwargs):
+        """reference fusion.py:404-410."""
+        state["memory"] = [outputs["left_img"], outputs["left_feat"], outputs["pred_disp"].squeeze(1)]

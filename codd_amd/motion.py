@@ -1,0 +1,216 @@
+"""Motion + RAFT3D on MI355X.
+
+reference: model/motion/motion.py:48-209, model/motion/raft3d/raft3d.py:44-280,
+blocks/{extractor,gru,corr}.py, se3_field.py, projective_ops.py.  The lietorch / lietorch_extras /
+pytorch3d CUDA ops of the reference are replaced by the HIP kernels in csrc/motion.hip; an SE3
+field is a plain float tensor [B, H, W, 7] = (t, q_xyzw).
+
+Per-iteration schedule (16x per frame): geometry -> pyramid lookup -> flow/corr encoders ->
+ConvGRU (z|r as one 256-channel conv pair, q) -> one 1024-channel head conv + four 1x1 heads ->
+Gauss-Newton step.  Attribute names equal the reference's, so checkpoints load by key.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .hrnet import ResizeConcatConv
+from .ops import Slice
+from .registry import MODELS, build_backbone, build_loss, register
+from .stereo import cv, packed
+
+BF_DEFAULT = 1050 * 0.2  # reference motion.py:45
+
+_PCAT = {}
+
+
+def packed_cat(mods):
+    """One PackedConv whose output channels are the concatenation of several same-shape convs."""
+    key = tuple(id(m) for m in mods)
+    ver = tuple((m.weight.data_ptr(), m.weight._version, m.bias._version) for m in mods)
+    ent = _PCAT.get(key)
+    if ent is None or ent[0] != ver:
+        w = torch.cat([m.weight.detach() for m in mods], 0)
+        b = torch.cat([m.bias.detach() for m in mods], 0)
+        ent = (ver, ops.PackedConv(w, b))
+        _PCAT[key] = ent
+    return ent[1]
+
+
+# ------------------------------------------------------------------------------------- encoder
+class ResidualBlock(nn.Module):
+    """reference blocks/extractor.py:9-58 (norm_fn='instance': no affine parameters)."""
+
+    def __init__(self, in_planes, planes, norm_fn="instance", stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_planes, planes, 3, padding=1, stride=stride)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1)
+        self.downsample = None if stride == 1 else nn.Sequential(nn.Conv2d(in_planes, planes, 1, stride=stride))
+
+    def run(self, x):
+        y = ops.instnorm(cv(self.conv1, x), relu=True)
+        y = ops.instnorm(cv(self.conv2, y), relu=True)
+        if self.downsample is not None:
+            x = ops.instnorm(cv(self.downsample[0], x), relu=False)
+        return ops.add_relu(x, y, relu=True)
+
+
+class BasicEncoder(nn.Module):
+    """reference blocks/extractor.py:119-199."""
+
+    def __init__(self, output_dim=128, norm_fn="instance", dropout=0.0):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3)
+        self.layer1 = nn.Sequential(ResidualBlock(64, 64), ResidualBlock(64, 64))
+        self.layer2 = nn.Sequential(ResidualBlock(64, 96, stride=2), ResidualBlock(96, 96))
+        self.layer3 = nn.Sequential(ResidualBlock(96, 128, stride=2), ResidualBlock(128, 128))
+        self.conv2 = nn.Conv2d(128, output_dim, 1)
+
+    def forward(self, x):
+        x = ops.instnorm(cv(self.conv1, x), relu=True)
+        for layer in (self.layer1, self.layer2, self.layer3):
+            for blk in layer:
+                x = blk.run(x)
+        return cv(self.conv2, x)
+
+
+# ------------------------------------------------------------------------------------- update block
+class ConvGRU(nn.Module):
+    """reference blocks/gru.py:9-35."""
+
+    def __init__(self, hidden_dim=128, dilation=4):
+        super().__init__()
+        for g in "zrq":
+            setattr(self, f"conv{g}1", nn.Conv2d(hidden_dim, hidden_dim, 3, padding=1))
+            setattr(self, f"conv{g}2", nn.Conv2d(hidden_dim, hidden_dim, 3, dilation=dilation, padding=dilation))
+
+    def run(self, h, isum):
+        """isum [B,384,h,w] = inp + cor + mot (z | r | q thirds)."""
+        t = ops.conv2d(h, packed_cat((self.convz1, self.convr1)), pad=1)
+        zr = ops.conv2d(h, packed_cat((self.convz2, self.convr2)), pad=4, dil=4, act="sigmoid", res1=t,
+                        res2=Slice(isum, 0, 256))
+        rh = ops.gru_rh(zr, h)
+        t = cv(self.convq1, rh)
+        q = cv(self.convq2, rh, act="tanh", res1=t, res2=Slice(isum, 256, 128))
+        return ops.gru_out(zr, q, h)
+
+
+def _head(cout):
+    return nn.Sequential(nn.Conv2d(128, 256, 3, padding=1), nn.ReLU(inplace=True), nn.Conv2d(256, cout, 1))
+
+
+class BasicUpdateBlock(nn.Module):
+    """reference raft3d.py:44-106."""
+
+    def __init__(self, hidden_dim=128, input_dim=128):
+        super().__init__()
+        self.gru = ConvGRU(hidden_dim)
+        self.corr_enc = nn.Sequential(nn.Conv2d(196, 256, 3, padding=1), nn.ReLU(inplace=True),
+                                      nn.Conv2d(256, 256, 3, padding=1), nn.ReLU(inplace=True),
+                                      nn.Conv2d(256, 384, 1))
+        self.flow_enc = nn.Sequential(nn.Conv2d(9, 128, 7, padding=3), nn.ReLU(inplace=True), nn.Conv2d(128, 384, 1))
+        self.ae = _head(32)
+        self.delta = _head(3)
+        self.weight = _head(3)
+        self.mask = _head(576)
+
+    def run(self, net, inp, corr, minfo, need_mask):
+        cor = cv(self.corr_enc[0], corr, act="relu")
+        cor = cv(self.corr_enc[2], cor, act="relu")
+        isum = cv(self.corr_enc[4], cor, res1=inp)  # inp + cor
+        mot = cv(self.flow_enc[0], minfo, act="relu")
+        isum = cv(self.flow_enc[2], mot, res1=isum)  # (inp + cor) + mot
+        net = self.gru.run(net, isum)
+        hid = ops.conv2d(net, packed_cat((self.ae[0], self.mask[0], self.delta[0], self.weight[0])), pad=1,
+                         act="relu")
+        ae = cv(self.ae[2], Slice(hid, 0, 256))
+        mask = cv(self.mask[2], Slice(hid, 256, 256)) if need_mask else None
+        delta = cv(self.delta[2], Slice(hid, 512, 256))
+        weight = cv(self.weight[2], Slice(hid, 768, 256), act="sigmoid")
+        return net, mask, ae, delta, weight
+
+
+@register
+class RAFT3D(nn.Module):
+    """reference raft3d.py:140-280 (inference branch)."""
+
+    def __init__(self, cnet_cfg=None):
+        super().__init__()
+        self.hidden_dim = self.context_dim = 128
+        self.corr_levels, self.corr_radius = 4, 3
+        self.fnet = BasicEncoder(output_dim=128, norm_fn="instance")
+        if cnet_cfg is None:
+            raise NotImplementedError("the reference's FPN fallback is undefined upstream; pass cnet_cfg")
+        cfg = dict(cnet_cfg)
+        self.cnet = nn.Sequential(build_backbone(cfg),
+                                  ResizeConcatConv(cfg["extra"]["stage4"]["num_channels"], 128 * 4))
+        self.update_block = BasicUpdateBlock(hidden_dim=128)
+
+    def context(self, image):
+        return self.cnet[1](self.cnet[0](image))
+
+    def forward(self, image_curr, depth_prev, depth_curr, intrinsics, state, outputs, iters=12, train_mode=False):
+        if "memory" not in state:
+            state["raft_feat"] = self.fnet(image_curr)
+            state["raft_netinp"] = self.context(image_curr)
+            return
+        B, _, H, W = image_curr.shape
+        h, w = H // 8, W // 8
+        K = [np.float32(v) for v in intrinsics]
+        K8 = [float(v / np.float32(8.0)) for v in K]
+        fmap_prev, net_inp = state["raft_feat"], state["raft_netinp"]
+        T = ops.se3_identity(B, h, w, image_curr.device)
+        fmap_curr = self.fnet(image_curr)
+        pyr = ops.allpairs_corr(fmap_prev, fmap_curr)
+        net, inp = ops.context_split(net_inp)
+        d1 = depth_prev[:, 3::8, 3::8].contiguous()
+        d2 = depth_curr[:, 3::8, 3::8].contiguous()
+        mask = weight = None
+        for it in range(iters):
+            xyz, minfo = ops.raft_geometry(T, d1, d2, K8)
+            corr = ops.corr_lookup(pyr, xyz, h, w)
+            net, mask, ae, delta, weight = self.update_block.run(net, inp, corr, minfo, need_mask=it == iters - 1)
+            ops.se3_gn_step(T, ae, xyz, delta, weight, d1, K8, radius=32)
+        T_up = ops.cvx_upsample(T, mask, 1)
+        outputs["Ts"] = T_up
+        outputs["weight"] = ops.cvx_upsample(weight, mask, 2)
+        state["raft_feat"] = fmap_curr
+        state["raft_netinp"] = self.context(image_curr)
+
+
+@register
+class Motion(nn.Module):
+    """reference motion.py:48-209."""
+
+    def __init__(self, raft3d=None, ds_scale=4, iters=16, loss=None):
+        super().__init__()
+        self.ds_scale = ds_scale
+        self.iters = iters
+        self.raft3d = MODELS.build(raft3d)
+        self.loss = build_loss(loss) if loss is not None else None
+
+    def forward(self, state, outputs, img_metas, train_mode=False, **kwargs):
+        img_curr = outputs["left_img"]
+        if "memory" not in state:
+            self.raft3d(img_curr, None, None, None, state, outputs, train_mode=train_mode)
+            return
+        intr = [np.float32(v) for v in img_metas[0]["intrinsics"]]
+        fx = intr[0]
+        bf = float(np.float32(np.float32(BF_DEFAULT) / fx) * fx)  # depth_scale * fx in fp32 (motion.py:154-159)
+        K = [float(v) for v in intr]
+        img_prev, feat_prev, disp_prev = state["memory"]
+        disp_curr = outputs["pred_disp"]
+        depth_prev = ops.disp_to_depth(disp_prev.contiguous(), bf)  # [B,H,W]
+        depth_curr = ops.disp_to_depth(disp_curr, bf).squeeze(1)
+        self.raft3d(img_curr, depth_prev, depth_curr, intr, state, outputs, iters=self.iters, train_mode=train_mode)
+        T_up = outputs["Ts"]
+        B, H, W = depth_prev.shape
+        # full-resolution warp of [img_prev | induced flow | confidence]; depth -> disparity fused
+        warped, disp_warp = ops.splat(T_up, depth_prev, img_prev, outputs["weight"], True, H, W, 0, 0, 1, K, 2.0,
+                                      bf=bf, cap=16)
+        # 1/ds-resolution feature warp with T, depth sampled at [o::ds, o::ds] and K / ds
+        ds, o = self.ds_scale, self.ds_scale // 2 - 1
+        Kd = [float(v / np.float32(ds)) for v in intr]
+        feat_warp, _ = ops.splat(T_up, depth_prev, feat_prev, None, False, H // ds, W // ds, o, o, ds, Kd, 4.0,
+                                 cap=48)
+        state["memory"] = [warped[:, :3], feat_warp, warped[:, 6:], disp_warp, warped[:, 3:6]]

@@ -201,3 +201,201 @@ def hyp_select(upd, cur, prev, out):
     _abi.check(lib.codd_hyp_select(upd.data_ptr(), _view(cur), _view(prev), B, hh, ww, os_.buf.data_ptr(),
                                    os_.buf.shape[1], os_.coff, _stream()), "hyp_select")
     return out
+
+
+# ----------------------------------------------------------------------------------------- motion
+def _f32(*shape, like):
+    return torch.empty(*shape, device=like.device, dtype=torch.float32)
+
+
+def instnorm(x, relu=True, res=None):
+    lib = _abi.load()
+    _require_gpu(x)
+    B, Cc, H, W = x.shape
+    stats = _f32(2 * B * Cc, like=x)
+    y = torch.empty_like(x)
+    _abi.check(lib.codd_instnorm(x.data_ptr(), B, Cc, H * W, stats.data_ptr(),
+                                 None if res is None else res.data_ptr(), int(relu), y.data_ptr(), _stream()),
+               "instnorm")
+    return y
+
+
+def allpairs_corr(f1, f2):
+    """-> 4 pyramid levels [B, h*w, (h>>i)*(w>>i)]."""
+    lib = _abi.load()
+    _require_gpu(f1)
+    B, D, h, w = f1.shape
+    lv = [_f32(B, h * w, (h >> i) * (w >> i), like=f1) for i in range(4)]
+    scratch = _f32(lib.codd_allpairs_corr_scratch(B, D, h, w), like=f1)
+    _abi.check(lib.codd_allpairs_corr(f1.data_ptr(), f2.data_ptr(), B, D, h, w, lv[0].data_ptr(), lv[1].data_ptr(),
+                                      lv[2].data_ptr(), lv[3].data_ptr(), scratch.data_ptr(), _stream()),
+               "allpairs_corr")
+    return lv
+
+
+def corr_lookup(pyr, coords, h, w, out=None):
+    """coords [B,h,w,>=2] (x,y,...) -> [B,196,h,w]."""
+    lib = _abi.load()
+    B = coords.shape[0]
+    if out is None:
+        out = _f32(B, 196, h, w, like=coords)
+    _abi.check(lib.codd_corr_lookup(pyr[0].data_ptr(), pyr[1].data_ptr(), pyr[2].data_ptr(), pyr[3].data_ptr(),
+                                    coords.data_ptr(), coords.shape[-1], B, h, w, out.data_ptr(), _stream()),
+               "corr_lookup")
+    return out
+
+
+def raft_geometry(T, d1, d2, K8):
+    lib = _abi.load()
+    B, h, w, _ = T.shape
+    xyz = _f32(B, h, w, 3, like=T)
+    minfo = _f32(B, 9, h, w, like=T)
+    _abi.check(lib.codd_raft_geometry(T.data_ptr(), d1.data_ptr(), d2.data_ptr(), B, h, w, *K8, xyz.data_ptr(),
+                                      minfo.data_ptr(), _stream()), "raft_geometry")
+    return xyz, minfo
+
+
+def se3_gn_step(T, ae, xyz, delta, weight, d1, K8, radius=32, lm=1e-4, ep=10.0):
+    """In-place Gauss-Newton update of the SE3 field T [B,h,w,7]."""
+    lib = _abi.load()
+    B, h, w, _ = T.shape
+    _abi.check(lib.codd_se3_gn_step(T.data_ptr(), ae.data_ptr(), ae.shape[1], xyz.data_ptr(), delta.data_ptr(),
+                                    weight.data_ptr(), d1.data_ptr(), B, h, w, *K8, radius, lm, ep, None, _stream()),
+               "se3_gn_step")
+    return T
+
+
+def cvx_upsample(data, mask, mode):
+    """mode 0: [B,h,w,D] -> [B,8h,8w,D]; 1: SE3 field [B,h,w,7]; 2: [B,D,h,w] -> [B,D,8h,8w]."""
+    lib = _abi.load()
+    if mode == 2:
+        B, D, h, w = data.shape
+        out = _f32(B, D, 8 * h, 8 * w, like=data)
+    else:
+        B, h, w, D = data.shape
+        out = _f32(B, 8 * h, 8 * w, D, like=data)
+    _abi.check(lib.codd_cvx_upsample(data.data_ptr(), mask.data_ptr(), B, h, w, D, mode, out.data_ptr(), _stream()),
+               "cvx_upsample")
+    return out
+
+
+def disp_to_depth(disp, bf):
+    lib = _abi.load()
+    out = torch.empty_like(disp)
+    _abi.check(lib.codd_disp_to_depth(disp.data_ptr(), disp.numel(), float(bf), out.data_ptr(), _stream()),
+               "disp_to_depth")
+    return out
+
+
+def splat(T, depth, featA, featB, with_flow, H, W, oy, ox, ds, K, radius, bf=0.0, cap=32):
+    """T [B,HT,WT,7], depth [B,HT,WT] sampled at (oy+ds*y, ox+ds*x) -> (out [B,C,H,W], z [B,1,H,W])."""
+    lib = _abi.load()
+    B, HT, WT, _ = T.shape
+    CA = 0 if featA is None else featA.shape[1]
+    CB = 0 if featB is None else featB.shape[1]
+    Cc = CA + (3 if with_flow else 0) + CB
+    out = _f32(B, Cc, H, W, like=T)
+    z = _f32(B, 1, H, W, like=T)
+    scratch = torch.empty(B * H * W * (1 + cap), device=T.device, dtype=torch.int32)
+    _abi.check(lib.codd_splat(T.data_ptr(), depth.data_ptr(), HT, WT, oy, ox, ds,
+                              None if featA is None else featA.data_ptr(), CA,
+                              None if featB is None else featB.data_ptr(), CB, int(with_flow), B, H, W, *K,
+                              float(radius), float(bf), out.data_ptr(), z.data_ptr(), scratch.data_ptr(), cap,
+                              _stream()), "splat")
+    return out, z
+
+
+def induced_flow(T, depth, K):
+    lib = _abi.load()
+    B, H, W, _ = T.shape
+    out = _f32(B, H, W, 3, like=T)
+    _abi.check(lib.codd_induced_flow(T.data_ptr(), depth.data_ptr(), B, H, W, *K, out.data_ptr(), _stream()),
+               "induced_flow")
+    return out
+
+
+def context_split(x):
+    lib = _abi.load()
+    B, _, h, w = x.shape
+    net, inp = _f32(B, 128, h, w, like=x), _f32(B, 384, h, w, like=x)
+    _abi.check(lib.codd_context_split(x.data_ptr(), B, h * w, net.data_ptr(), inp.data_ptr(), _stream()),
+               "context_split")
+    return net, inp
+
+
+def se3_identity(B, h, w, device):
+    lib = _abi.load()
+    T = torch.empty(B, h, w, 7, device=device, dtype=torch.float32)
+    _abi.check(lib.codd_se3_identity(T.data_ptr(), B * h * w, _stream()), "se3_identity")
+    return T
+
+
+def resize_bilinear(x, size, align_corners, out=None, accumulate=False, relu=False):
+    lib = _abi.load()
+    B, Cc, Hi, Wi = x.shape
+    Ho, Wo = size
+    if out is None:
+        out = _f32(B, Cc, Ho, Wo, like=x)
+    os_ = _as_slice(out)
+    _abi.check(lib.codd_resize_bilinear(x.data_ptr(), B, Cc, Hi, Wi, Ho, Wo, int(align_corners), os_.buf.data_ptr(),
+                                        os_.buf.shape[1], os_.coff, int(accumulate), int(relu), _stream()),
+               "resize_bilinear")
+    return out
+
+
+def add_relu(a, b=None, relu=True, out=None):
+    lib = _abi.load()
+    if out is None:
+        out = torch.empty_like(a)
+    _abi.check(lib.codd_add_relu(a.data_ptr(), None if b is None else b.data_ptr(), a.numel(), int(relu),
+                                 out.data_ptr(), _stream()), "add_relu")
+    return out
+
+
+def gru_rh(zr, h):
+    lib = _abi.load()
+    rh = torch.empty_like(h)
+    _abi.check(lib.codd_gru_rh(zr.data_ptr(), h.data_ptr(), h.shape[0], h.shape[2] * h.shape[3], rh.data_ptr(),
+                               _stream()), "gru_rh")
+    return rh
+
+
+def gru_out(zr, q, h):
+    lib = _abi.load()
+    ho = torch.empty_like(h)
+    _abi.check(lib.codd_gru_out(zr.data_ptr(), q.data_ptr(), h.data_ptr(), h.shape[0], h.shape[2] * h.shape[3],
+                                ho.data_ptr(), _stream()), "gru_out")
+    return ho
+
+
+# ----------------------------------------------------------------------------------------- fusion
+def fusion_cues_lr(pred_curr, pred_warp, feat_curr, feat_warp, fea_l, fea_r, dsub):
+    """-> corr_feat [B,31,H/4,W/4]; writes (pc, pw) sub-sampled into the 2-channel Slice ``dsub``."""
+    lib = _abi.load()
+    B, _, H, W = pred_curr.shape
+    corr = _f32(B, 31, H // 4, W // 4, like=pred_curr)
+    ds_ = _as_slice(dsub)
+    _abi.check(lib.codd_fusion_cues_lr(pred_curr.data_ptr(), pred_warp.data_ptr(), feat_curr.data_ptr(),
+                                       feat_warp.data_ptr(), fea_l.data_ptr(), fea_r.data_ptr(), B, H, W,
+                                       feat_curr.shape[1], fea_l.shape[1], corr.data_ptr(), ds_.buf.data_ptr(),
+                                       ds_.buf.shape[1], ds_.coff, _stream()), "fusion_cues_lr")
+    return corr
+
+
+def fusion_cues_fr(pred_curr, pred_warp, flow_warp, conf_warp):
+    lib = _abi.load()
+    B, _, H, W = pred_curr.shape
+    out = _f32(B, 32, H, W, like=pred_curr)
+    _abi.check(lib.codd_fusion_cues_fr(pred_curr.data_ptr(), pred_warp.data_ptr(), flow_warp.data_ptr(),
+                                       conf_warp.data_ptr(), B, H, W, out.data_ptr(), _stream()), "fusion_cues_fr")
+    return out
+
+
+def fusion_blend(pred_curr, pred_warp, wf_lr, wr, ds=4):
+    lib = _abi.load()
+    B, _, H, W = pred_curr.shape
+    fused, wf, wro = torch.empty_like(pred_curr), torch.empty_like(pred_curr), torch.empty_like(pred_curr)
+    _abi.check(lib.codd_fusion_blend(pred_curr.data_ptr(), pred_warp.data_ptr(), wf_lr.data_ptr(), wr.data_ptr(),
+                                     B, H, W, ds, fused.data_ptr(), wf.data_ptr(), wro.data_ptr(), _stream()),
+               "fusion_blend")
+    return fused, wf, wro

@@ -83,6 +83,10 @@ long long codd_conv2d_packed_size(int Cout, int Cin, int kh, int kw, int mb, int
 /* w: [Cout][Cin][kh][kw] device pointer -> wpacked (device).  Runs on `stream`. */
 int codd_conv2d_pack_weights(const float* w, float* wpacked, int Cout, int Cin, int kh, int kw,
                              int mb, int ck, void* stream);
+/* generalised: element (co, ci, tap) is read from w[co*co_stride + ci*ci_stride + tap] and scaled. */
+int codd_conv2d_pack_weights_ex(const float* w, float* wpacked, int Cout, int Cin, int kh, int kw,
+                                int mb, int ck, long long co_stride, long long ci_stride, float scale,
+                                void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stereo (HITNetMF)
@@ -126,10 +130,15 @@ int codd_instnorm(const float* x, int B, int C, int HW, float* stats, const floa
                   float* y, void* stream);
 
 /* All-pairs correlation pyramid (CorrBlock.__init__/corr, blocks/corr.py:28-45,56-62):
- * lvl0[n1,n2] = <f1[:,n1], f2[:,n2]> / 16, lvl_{i+1} = avg_pool2d(lvl_i, 2) over (y2,x2).
+ * lvl0[n1,n2] = <f1[:,n1], f2[:,n2]> / 16, lvl_{i+1} = avg_pool2d(lvl_i, 2) over (y2,x2), computed by
+ * linearity as <f1, avg_pool^i(f2)> / 16 so the 300 MB level-0 volume is never re-read.
  * f1,f2 [B,D,h,w]; lvl_i [B,h*w,(h>>i)*(w>>i)]. */
 int codd_allpairs_corr(const float* f1, const float* f2, int B, int D, int h, int w,
-                       float* lvl0, float* lvl1, float* lvl2, float* lvl3, void* stream);
+                       float* lvl0, float* lvl1, float* lvl2, float* lvl3, float* scratch, void* stream);
+/* floats of `scratch` codd_allpairs_corr needs (packed f1 + pooled f2 levels) */
+long long codd_allpairs_corr_scratch(int B, int D, int h, int w);
+/* avg_pool2d(kernel 2, stride 2, floor): in [BC,h,w] -> out [BC,h/2,w/2] */
+int codd_avgpool2(const float* in, int BC, int h, int w, float* out, void* stream);
 
 /* Pyramid lookup (lietorch_extras.corr_index_forward, call site blocks/corr.py:10-18,47-54):
  * out[b, l*49 + i*7 + j, y, x] = bilinear(lvl_l[b,y,x,:,:], (cx/2^l - 3 + i, cy/2^l - 3 + j)), zero
@@ -171,11 +180,21 @@ int codd_disp_to_depth(const float* disp, long long n, float bf, float* depth, v
  *   feat channels = concat(featA [CA], flow(3, computed when with_flow), featB [CB]);
  *   out [B,C,H,W], zout [B,1,H,W] (nearest z, 0 when empty) or disparity when bf > 0:
  *   disp = bf/(z+1e-5), > W -> 0 (motion.py:190-193).
- * scratch: (H*W*(1+8*2)) ints per batch item. */
+ * scratch: B*H*W*(1+cap) ints; cap = candidate-list capacity per pixel (>= 8). */
 int codd_splat(const float* T, const float* depth, int HT, int WT, int oy, int ox, int ds,
                const float* featA, int CA, const float* featB, int CB, int with_flow,
                int B, int H, int W, float fx, float fy, float cx, float cy, float radius,
-               float bf, float* out, float* zout, float* flow_out, int* scratch, void* stream);
+               float bf, float* out, float* zout, int* scratch, int cap, void* stream);
+
+/* induced_flow (projective_ops.py:55-68): out [B,H,W,3] = project(T*X0) - project(X0). */
+int codd_induced_flow(const float* T, const float* depth, int B, int H, int W,
+                      float fx, float fy, float cx, float cy, float* out, void* stream);
+
+/* context split (raft3d.py:183-186): net = tanh(x[:, :128]), inp = relu(x[:, 128:512]). */
+int codd_context_split(const float* x, int B, int hw, float* net, float* inp, void* stream);
+
+/* SE3.Identity field (raft3d.py:173): T [npix, 7] = (0,0,0, 0,0,0,1). */
+int codd_se3_identity(float* T, long long npix, void* stream);
 
 /* bilinear resize (HRNet fuse layers, align_corners = 0; ResizeConcatConv, align_corners = 1):
  * out view += / = resize(in).  accumulate: 0 overwrite, 1 add; relu applied after. */

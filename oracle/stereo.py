@@ -59,6 +59,16 @@ def hitunet(sd, p, x):
 
 
 # ----------------------------------------------------------------------------- tile init
+def _l1_seq(a, b):
+    """sum_c |a - b| accumulated strictly in channel order (c = 0, 1, ...), so that mathematically
+    equal costs are bitwise equal and the systematic ties of the zero-padded region resolve to the
+    first index (torch's vectorised .sum(1) changes the association order per output element)."""
+    acc = (a[:, 0] - b[:, 0]).abs()
+    for c in range(1, a.shape[1]):
+        acc = acc + (a[:, c] - b[:, c]).abs()
+    return acc
+
+
 def tile_cost_volume_min(fl, fr, D, chunk=16):
     """Fused restatement of calc_init_disp + torch.min (reference initialization.py:18-45,
     :167-171): cv[d,y,x] = sum_c |L[c,y,x] - R~[c,y,4x-d]|, R~ = 0 outside [0, W_r);
@@ -74,7 +84,7 @@ def tile_cost_volume_min(fl, fr, D, chunk=16):
         ok = (idx >= 0) & (idx < Wr)
         g = fr[:, :, :, idx.clamp(0, Wr - 1)]  # [B,C,Ht,dc,Wt]
         g = g * ok[None, None, None].to(g.dtype)
-        cv = (fl[:, :, :, None, :] - g).abs().sum(1)  # [B,Ht,dc,Wt]
+        cv = _l1_seq(fl[:, :, :, None, :], g)  # [B,Ht,dc,Wt]
         c, a = cv.min(2)  # first minimal index inside the chunk
         upd = c < best  # strict: earlier chunk wins ties
         best = torch.where(upd, c, best)
@@ -89,7 +99,7 @@ def tile_cost_volume(fl, fr, D):
     idx = 4 * torch.arange(Wt)[None, :] - torch.arange(D)[:, None]
     ok = (idx >= 0) & (idx < Wr)
     g = fr[:, :, :, idx.clamp(0, Wr - 1)] * ok[None, None, None].to(fr.dtype)  # [B,C,Ht,D,Wt]
-    return (fl[:, :, :, None, :] - g).abs().sum(1).permute(0, 2, 1, 3).contiguous()
+    return _l1_seq(fl[:, :, :, None, :], g).permute(0, 2, 1, 3).contiguous()
 
 
 _LEVELS = ["16x", "8x", "4x", "2x", "1x"]

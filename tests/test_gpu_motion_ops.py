@@ -1,0 +1,210 @@
+"""GPU parity of the Motion / RAFT3D / Fusion kernels against the CPU oracle (fp32)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rnd(*s, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(s))
+    return torch.randn(*s, generator=g)
+
+
+def rel(a, b):
+    return (a - b).abs().max().item() / max(1e-6, b.abs().max().item())
+
+
+def test_instnorm():
+    from codd_amd import ops
+    x, r = rnd(2, 64, 36, 60) * 3 + 1, rnd(2, 64, 36, 60, seed=1)
+    ref = F.relu(F.instance_norm(x) + r)
+    got = ops.instnorm(x.to(DEV), relu=True, res=r.to(DEV)).cpu()
+    assert (got - ref).abs().max().item() < 1e-4
+
+
+def test_allpairs_and_lookup():
+    from codd_amd import ops
+    from oracle import motion as om
+    h, w = 24, 40
+    f1, f2 = rnd(1, 128, h, w), rnd(1, 128, h, w, seed=1)
+    pyr_ref = om.corr_pyramid(f1, f2)
+    pyr = ops.allpairs_corr(f1.to(DEV), f2.to(DEV))
+    for a, b in zip(pyr, pyr_ref):
+        assert rel(a.cpu().view(-1), b.reshape(-1)) < 1e-4
+    g = torch.Generator().manual_seed(5)
+    coords = torch.rand(1, h, w, 3, generator=g) * torch.tensor([w + 8.0, h + 8.0, 1.0]) - 4.0
+    coords[0, 0, 0] = torch.tensor([3.0, 2.0, 0.0])  # exact integer position
+    coords[0, 0, 1] = torch.tensor([-50.0, 1e6, 0.0])  # far outside
+    ref = om.corr_lookup(pyr_ref, coords[..., :2].permute(0, 3, 1, 2).contiguous())
+    got = ops.corr_lookup(pyr, coords.to(DEV), h, w).cpu()
+    assert got.shape == ref.shape == (1, 196, h, w)
+    assert (got - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+
+
+def _se3_field(B, h, w, scale=0.05, seed=0):
+    from oracle import se3
+    return se3.exp(rnd(B, h, w, 6, seed=seed) * scale)
+
+
+def test_raft_geometry():
+    from codd_amd import ops
+    from oracle import motion as om, se3
+    B, h, w = 1, 16, 32
+    T = _se3_field(B, h, w)
+    g = torch.Generator().manual_seed(3)
+    d1 = torch.rand(B, h, w, generator=g) * 40 + 2
+    d2 = torch.rand(B, h, w, generator=g) * 40 + 2
+    K8 = [35.0, 36.0, 16.0, 8.0]
+    Kt = torch.tensor([K8])
+    xyz_ref = om.project(se3.act(T, om.inv_project(d1, Kt)), Kt)
+    coords1, zp = xyz_ref[..., :2], xyz_ref[..., 2:]
+    zinv = om.sample_bilinear((1.0 / d2)[:, None], coords1)
+    y0, x0 = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+    c0 = torch.stack([x0, y0], -1)[None]
+    mi_ref = om.motion_info(coords1 - c0, se3.log(T), zinv.unsqueeze(-1) - zp)
+    xyz, mi = ops.raft_geometry(T.to(DEV), d1.to(DEV), d2.to(DEV), K8)
+    assert (xyz.cpu() - xyz_ref).abs().max().item() < 1e-3 * xyz_ref.abs().max().item()
+    assert (mi.cpu() - mi_ref).abs().max().item() < 2e-4 * max(1.0, mi_ref.abs().max().item())
+
+
+@pytest.mark.parametrize("h,w,radius", [(12, 20, 32), (20, 44, 6)])
+def test_se3_gn_step(h, w, radius):
+    from codd_amd import ops
+    from oracle import motion as om, se3
+    B = 1
+    T = _se3_field(B, h, w, 0.03)
+    g = torch.Generator().manual_seed(7)
+    d1 = torch.rand(B, h, w, generator=g) * 30 + 3
+    K8 = [40.0, 42.0, w / 2.0, h / 2.0]
+    Kt = torch.tensor([K8])
+    ae = rnd(B, 32, h, w, seed=2) * 4
+    xyz = om.project(se3.act(T, om.inv_project(d1, Kt)), Kt)
+    delta = rnd(B, 3, h, w, seed=3) * torch.tensor([1.0, 1.0, 0.01]).view(1, 3, 1, 1)
+    weight = torch.sigmoid(rnd(B, 3, h, w, seed=4))
+    target = (xyz.permute(0, 3, 1, 2) + delta).contiguous()
+    pts = om.inv_project(d1, Kt).permute(0, 3, 1, 2).contiguous()
+    Hm, bm = om.se3_build(T, ae / 8.0, pts, target, weight, Kt, radius=radius)
+    T_ref = se3.compose(se3.exp(om.gn_solve(Hm, bm)), T)
+    Tg = T.to(DEV).clone()
+    ops.se3_gn_step(Tg, ae.to(DEV), xyz.to(DEV), delta.to(DEV), weight.to(DEV), d1.to(DEV), K8, radius=radius)
+    err = (Tg.cpu() - T_ref).abs().max().item()
+    step = (T_ref - T).abs().max().item()
+    print("gn step size", step, "err", err)
+    assert err < 2e-4 * max(1.0, T_ref.abs().max().item()) and err < 0.02 * step
+
+
+def test_cvx_upsample():
+    from codd_amd import ops
+    from oracle import motion as om
+    B, h, w = 1, 9, 70
+    mask = rnd(B, 576, h, w) * 2
+    T = _se3_field(B, h, w, 0.2)
+    ref = om.upsample_se3(T, mask)
+    got = ops.cvx_upsample(T.to(DEV), mask.to(DEV), 1).cpu()
+    assert (got - ref).abs().max().item() < 1e-5
+    wgt = rnd(B, 3, h, w, seed=1)
+    ref = om.cvx_upsample(wgt.permute(0, 2, 3, 1), mask).permute(0, 3, 1, 2)
+    got = ops.cvx_upsample(wgt.to(DEV), mask.to(DEV), 2).cpu()
+    assert (got - ref).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("ds,radius,C", [(1, 2.0, 6), (4, 4.0, 32)])
+def test_splat(ds, radius, C):
+    from codd_amd import ops
+    from oracle import motion as om
+    B, HT, WT = 1, 64, 96
+    T = _se3_field(B, HT, WT, 0.02)
+    g = torch.Generator().manual_seed(11)
+    depth = torch.rand(B, HT, WT, generator=g) * 20 + 5
+    depth[0, 10:14, 20:30] = 0.0  # culled points
+    o = ds // 2 - 1 if ds > 1 else 0
+    H, W = HT // ds, WT // ds
+    K = [60.0 / ds, 62.0 / ds, WT / 2.0 / ds, HT / 2.0 / ds]
+    feat = rnd(B, C, H, W, seed=2)
+    Ts, ds_ = T[:, o::ds, o::ds], depth[:, o::ds, o::ds]
+    ref, zref = om.splat(Ts, ds_, feat, torch.tensor([K]), radius)
+    got, z = ops.splat(T.to(DEV), depth.to(DEV), feat.to(DEV), None, False, H, W, o, o, ds, K, radius, cap=48)
+    bad = ((got.cpu() - ref).abs().amax(1) > 1e-3).float().mean().item()
+    badz = ((z.cpu() - zref).abs() > 1e-3).float().mean().item()
+    print("splat mismatching pixels", bad, badz, "coverage", (zref > 0).float().mean().item())
+    assert bad < 1e-3 and badz < 1e-3
+    # with induced flow + disparity conversion
+    if ds == 1:
+        bf = 210.0
+        got, dsp = ops.splat(T.to(DEV), depth.to(DEV), feat[:, :3].to(DEV), feat[:, 3:].to(DEV), True, H, W, 0, 0, 1, K,
+                             radius, bf=bf, cap=16)
+        flow = om.induced_flow2d(T, depth, torch.tensor([K])).permute(0, 3, 1, 2)
+        ref, zref = om.splat(T, depth, torch.cat([feat[:, :3], flow, feat[:, 3:]], 1), torch.tensor([K]), radius)
+        dref = bf / (zref + 1e-5)
+        dref = torch.where(dref > W, torch.zeros_like(dref), dref)
+        assert ((got.cpu() - ref).abs().amax(1) > 1e-3).float().mean().item() < 1e-3
+        assert ((dsp.cpu() - dref).abs() > 1e-3 * (1 + dref.abs())).float().mean().item() < 1e-3
+
+
+def _model(iters=2):
+    import codd_amd  # noqa: F401
+    from codd_amd import configs, synth
+    from codd_amd.registry import build_estimator
+    est = build_estimator(configs.codd(iters=iters)).eval()
+    synth.load_synthetic_weights(est, gain=1.4)
+    sd = {k: v.clone() for k, v in est.state_dict().items()}
+    return est.to(DEV), sd
+
+
+def test_fnet_cnet_update_block():
+    from oracle import motion as om
+    est, sd = _model()
+    r3 = est.motion.raft3d
+    x = rnd(1, 3, 128, 192)
+    ref = om.basic_encoder(sd, "motion.raft3d.fnet", x)
+    got = r3.fnet(x.to(DEV)).cpu()
+    assert rel(got, ref) < 2e-4, rel(got, ref)
+    ref = om.hrnet_cnet(sd, "motion.raft3d.cnet", x)
+    got = r3.context(x.to(DEV)).cpu()
+    assert got.shape == ref.shape == (1, 512, 16, 24)
+    assert rel(got, ref) < 2e-4, rel(got, ref)
+    net, inp, corr, minfo = rnd(1, 128, 16, 24), rnd(1, 384, 16, 24, seed=1), rnd(1, 196, 16, 24, seed=2), \
+        rnd(1, 9, 16, 24, seed=3)
+    refs = om.update_block(sd, "motion.raft3d.update_block", net, inp, corr, minfo)
+    gots = r3.update_block.run(net.to(DEV), inp.to(DEV), corr.to(DEV), minfo.to(DEV), True)
+    for name, a, b in zip(("net", "mask", "ae", "delta", "weight"), gots, refs):
+        assert rel(a.cpu(), b) < 2e-4, (name, rel(a.cpu(), b))
+
+
+def test_fusion_query():
+    from oracle import fusion as ofu
+    est, sd = _model()
+    H, W = 64, 128
+    g = torch.Generator().manual_seed(0)
+    R = lambda *s: torch.randn(*s, generator=g)
+    pred = (R(1, 1, H, W) * 5 + 20).abs()
+    pw = (R(1, 1, H, W) * 5 + 20).abs()
+    pw[:, :, 10:20, 30:50] = 0
+    out = dict(left_feat=R(1, 24, H // 4, W // 4), right_feat=R(1, 24, H // 4, W // 4), pred_disp=pred,
+               left_img=R(1, 3, H, W))
+    mem = [R(1, 3, H, W), R(1, 32, H // 4, W // 4), torch.rand(1, 3, H, W, generator=g), pw, R(1, 3, H, W)]
+    o_ref = dict(out)
+    ofu.memory_query(sd, o_ref, dict(memory=mem))
+    o_gpu = {k: v.to(DEV) for k, v in out.items()}
+    est.fusion.memory_query(o_gpu, dict(memory=[m.to(DEV) for m in mem]))
+    for k in ("left_feat", "fusion_weights", "reset_weights", "pred_disp"):
+        assert rel(o_gpu[k].cpu(), o_ref[k]) < 2e-4, (k, rel(o_gpu[k].cpu(), o_ref[k]))
+
+
+@pytest.mark.parametrize("iters", [2])
+def test_full_codd_sequence(iters):
+    from codd_amd import synth
+    from oracle import codd as oc
+    est, sd = _model(iters)
+    H, W, MF = 128, 256, 3
+    img, r_img, _ = synth.stereo_sequence(H, W, MF)
+    metas = synth.default_metas(H, W, intrinsics=(280.0, 280.0, 128.0, 64.0))
+    ref = oc.inference(sd, img, r_img, metas, iters=iters)
+    got = est(img=[img.to(DEV)], img_metas=metas, return_loss=False, r_img=[r_img.to(DEV)], evaluate=False)[0].cpu()
+    assert got.shape == ref.shape == (1, MF, H, W)
+    for f in range(MF):
+        epe = (got[:, f] - ref[:, f]).abs().mean().item()
+        print(f"frame {f}: EPE delta {epe:.3e}  max {(got[:, f] - ref[:, f]).abs().max().item():.3e}")
+        assert epe < 1e-3
