@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""bench.py -- frames/sec of the full CODD forward (stereo -> motion -> fusion) at 960x540.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 launched with
+``python -m torch.distributed.run --nproc-per-node N ...`` (one rank per GPU, RCCL).
+
+A "step" is ONE steady-state frame (frame index >= 1, so motion and fusion run; the reference's own
+benchmark_speed.py:36-65 only ever times frame 0) of full CODD on a synthetic 960x540 stereo
+sequence reflect-free padded to 960x576 (reference pipeline pads to a multiple of 64,
+datasets/transforms.py:147-161), fp32, iters=16, max_disp=320, random-init weights
+(deterministic filler).  Inputs are resident in HBM when the timed region starts.  Each rank
+processes its own video (weak scaling; no data-path collective); the only collective is the single
+all_reduce of the [3,12] metric tensor after the timed frames, inside the timed region.
+
+Prints ONE JSON line on rank 0 (see README / task contract), including
+  roofline     -- fp32-MFMA roofline of the dominant kernel family (conv_mfma_kernel): algorithmic
+                  conv FLOPs of one frame / summed conv launch time measured with HIP events on the
+                  launch stream, vs the 157.3 TFLOP/s fp32 matrix peak;
+  cpu_baseline -- the CPU oracle (port of the reference's PyTorch-CPU path) timed on this host's
+                  cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+RAW_H, RAW_W = 540, 960
+PAD_H, PAD_W = 576, 960
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip-level parameters
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--iters", type=int, default=16)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stereo-only", action="store_true")
+    ap.add_argument("--height", type=int, default=PAD_H)
+    ap.add_argument("--width", type=int, default=PAD_W)
+    return ap.parse_args()
+
+
+def build_model(args, device):
+    import codd_amd  # noqa: F401
+    from codd_amd import configs, synth
+    from codd_amd.registry import build_estimator
+    cfg = configs.stereo_only() if args.stereo_only else configs.codd(iters=args.iters)
+    est = build_estimator(cfg).eval()
+    synth.load_synthetic_weights(est, gain=1.4)
+    return est.to(device)
+
+
+def conv_roofline(runner, frames, device):
+    """Time every conv launch of ONE extra steady-state frame (eager) with HIP events recorded on
+    the launch stream, and count its algorithmic FLOPs (2*Cin*Cout*kh*kw*Hout*Wout*B)."""
+    from codd_amd import ops
+    recs = []
+    orig = ops._launch_conv
+
+    def timed(lib, p, stream):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(torch.cuda.current_stream(device))
+        rc = orig(lib, p, stream)
+        e.record(torch.cuda.current_stream(device))
+        cout = p.Cout * (4 if p.store_mode else 1)
+        recs.append((s, e, 2.0 * (p.C0 + p.C1) * cout * p.kh * p.kw * p.Hout * p.Wout * p.B))
+        return rc
+
+    ops._launch_conv = timed
+    try:
+        l, r = frames
+        runner.eager_frame_on_static_state(l, r)
+        torch.cuda.synchronize(device)
+    finally:
+        ops._launch_conv = orig
+    t_ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+    flops = sum(f for _, _, f in recs)
+    return dict(launches=len(recs), time_ms=t_ms, gflop=flops / 1e9)
+
+
+def cpu_baseline(args):
+    """Oracle (CPU port of the reference's PyTorch path) on a bounded sample: one steady-state frame
+    of full CODD at 1/9 of the pixels (320x192), iters=16, all host cores."""
+    from codd_amd import configs, synth
+    from codd_amd.registry import build_estimator
+    from oracle import codd as oc
+    h, w = 192, 320
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    est = build_estimator(configs.stereo_only() if args.stereo_only else configs.codd(iters=args.iters)).eval()
+    synth.load_synthetic_weights(est, gain=1.4)
+    sd = est.state_dict()
+    img, r_img, _ = synth.stereo_sequence(h, w, 2)
+    intr = (1050.0 * w / PAD_W, 1050.0 * w / PAD_W, w / 2.0, h / 2.0)
+    state = {}
+    with torch.no_grad():
+        oc.frame(sd, img[:, 0], r_img[:, 0], state, intr, iters=args.iters, with_motion=not args.stereo_only,
+                 with_fusion=not args.stereo_only)
+        t0 = time.perf_counter()
+        oc.frame(sd, img[:, 1], r_img[:, 1], state, intr, iters=args.iters, with_motion=not args.stereo_only,
+                 with_fusion=not args.stereo_only)
+        dt = time.perf_counter() - t0
+    scale = (h * w) / float(PAD_H * PAD_W)
+    return dict(value=round(scale / dt, 5), unit="frames/s", cores=cores, kind="port",
+                sample=f"1 steady-state frame of the CPU oracle at {w}x{h} ({scale:.3f} of the 960x576 pixels, "
+                       f"iters={args.iters}) took {dt:.2f} s on {cores} threads; value = pixel-scaled estimate "
+                       f"for 960x576 (measured {1.0 / dt:.4f} frames/s at {w}x{h})")
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    from codd_amd import metrics, synth
+    from codd_amd.runtime import FrameRunner
+
+    est = build_model(args, device)
+    H, W = args.height, args.width
+    MF = 6  # distinct synthetic frames, cycled (frame t+1 = frame t translated by a sub-pixel flow)
+    img, r_img, gt = synth.stereo_sequence(H, W, MF)
+    img, r_img, gt = img.to(device), r_img.to(device), gt.to(device)
+    raw_h, raw_w = (RAW_H, RAW_W) if (H, W) == (PAD_H, PAD_W) else (H, W)
+    metas = synth.default_metas(H, W, img_shape=(raw_h, raw_w, 3))
+    runner = FrameRunner(est, metas, use_graph=not args.no_graph and not args.stereo_only)
+
+    def frame(i):
+        k = i % MF
+        return img[:, k].contiguous(), r_img[:, k].contiguous(), gt[:, k]
+
+    # frame 0 primes the recurrent state; then W untimed warm-up frames (graph capture happens here)
+    l, r, _ = frame(0)
+    runner.step(l, r)
+    for i in range(1, 1 + max(args.warmup, 1)):
+        l, r, _ = frame(i)
+        runner.step(l, r)
+    seqm = metrics.SequenceMetrics(metas[0][0], device)
+
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        l, r, g = frame(1 + args.warmup + i)
+        d = runner.step(l, r)
+        seqm.update(d[:, :, :raw_h, :raw_w], g[:, :, :raw_h, :raw_w])
+    red = metrics.reduce_rows([seqm.row()], device)  # the job's only collective (RCCL all_reduce)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+
+    roof = None
+    cpu = None
+    if rank == 0:
+        try:
+            l, r, _ = frame(1)
+            cr = conv_roofline(runner, (l, r), device)
+            ach = cr["gflop"] / cr["time_ms"]  # GFLOP/ms = TFLOP/s
+            roof = dict(bound="mfma", achieved=round(ach, 3), peak=FP32_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), traffic=None, kernel="conv_mfma_kernel<*>",
+                        launches_per_frame=cr["launches"], gflop_per_frame=round(cr["gflop"], 2),
+                        conv_ms_per_frame=round(cr["time_ms"], 3))
+        except Exception as e:  # pragma: no cover
+            roof = dict(error=repr(e))
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args)
+    if rank == 0:
+        fps = world * args.steps / dt
+        out = {
+            "metric": "frames/sec full CODD forward @960x540 (whole job)",
+            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("HITNetMF stereo-only" if args.stereo_only else
+                                    "full CODD (HITNetMF + Motion/RAFT3D iters=%d + Fusion)" % args.iters) +
+                                   f" {raw_w}x{raw_h} padded to {W}x{H}, max_disp=320, one video per GPU, "
+                                   "steady-state frames (idx>=1), synthetic stereo sequence, random-init weights",
+                       "hip_graph": bool(runner.graph is not None), "frames_per_gpu": args.steps,
+                       "fps_per_gpu": round(fps / world, 3)},
+            "epe_vs_synthetic_gt": red["epe"][0],
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,139 @@
+"""On-device evaluation metrics and the cross-GPU reduction.
+
+reference: model/codd.py:435-575 (calc_metric), utils/metric.py:19-54, utils/misc.py:12-36,62-77,
+utils/warp.py:69-92, utils/running_stats.py:132-183, apis/inference.py:145-154.
+
+The reference syncs the host ~10 times per frame (``.item()``) and gathers pickled Python objects
+across ranks.  Here every per-frame metric is accumulated on the device as (sum, count) pairs, a
+video's 12-column row is formed once per sequence, and ranks exchange ONE ``all_reduce(SUM)`` of a
+[3, 12] fp64 tensor (sum, sum of squares, non-NaN count per column) -- RCCL over xGMI on the GPU
+node, gloo in the CPU tests.  This is evaluation plumbing, not the hot path: torch ops are used.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+COLUMNS = ("epe", "th3", "tepe", "th3_tepe", "tepe_rel", "th1_tepe_rel", "flow_mag", "count",
+           "epe2d_scene_flow", "epe2d_optical_flow", "1px_scene_flow", "1px_optical_flow")
+BF_DEFAULT = 1050 * 0.2
+
+
+def valid_mask(gt_disp, meta, gt_flow_prev=None):
+    """reference utils/misc.py:12-36."""
+    m = (gt_disp > meta["disp_range"][0]) & (gt_disp < meta["disp_range"][1])
+    if gt_flow_prev is not None:
+        m &= torch.sum(gt_flow_prev ** 2, dim=1, keepdim=True).sqrt() < BF_DEFAULT
+    return m
+
+
+def flow_warp_nearest(img, flow):
+    """reference utils/warp.py:69-92 with padding_mode='zeros', mode='nearest'."""
+    B, _, H, W = img.shape
+    y, x = torch.meshgrid(torch.arange(H, device=img.device, dtype=img.dtype),
+                          torch.arange(W, device=img.device, dtype=img.dtype), indexing="ij")
+    gx = 2 * ((x[None] + flow[:, 0]) / (W - 1)) - 1
+    gy = 2 * ((y[None] + flow[:, 1]) / (H - 1)) - 1
+    grid = torch.stack([gx, gy], -1)
+    out = F.grid_sample(img, grid, mode="nearest", padding_mode="zeros", align_corners=True)
+    valid = F.grid_sample(torch.ones_like(img[:, :1]), grid, mode="nearest", padding_mode="zeros",
+                          align_corners=True) > 0.9999
+    return out, valid
+
+
+class _Meter:
+    """Mean of per-frame means (reference AverageMeter, utils/running_stats.py:9-31), kept on device."""
+
+    def __init__(self, device):
+        self.s = torch.zeros((), device=device, dtype=torch.float64)
+        self.n = torch.zeros((), device=device, dtype=torch.float64)
+
+    def update(self, values, mask=None):
+        """adds mean(values[mask]) if the mask is non-empty -- without a host sync."""
+        if mask is None:
+            mask = torch.ones_like(values, dtype=torch.bool)
+        cnt = mask.sum().double()
+        mean = (values.double() * mask).sum() / cnt.clamp(min=1)
+        ok = (cnt > 0).double()
+        self.s += mean * ok
+        self.n += ok
+
+    def avg(self):
+        return torch.where(self.n > 0, self.s / self.n.clamp(min=1), torch.full_like(self.s, float("nan")))
+
+
+class SequenceMetrics:
+    """Per-video metric row (disparity + temporal columns of COLUMNS)."""
+
+    def __init__(self, meta, device):
+        self.meta = meta
+        self.m = {k: _Meter(device) for k in COLUMNS[:7]}
+        self.prev = None
+        self.device = device
+
+    def update(self, pred, gt, gt_flow=None):
+        """pred, gt [B,1,h,w]; gt_flow [B,2,h,w] = flow from THIS frame to the next (reference
+        state['gt_flow'][-2] semantics when the next frame arrives)."""
+        mask = valid_mask(gt, self.meta)
+        err = (pred - gt).abs()
+        self.m["epe"].update(err, mask)
+        self.m["th3"].update((err > 3.0).to(err.dtype), mask)
+        if self.prev is not None:
+            p_pred, p_gt, p_mask, flow = self.prev
+            if flow is not None:
+                mk = valid_mask(gt, self.meta, gt_flow_prev=flow)
+                warped, valid = flow_warp_nearest(torch.cat([gt, pred, mk.to(gt.dtype)], 1), flow)
+                w_gt, w_pred, w_mask = warped[:, 0:1], warped[:, 1:2], warped[:, 2:3]
+                m_curr = valid & w_mask.bool() & mk
+                both = p_mask & m_curr
+                d_est, d_gt = w_pred - p_pred, w_gt - p_gt
+                tepe = (d_est - d_gt).abs()
+                rel = tepe / (d_gt.abs() + 1e-3)
+                self.m["tepe"].update(tepe, both)
+                self.m["tepe_rel"].update(rel, both)
+                self.m["th1_tepe_rel"].update((rel > 1.0).to(rel.dtype), both)
+                self.m["th3_tepe"].update((tepe > 3.0).to(rel.dtype), both)
+                self.m["flow_mag"].update(torch.sum(flow ** 2, dim=1).sqrt())
+        self.prev = (pred, gt, mask, gt_flow)
+
+    def row(self):
+        """[12] fp64 tensor; columns without data are NaN (reference nanmean semantics)."""
+        nan = torch.full((), float("nan"), device=self.device, dtype=torch.float64)
+        vals = [self.m[k].avg() for k in COLUMNS[:7]] + [nan] * 5
+        return torch.stack(vals)
+
+
+def reduce_rows(rows, device=None, group=None):
+    """rows: list of [12] fp64 tensors (this rank's videos).  ONE all_reduce of [3,12]
+    (sum, sum sq, non-NaN count) -> dict column -> (mean, std, n) with nanmean / nanvar semantics
+    (reference utils/running_stats.py:176-183, apis/inference.py:145-154)."""
+    import torch.distributed as dist
+    if device is None:
+        device = rows[0].device if rows else torch.device("cpu")
+    acc = torch.zeros(3, len(COLUMNS), dtype=torch.float64, device=device)
+    for r in rows:
+        r = r.to(device=device, dtype=torch.float64)
+        ok = ~torch.isnan(r)
+        v = torch.where(ok, r, torch.zeros_like(r))
+        acc[0] += v
+        acc[1] += v * v
+        acc[2] += ok.double()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+    acc = acc.cpu()
+    out = {}
+    for i, k in enumerate(COLUMNS):
+        n = acc[2, i].item()
+        if n == 0:
+            out[k] = (float("nan"), float("nan"), 0)
+            continue
+        mean = acc[0, i].item() / n
+        var = max(acc[1, i].item() / n - mean * mean, 0.0)
+        out[k] = (mean, math.sqrt(var), int(n))
+    return out
+
+
+def shard_videos(num_videos, rank, world_size):
+    """One video per GPU, round robin (what DistributedSampler(shuffle=False) gives the reference,
+    inference.py:108-115; padding duplicates are dropped instead of de-duplicated later)."""
+    return list(range(rank, num_videos, world_size))

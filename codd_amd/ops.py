@@ -84,6 +84,11 @@ class PackedConv:
         return self._packs[ck]
 
 
+def _launch_conv(lib, p, stream):
+    """Single choke point of every conv launch (bench.py wraps it with HIP events)."""
+    return lib.codd_conv2d(C.byref(p), stream)
+
+
 def _wrow(mb):
     return 16 * mb + (0 if mb & 1 else 16)
 
@@ -154,7 +159,7 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
     p.act = ACT[act]
     p.store_mode = 1 if pc.deconv else 0
     p.mb, p.npb, p.ck = pc.mb, npb, ck
-    _abi.check(lib.codd_conv2d(C.byref(p), _stream()), "codd_conv2d")
+    _abi.check(_launch_conv(lib, p, _stream()), "codd_conv2d")
     return out
 
 
