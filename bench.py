@@ -36,6 +36,14 @@ PAD_H, PAD_W = 576, 960
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip-level parameters
 
 
+_T0 = time.time()
+
+
+def log(msg):
+    if os.environ.get("CODD_BENCH_VERBOSE"):
+        print(f"[bench +{time.time() - _T0:7.2f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -44,6 +52,8 @@ def parse():
     ap.add_argument("--iters", type=int, default=16)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--stereo-only", action="store_true")
     ap.add_argument("--height", type=int, default=PAD_H)
     ap.add_argument("--width", type=int, default=PAD_W)
@@ -90,12 +100,13 @@ def conv_roofline(runner, frames, device):
 
 def cpu_baseline(args):
     """Oracle (CPU port of the reference's PyTorch path) on a bounded sample: one steady-state frame
-    of full CODD at 1/9 of the pixels (320x192), iters=16, all host cores."""
+    of full CODD at ~1/5 of the pixels (448x256), iters=16, on min(host cores, --cpu-threads) threads
+    (the 256-hardware-thread GPU host stalls torch's CPU pool when all of them are requested)."""
     from codd_amd import configs, synth
     from codd_amd.registry import build_estimator
     from oracle import codd as oc
-    h, w = 192, 320
-    cores = os.cpu_count() or 1
+    h, w = 256, 448  # multiple of 64 (the pipeline pads to 64)
+    cores = max(1, min(os.cpu_count() or 1, args.cpu_threads))
     torch.set_num_threads(cores)
     est = build_estimator(configs.stereo_only() if args.stereo_only else configs.codd(iters=args.iters)).eval()
     synth.load_synthetic_weights(est, gain=1.4)
@@ -117,8 +128,28 @@ def cpu_baseline(args):
                        f"for 960x576 (measured {1.0 / dt:.4f} frames/s at {w}x{h})")
 
 
+def cpu_baseline_subprocess(args, timeout=240):
+    """Run the CPU leg in a child process with a hard wall-clock bound so it can never stall the bench."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--iters", str(args.iters),
+           "--cpu-threads", str(args.cpu_threads)] + (["--stereo-only"] if args.stereo_only else [])
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+        return json.loads(line)
+    except subprocess.TimeoutExpired:
+        return dict(value=None, unit="frames/s", cores=args.cpu_threads, kind="port",
+                    sample=f"CPU oracle sample did not finish within {timeout} s")
+    except Exception as e:  # pragma: no cover
+        return dict(value=None, unit="frames/s", cores=args.cpu_threads, kind="port", sample=f"failed: {e!r}")
+
+
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args)), flush=True)
+        return
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -139,18 +170,23 @@ def main():
     img, r_img, gt = img.to(device), r_img.to(device), gt.to(device)
     raw_h, raw_w = (RAW_H, RAW_W) if (H, W) == (PAD_H, PAD_W) else (H, W)
     metas = synth.default_metas(H, W, img_shape=(raw_h, raw_w, 3))
-    runner = FrameRunner(est, metas, use_graph=not args.no_graph and not args.stereo_only)
+    runner = FrameRunner(est, metas[0], use_graph=not args.no_graph and not args.stereo_only)
 
     def frame(i):
         k = i % MF
         return img[:, k].contiguous(), r_img[:, k].contiguous(), gt[:, k]
 
     # frame 0 primes the recurrent state; then W untimed warm-up frames (graph capture happens here)
+    log("model built, inputs resident")
     l, r, _ = frame(0)
     runner.step(l, r)
+    torch.cuda.synchronize(device)
+    log("frame 0 done")
     for i in range(1, 1 + max(args.warmup, 1)):
         l, r, _ = frame(i)
         runner.step(l, r)
+        torch.cuda.synchronize(device)
+        log(f"warm-up frame {i} done")
     seqm = metrics.SequenceMetrics(metas[0][0], device)
 
     torch.cuda.synchronize(device)
@@ -173,6 +209,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
 
+    log(f"timed region done: {dt:.3f} s")
     roof = None
     cpu = None
     if rank == 0:
@@ -186,8 +223,10 @@ def main():
                         conv_ms_per_frame=round(cr["time_ms"], 3))
         except Exception as e:  # pragma: no cover
             roof = dict(error=repr(e))
+        log(f"roofline pass done: {roof}")
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args)
+            cpu = cpu_baseline_subprocess(args)
+            log("cpu baseline done")
     if rank == 0:
         fps = world * args.steps / dt
         out = {
