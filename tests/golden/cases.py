@@ -1,0 +1,74 @@
+"""Deterministic inputs / weights shared by the golden generator and the oracle tests (data only:
+closed-form textures and seeded torch generators -- no reference code)."""
+import torch
+
+from codd_amd import configs, synth
+
+# H >= 128: with a single tile row (H = 64) the reference normalises y by (Ht - 1) = 0 and samples NaN
+# coordinates (initialization.py:27), i.e. its own cost volume degenerates to the zero-padded value.
+STEREO_SIZES = {"s128": (128, 192), "s192": (192, 256)}
+_SD = None
+
+
+def state_dict():
+    """Synthetic weights for every parameter of the full CODD model (reference key names)."""
+    global _SD
+    if _SD is None:
+        import codd_amd  # noqa: F401
+        from codd_amd.registry import build_estimator
+        est = build_estimator(configs.codd())
+        _SD = synth.fill_state_dict(est.state_dict(), gain=1.4)
+    return _SD
+
+
+def stereo_pair(H, W):
+    img, r_img, _ = synth.stereo_sequence(H, W, 1, dmax=24.0)
+    return img[:, 0], r_img[:, 0]
+
+
+def image(H, W):
+    return stereo_pair(H, W)[0]
+
+
+def _gen(seed):
+    g = torch.Generator().manual_seed(seed)
+    return lambda *s: torch.randn(*s, generator=g)
+
+
+def fusion_case(H=64, W=128):
+    R = _gen(100)
+    pred = (R(1, 1, H, W) * 5 + 20).abs()
+    pw = (R(1, 1, H, W) * 5 + 20).abs()
+    pw[:, :, 10:20, 30:50] = 0  # holes: pred_warp == 0
+    out = dict(left_feat=R(1, 24, H // 4, W // 4), right_feat=R(1, 24, H // 4, W // 4), pred_disp=pred,
+               left_img=R(1, 3, H, W))
+    mem = [R(1, 3, H, W), R(1, 32, H // 4, W // 4), torch.sigmoid(R(1, 3, H, W)), pw, R(1, 3, H, W)]
+    return out, dict(memory=mem)
+
+
+def update_inputs(h=8, w=16):
+    R = _gen(200)
+    return R(1, 128, h, w), R(1, 384, h, w), R(1, 196, h, w), R(1, h, w, 2), R(1, h, w, 6), R(1, h, w, 1)
+
+
+def fmaps(h=16, w=24):
+    R = _gen(300)
+    return R(1, 128, h, w), R(1, 128, h, w)
+
+
+def cvx_inputs(h=8, w=16):
+    R = _gen(400)
+    return R(1, h, w, 6), R(1, 576, h, w)
+
+
+def proj_inputs(h=8, w=16):
+    g = torch.Generator().manual_seed(500)
+    depth = torch.rand(1, h, w, generator=g) * 50 + 1
+    K = torch.tensor([[100.0, 110.0, 8.0, 4.0]])
+    coords = torch.rand(1, h, w, 2, generator=g) * torch.tensor([20.0, 10.0]) - 2
+    return depth, K, coords
+
+
+def warp_inputs(h=16, w=32):
+    R = _gen(600)
+    return R(1, 24, h, w), R(1, 1, h, w).abs() * 4

@@ -1,0 +1,108 @@
+"""DEV-ONLY generator of the golden vectors (runs only in the build container, where
+/root/reference exists): imports the reference through tools/ref_import.py (mmcv / mmseg /
+lietorch / pytorch3d stubbed), feeds it the deterministic synthetic weights and inputs of
+codd_amd.synth, and stores the reference's OUTPUTS as small .npz fixtures.  Inputs and weights are
+NOT stored: tests regenerate them from the same closed-form generators (tests/golden/cases.py).
+
+    python tests/golden/make_golden.py
+
+Covers every stage of the hot path that the reference can run without its absent CUDA
+dependencies: whole HITNetMF (S0-S8), Fusion.memory_query (F0-F6), BasicEncoder (M1),
+CorrBlock.corr + pyramid (M3), BasicUpdateBlock + ConvGRU (M6), cvx_upsample (M8),
+inv_project / project / depth_sampler (M5), disp_warp.  The lietorch / pytorch3d / mmseg-HRNet
+pieces cannot be run here: parity unpinned for those.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import cases  # noqa: E402
+
+# build the synthetic weights from the product's parameter spec BEFORE the reference (and its stub
+# registry) is imported, so that the product classes are not mirrored into the stub registry.
+_SD = cases.state_dict()
+
+import ref_import  # noqa: E402
+
+ref_import.import_reference()
+from mmseg.models.builder import MODELS  # noqa: E402  (stub registry holding the reference classes)
+from model.builder import build_estimator  # noqa: E402
+from model.motion.raft3d import projective_ops as pops, se3_field  # noqa: E402
+from model.motion.raft3d.blocks.corr import CorrBlock  # noqa: E402
+from model.motion.raft3d.blocks.extractor import BasicEncoder  # noqa: E402
+from model.motion.raft3d.raft3d import BasicUpdateBlock  # noqa: E402
+from model.motion.raft3d.sampler_ops import depth_sampler  # noqa: E402
+from utils import disp_warp  # noqa: E402
+
+
+def load(module, sd, prefix):
+    sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    missing = module.load_state_dict(sub, strict=True)
+    return module.eval()
+
+
+def main():
+    sd = cases.state_dict()
+    out = {}
+    with torch.no_grad():
+        # ---- stereo: whole HITNetMF ------------------------------------------------------------
+        est = build_estimator(dict(type="ConsistentOnlineDynamicDepth", stereo=dict(
+            type="HITNetMF", backbone=dict(type="HITUNet"),
+            initialization=dict(type="TileInitialization", max_disp=320),
+            propagation=dict(type="TilePropagation"))))
+        load(est.stereo, sd, "stereo.")
+        for name, (H, W) in cases.STEREO_SIZES.items():
+            l, r = cases.stereo_pair(H, W)
+            o = est.stereo.stereo_matching(l, r)
+            out[f"stereo_{name}_pred_disp"] = o["pred_disp"]
+            out[f"stereo_{name}_left_feat"] = o["left_feat"]
+            fea_l, fea_r = est.stereo.extract_feat(l), est.stereo.extract_feat(r)
+            _, hyps = est.stereo.tile_init(fea_l, fea_r)
+            for i, h in enumerate(hyps):
+                out[f"stereo_{name}_init_d{i}"] = h[:, 0:1]
+        # ---- fusion ----------------------------------------------------------------------------
+        fus = load(MODELS.build(dict(type="Fusion", in_channels=24, fusion_channel=32,
+                                     corr_cfg=dict(type="px2patch", patch_size=3))), sd, "fusion.")
+        o, st = cases.fusion_case()
+        fus.memory_query(o, st)
+        for k in ("pred_disp", "fusion_weights", "reset_weights", "left_feat"):
+            out[f"fusion_{k}"] = o[k]
+        o1, _ = cases.fusion_case()
+        fus.memory_query(o1, {})
+        out["fusion_first_left_feat"] = o1["left_feat"]
+        # ---- RAFT3D pure-torch blocks ------------------------------------------------------------
+        fnet = load(BasicEncoder(output_dim=128, norm_fn="instance"), sd, "motion.raft3d.fnet.")
+        out["fnet"] = fnet(cases.image(64, 128))
+        ub = load(BasicUpdateBlock(), sd, "motion.raft3d.update_block.")
+        net, inp, corr, flow, twist, dz = cases.update_inputs()
+        res = ub(net, inp, corr, flow, dz, twist)  # NB reference call order (raft3d.py:238-240)
+        for k, v in zip(("net", "mask", "ae", "delta", "weight"), res):
+            out[f"update_{k}"] = v[:, ::7] if k == "mask" else v
+        f1, f2 = cases.fmaps()
+        cb = CorrBlock(f1, f2, radius=3)
+        for i, c in enumerate(cb.corr_pyramid):
+            out[f"corr_lvl{i}"] = c.reshape(c.shape[0], c.shape[1] * c.shape[2], -1)[:, ::5, ::3]
+        data, mask = cases.cvx_inputs()
+        out["cvx_upsample"] = se3_field.cvx_upsample(data, mask)[:, ::3, ::5]
+        depth, K, coords = cases.proj_inputs()
+        X = pops.inv_project(depth, K)
+        out["inv_project"] = X
+        out["project"] = pops.project(X, K)
+        out["depth_sampler"] = depth_sampler(depth, coords)[0]
+        img, disp = cases.warp_inputs()
+        out["disp_warp"] = disp_warp(img, disp, padding_mode="zeros")[0]
+    path = os.path.join(HERE, "reference_outputs.npz")
+    np.savez_compressed(path, **{k: v.detach().cpu().numpy().astype(np.float32) for k, v in out.items()})
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()
