@@ -197,114 +197,239 @@ extern "C" int codd_raft_geometry(const float* T, const float* depth1, const flo
 
 // ------------------------------------------------------------------------------------------------
 // Dense SE3 Gauss-Newton step (reference se3_field.py:150-170).
-// One wave per pixel i; lanes sweep the (2r+1)^2 neighbourhood (consecutive lanes = consecutive
-// x_j, so every per-neighbour load is a coalesced row segment), accumulate the 21 + 6 normal
-// equation sums, butterfly-reduce them, and lane 0 damps, solves (Cholesky) and retracts.
+// Workgroup = 8 waves = one 8x8 tile of pixels i (lane = pixel).  The (8+2r)^2 neighbourhood of the
+// tile is streamed row by row through LDS: wave w stages rows w, w+8, ... (coalesced global reads,
+// 44 floats per neighbour j: ae/8 (32), X_j (3), target_j (3), weight_j (3), |ae_j|^2) and every
+// lane then walks the row with BROADCAST LDS reads, accumulating its 21 + 6 normal-equation sums in
+// registers.  The 8 partial sums per pixel are combined through LDS and 64 lanes damp, solve
+// (Cholesky, fp64) and retract their pixels in parallel.
+//   a_ij = sigmoid(-|ae_i - ae_j|^2), |.|^2 expanded as |a_i|^2 + |a_j|^2 - 2 <a_i, a_j>.
 // ------------------------------------------------------------------------------------------------
 #define GN_AE 32
-__global__ __launch_bounds__(256) void se3_gn_kernel(float* __restrict__ T, const float* __restrict__ ae, int ae_c,
-                                                     const float* __restrict__ xyz, const float* __restrict__ delta,
-                                                     const float* __restrict__ wgt, const float* __restrict__ d1, int h,
-                                                     int w, float fx, float fy, float cx, float cy, int radius,
-                                                     float lm, float ep, float* __restrict__ Tout) {
+#define GN_JS 44  // floats per staged neighbour record (16-byte aligned)
+#define GN_WAVES 4
+// Work decomposition: (tile, row-group) tasks, one per WAVE (lane = pixel i of an 8x8 tile); R
+// row-groups per tile are chosen so that tiles*R fills the chip.  A pre-pass packs everything a
+// neighbour j contributes -- ae_j/8 (32), X_j (3), target_j (3), weight_j (3), |ae_j/8|^2 -- into one
+// 176-byte record; because all 64 lanes of a wave visit the same j, the main loop reads the record
+// with SCALAR loads (wave-uniform address -> s_load_dwordx*, SGPR operands feed the VALU directly):
+// no LDS, no broadcast traffic, and the loop body is branch-free so the loads pipeline.
+// Partial sums go to scratch [task][27][64]; se3_gn_solve_kernel adds the R partials of each pixel
+// in a fixed order (deterministic), damps, solves and retracts.
+__global__ void se3_gn_prep_kernel(const float* __restrict__ ae, int ae_c, const float* __restrict__ xyz,
+                                   const float* __restrict__ delta, const float* __restrict__ wgt,
+                                   const float* __restrict__ d1, int h, int w, float fx, float fy, float cx, float cy,
+                                   float* __restrict__ jd) {
+  const int N = h * w;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (j >= N) return;
+  const int yj = j / w, xj = j - yj * w;
+  const float* aeb = ae + (size_t)b * ae_c * N;
+  float* rp = jd + ((size_t)b * N + j) * GN_JS;
+  float av[GN_AE];
+#pragma unroll
+  for (int c = 0; c < GN_AE; ++c) av[c] = aeb[(size_t)min(c, ae_c - 1) * N + j];
+  float a2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < GN_AE; ++c) {
+    const float v = av[c] * (c < ae_c ? 0.125f : 0.f);
+    rp[c] = v;
+    a2 += v * v;
+  }
+  const V3 X = inv_project(d1[(size_t)b * N + j], xj, yj, fx, fy, cx, cy);
+  const float* xb = xyz + ((size_t)b * N + j) * 3;
+  const float* db = delta + (size_t)b * 3 * N + j;
+  const float* wb = wgt + (size_t)b * 3 * N + j;
+  rp[32] = X.x; rp[33] = X.y; rp[34] = X.z;
+  rp[35] = xb[0] + db[0]; rp[36] = xb[1] + db[N]; rp[37] = xb[2] + db[2 * N];
+  rp[38] = wb[0]; rp[39] = wb[N]; rp[40] = wb[2 * N];
+  rp[41] = a2; rp[42] = 0.f; rp[43] = 0.f;
+}
+
+__global__ __launch_bounds__(64 * GN_WAVES) void se3_gn_build_kernel(
+    const float* __restrict__ T, const float* __restrict__ jd, int h, int w, float fx, float fy, float cx, float cy,
+    int radius, int tiles_x, int ntiles, int R, float* __restrict__ part) {
   const int N = h * w;
   const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.y;
-  if (i >= N) return;
-  const int yi = i / w, xi = i - yi * w;
+  const int task = blockIdx.x * GN_WAVES + wave;
+  if (task >= ntiles * R) return;
+  const int tile = task / R, rg = task - tile * R;
+  const int tx0 = (tile % tiles_x) * 8, ty0 = (tile / tiles_x) * 8;
+  const int xi = tx0 + (lane & 7), yi = ty0 + (lane >> 3);
+  const bool vi = xi < w && yi < h;
+  const int i = vi ? yi * w + xi : 0;
+  // rows / columns of the tile's neighbourhood, clipped to the image (all wave-uniform)
+  const int ylo = max(ty0 - radius, 0), yhi = min(ty0 + 7 + radius, h - 1);
+  const int xlo = max(tx0 - radius, 0), xhi = min(tx0 + 7 + radius, w - 1);
+  const int nrows = yhi - ylo + 1;
+  const int r0 = ylo + (int)((long long)nrows * rg / R), r1 = ylo + (int)((long long)nrows * (rg + 1) / R);
+
+  const float* rec = jd + (size_t)b * N * GN_JS;
+  const float* aip = rec + (size_t)i * GN_JS;
   const SE3T Ti = se3_load(T + ((size_t)b * N + i) * 7);
-  const float* aeb = ae + (size_t)b * ae_c * N;
+  // rotation matrix of T_i: Y = [c0 c1 c2] X + t
+  const V3 c0 = qrot(Ti.q, V3{1.f, 0.f, 0.f}), c1 = qrot(Ti.q, V3{0.f, 1.f, 0.f}), c2 = qrot(Ti.q, V3{0.f, 0.f, 1.f});
   float ai[GN_AE];
 #pragma unroll
-  for (int c = 0; c < GN_AE; ++c) ai[c] = c < ae_c ? aeb[(size_t)c * N + i] * 0.125f : 0.f;
+  for (int c = 0; c < GN_AE; ++c) ai[c] = aip[c];
+  const float ai2 = aip[41];
   float Hs[21], bs[6];
 #pragma unroll
   for (int k = 0; k < 21; ++k) Hs[k] = 0.f;
 #pragma unroll
   for (int k = 0; k < 6; ++k) bs[k] = 0.f;
-  const int y0 = max(yi - radius, 0), y1 = min(yi + radius, h - 1);
-  const int x0 = max(xi - radius, 0), x1 = min(xi + radius, w - 1);
-  const int ww = x1 - x0 + 1, cnt = ww * (y1 - y0 + 1);
-  const float* xb = xyz + (size_t)b * N * 3;
-  const float* db = delta + (size_t)b * 3 * N;
-  const float* wb = wgt + (size_t)b * 3 * N;
-  const float* dd = d1 + (size_t)b * N;
-  for (int e = lane; e < cnt; e += 64) {
-    const int ry = e / ww, yj = y0 + ry, xj = x0 + (e - ry * ww);
-    const int j = yj * w + xj;
-    float d2 = 0.f;
+
+  for (int yj = r0; yj < r1; ++yj) {
+    const bool rowin = vi && abs(yj - yi) <= radius;
+    const float* rrow = rec + (size_t)yj * w * GN_JS;
+    for (int xj = xlo; xj <= xhi; ++xj) {
+      const float* rp = rrow + (size_t)xj * GN_JS;  // wave-uniform address -> scalar loads
+      const float Xx = rp[32], Xy = rp[33], Xz = rp[34];
+      const float Yx = c0.x * Xx + c1.x * Xy + c2.x * Xz + Ti.t.x;
+      const float Yy = c0.y * Xx + c1.y * Xy + c2.y * Xz + Ti.t.y;
+      const float Yz = c0.z * Xx + c1.z * Xy + c2.z * Xz + Ti.t.z;
+      const bool in = rowin && abs(xj - xi) <= radius && Xz >= MIN_DEPTH && Yz >= MIN_DEPTH;
+      float dot = 0.f;
 #pragma unroll
-    for (int c = 0; c < GN_AE; ++c) {
-      if (c < ae_c) { const float df = ai[c] - aeb[(size_t)c * N + j] * 0.125f; d2 += df * df; }
-    }
-    const V3 X = inv_project(dd[j], xj, yj, fx, fy, cx, cy);
-    const V3 Y = se3_act(Ti, X);
-    if (!(X.z >= MIN_DEPTH) || !(Y.z >= MIN_DEPTH)) continue;
-    const float a = 1.f / (1.f + expf(d2));  // sigmoid(-d2)
-    const float d = 1.f / Y.z;
-    const float xn = Y.x * d, yn = Y.y * d;
-    // rows of J = dp/dxi (tau, phi)
-    const float Jx[6] = {fx * d, 0.f, -fx * xn * d, -fx * xn * yn, fx * (1.f + xn * xn), -fx * yn};
-    const float Jy[6] = {0.f, fy * d, -fy * yn * d, -fy * (1.f + yn * yn), fy * xn * yn, fy * xn};
-    const float Jz[6] = {0.f, 0.f, -d * d, -yn * d, xn * d, 0.f};
-    const float rx = (xb[(size_t)j * 3] + db[j]) - (fx * xn + cx);
-    const float ry_ = (xb[(size_t)j * 3 + 1] + db[N + j]) - (fy * yn + cy);
-    const float rz = (xb[(size_t)j * 3 + 2] + db[2 * N + j]) - d;
-    const float wx = a * wb[j], wy = a * wb[N + j], wz = a * wb[2 * N + j];
-    int k = 0;
+      for (int c = 0; c < GN_AE; ++c) dot += ai[c] * rp[c];
+      const float d2 = fmaxf(ai2 + rp[41] - 2.f * dot, 0.f);
+      const float a = (in ? 1.f : 0.f) * __builtin_amdgcn_rcpf(1.f + __expf(d2));  // sigmoid(-d2), masked (branch-free)
+      const float d = __builtin_amdgcn_rcpf(fmaxf(Yz, MIN_DEPTH));
+      const float xn = Yx * d, yn = Yy * d;
+      const float Jx[6] = {fx * d, 0.f, -fx * xn * d, -fx * xn * yn, fx * (1.f + xn * xn), -fx * yn};
+      const float Jy[6] = {0.f, fy * d, -fy * yn * d, -fy * (1.f + yn * yn), fy * xn * yn, fy * xn};
+      const float Jz[6] = {0.f, 0.f, -d * d, -yn * d, xn * d, 0.f};
+      const float rx = rp[35] - (fx * xn + cx);
+      const float ry_ = rp[36] - (fy * yn + cy);
+      const float rz = rp[37] - d;
+      const float wx = a * rp[38], wy = a * rp[39], wz = a * rp[40];
+      float wJx[6], wJy[6], wJz[6];
 #pragma unroll
-    for (int p = 0; p < 6; ++p) {
+      for (int p = 0; p < 6; ++p) { wJx[p] = wx * Jx[p]; wJy[p] = wy * Jy[p]; wJz[p] = wz * Jz[p]; }
+      int k = 0;
 #pragma unroll
-      for (int q = p; q < 6; ++q) { Hs[k] += wx * Jx[p] * Jx[q] + wy * Jy[p] * Jy[q] + wz * Jz[p] * Jz[q]; ++k; }
-      bs[p] += wx * rx * Jx[p] + wy * ry_ * Jy[p] + wz * rz * Jz[p];
+      for (int p = 0; p < 6; ++p) {
+#pragma unroll
+        for (int qq = p; qq < 6; ++qq) { Hs[k] += wJx[p] * Jx[qq] + wJy[p] * Jy[qq] + wJz[p] * Jz[qq]; ++k; }
+        bs[p] += wJx[p] * rx + wJy[p] * ry_ + wJz[p] * rz;
+      }
     }
   }
+  float* pp = part + ((size_t)b * ntiles * R + task) * 27 * 64 + lane;
 #pragma unroll
-  for (int k = 0; k < 21; ++k) Hs[k] = wave_sum(Hs[k]);
+  for (int k = 0; k < 21; ++k) pp[k * 64] = Hs[k];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) bs[k] = wave_sum(bs[k]);
-  if (lane != 0) return;
-  // damping H += (lm*H + ep) on the diagonal, then Cholesky solve (fp64 for the 6x6 system)
-  double A[6][6], L[6][6], rhs[6];
+  for (int k = 0; k < 6; ++k) pp[(21 + k) * 64] = bs[k];
+}
+
+// Combine the R partials of a tile: one wave per (tile, k); consecutive lanes = pixels (coalesced),
+// 27*ntiles waves in flight hide the R dependent adds.  sums: [tile][27][64].
+__global__ __launch_bounds__(64) void se3_gn_reduce_kernel(const float* __restrict__ part, int ntiles, int R,
+                                                           float* __restrict__ sums) {
+  const int lane = threadIdx.x, k = blockIdx.x % 27, tile = blockIdx.x / 27, b = blockIdx.y;
+  const float* p = part + (((size_t)b * ntiles + tile) * R) * 27 * 64 + k * 64 + lane;
+  float s = 0.f;
+  for (int r = 0; r < R; ++r) s += p[(size_t)r * 27 * 64];
+  sums[(((size_t)b * ntiles + tile) * 27 + k) * 64 + lane] = s;
+}
+
+__global__ __launch_bounds__(64) void se3_gn_solve_kernel(float* __restrict__ T, const float* __restrict__ sums, int h,
+                                                          int w, int tiles_x, int ntiles, float lm, float ep) {
+  const int lane = threadIdx.x;
+  const int tile = blockIdx.x, b = blockIdx.y;
+  const int xi = (tile % tiles_x) * 8 + (lane & 7), yi = (tile / tiles_x) * 8 + (lane >> 3);
+  if (xi >= w || yi >= h) return;
+  const int N = h * w, i = yi * w + xi;
+  float Hf[21], bf[6];
+  const float* sp = sums + (((size_t)b * ntiles + tile) * 27) * 64 + lane;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const float s = sp[k * 64];
+    if (k < 21) Hf[k] = s; else bf[k - 21] = s;
+  }
+  // damping H_pp += lm*H_pp + ep (fp32, as the reference), then Cholesky solve in fp64
+  double L[6][6];
   {
     int k = 0;
+#pragma unroll
     for (int p = 0; p < 6; ++p)
-      for (int q = p; q < 6; ++q) { A[p][q] = A[q][p] = (double)Hs[k]; ++k; }
-  }
-  for (int p = 0; p < 6; ++p) {
-    const float hd = (float)A[p][p];
-    A[p][p] = (double)(hd + (lm * hd + ep));
-    rhs[p] = (double)bs[p];
+#pragma unroll
+      for (int q = p; q < 6; ++q) {
+        float v = Hf[k++];
+        if (p == q) v = v + (lm * v + ep);
+        L[q][p] = (double)v;  // lower triangle holds A
+      }
   }
   bool ok = true;
+#pragma unroll
   for (int p = 0; p < 6; ++p) {
+#pragma unroll
     for (int q = 0; q <= p; ++q) {
-      double s = A[p][q];
+      double s = L[p][q];
+#pragma unroll
       for (int r = 0; r < q; ++r) s -= L[p][r] * L[q][r];
       if (p == q) { if (!(s > 0.0)) { ok = false; s = 1.0; } L[p][p] = sqrt(s); }
       else L[p][q] = s / L[q][q];
     }
   }
   double yv[6], xv[6];
-  for (int p = 0; p < 6; ++p) { double s = rhs[p]; for (int r = 0; r < p; ++r) s -= L[p][r] * yv[r]; yv[p] = s / L[p][p]; }
-  for (int p = 5; p >= 0; --p) { double s = yv[p]; for (int r = p + 1; r < 6; ++r) s -= L[r][p] * xv[r]; xv[p] = s / L[p][p]; }
-  SE3T Tn = Ti;
-  if (ok) {
-    const SE3T dT = se3_exp(V3{(float)xv[0], (float)xv[1], (float)xv[2]}, V3{(float)xv[3], (float)xv[4], (float)xv[5]});
-    Tn = se3_compose(dT, Ti);
+#pragma unroll
+  for (int p = 0; p < 6; ++p) {
+    double s = (double)bf[p];
+#pragma unroll
+    for (int r = 0; r < p; ++r) s -= L[p][r] * yv[r];
+    yv[p] = s / L[p][p];
   }
-  se3_store(Tout + ((size_t)b * N + i) * 7, Tn);
+#pragma unroll
+  for (int p = 5; p >= 0; --p) {
+    double s = yv[p];
+#pragma unroll
+    for (int r = p + 1; r < 6; ++r) s -= L[r][p] * xv[r];
+    xv[p] = s / L[p][p];
+  }
+  if (ok) {
+    float* tp = T + ((size_t)b * N + i) * 7;
+    const SE3T Ti = se3_load(tp);
+    const SE3T dT = se3_exp(V3{(float)xv[0], (float)xv[1], (float)xv[2]}, V3{(float)xv[3], (float)xv[4], (float)xv[5]});
+    se3_store(tp, se3_compose(dT, Ti));
+  }
+}
+
+static inline int gn_rowgroups(int ntiles, int NC) {
+  int R = 3072 / (ntiles > 0 ? ntiles : 1);  // ~3 waves per SIMD on 256 CUs
+  if (R < 1) R = 1;
+  if (R > NC) R = NC;
+  return R;
+}
+
+extern "C" long long codd_se3_gn_scratch(int B, int h, int w, int radius) {
+  const int ntiles = cdiv(w, 8) * cdiv(h, 8);
+  return (long long)B * ntiles * (gn_rowgroups(ntiles, 8 + 2 * radius) + 1) * 27 * 64 + (long long)B * h * w * GN_JS;
 }
 
 extern "C" int codd_se3_gn_step(float* T, const float* ae, int ae_c, const float* xyz, const float* delta,
                                 const float* weight, const float* depth1, int B, int h, int w, float fx, float fy,
                                 float cx, float cy, int radius, float lm, float ep, float* Hb, void* stream) {
-  (void)Hb;
-  if (!T || !ae || !xyz || !delta || !weight || !depth1 || ae_c < 1 || ae_c > GN_AE || radius < 0) return CODD_EINVAL;
-  dim3 grid(cdiv(h * w, 4), B);
-  se3_gn_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(T, ae, ae_c, xyz, delta, weight, depth1, h, w, fx, fy, cx, cy,
-                                                       radius, lm, ep, T);
+  if (!T || !ae || !xyz || !delta || !weight || !depth1 || !Hb || ae_c < 1 || ae_c > GN_AE || radius < 0)
+    return CODD_EINVAL;
+  const int NC = 8 + 2 * radius;
+  const int tiles_x = cdiv(w, 8), ntiles = tiles_x * cdiv(h, 8);
+  const int R = gn_rowgroups(ntiles, NC);
+  float* part = Hb;
+  float* sums = Hb + (size_t)B * ntiles * R * 27 * 64;
+  float* jd = sums + (size_t)B * ntiles * 27 * 64;
+  hipStream_t s = (hipStream_t)stream;
+  se3_gn_prep_kernel<<<dim3(cdiv(h * w, 128), B), 128, 0, s>>>(ae, ae_c, xyz, delta, weight, depth1, h, w, fx, fy, cx,
+                                                             cy, jd);
+  CODD_LAUNCH_CHECK();
+  dim3 grid(cdiv(ntiles * R, GN_WAVES), B);
+  se3_gn_build_kernel<<<grid, 64 * GN_WAVES, 0, s>>>(T, jd, h, w, fx, fy, cx, cy, radius, tiles_x, ntiles, R, part);
+  CODD_LAUNCH_CHECK();
+  se3_gn_reduce_kernel<<<dim3(ntiles * 27, B), 64, 0, s>>>(part, ntiles, R, sums);
+  CODD_LAUNCH_CHECK();
+  se3_gn_solve_kernel<<<dim3(ntiles, B), 64, 0, s>>>(T, sums, h, w, tiles_x, ntiles, lm, ep);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }

@@ -264,9 +264,10 @@ def se3_gn_step(T, ae, xyz, delta, weight, d1, K8, radius=32, lm=1e-4, ep=10.0):
     """In-place Gauss-Newton update of the SE3 field T [B,h,w,7]."""
     lib = _abi.load()
     B, h, w, _ = T.shape
+    scratch = _f32(lib.codd_se3_gn_scratch(B, h, w, radius), like=T)
     _abi.check(lib.codd_se3_gn_step(T.data_ptr(), ae.data_ptr(), ae.shape[1], xyz.data_ptr(), delta.data_ptr(),
-                                    weight.data_ptr(), d1.data_ptr(), B, h, w, *K8, radius, lm, ep, None, _stream()),
-               "se3_gn_step")
+                                    weight.data_ptr(), d1.data_ptr(), B, h, w, *K8, radius, lm, ep,
+                                    scratch.data_ptr(), _stream()), "se3_gn_step")
     return T
 
 
