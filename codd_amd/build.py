@@ -33,7 +33,10 @@ def build(force=False, verbose=True):
                 os.path.getmtime(src), os.path.getmtime(os.path.join(CSRC, "common.h")),
                 os.path.getmtime(os.path.join(ROOT, "include", "codd_hip.h"))):
             cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
-                   "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wno-unused-result"]
+                   "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wno-unused-result", "-Wno-pass-failed",
+                   # keep MFMA accumulators in VGPRs: without it hipcc (ROCm 7.2) copies all
+                   # accumulators VGPR<->AGPR around EVERY k-step of the conv loop (10 VALU per MFMA)
+                   "-mllvm", "-amdgpu-mfma-vgpr-form"]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -22,14 +22,24 @@ struct ConvK {
   int wrow, wchunk;
   int tiles_x, tiles_y, ncog;
   int cout_eff;
-  int step_c, step_y, step_x;  // decomposition of 256 in (c, y, x) units of the LDS tile
+  int twp;     // LDS row stride (floats, multiple of 4) of the input tile
+  int xoff;    // column of the tile's first input pixel inside the 4-aligned LDS row
+  int twp4;    // float4 units per LDS row
+  int upc;     // float4 units per channel = thi * twp4
+  int nunits;  // ck * upc
+  int vec_ok;  // 16-byte global loads allowed (Win % 4 == 0 and 16-byte aligned bases)
 };
 
 __device__ __forceinline__ const float* view_ptr(const codd_view& v, int b, int c, int hw) {
   return v.ptr + ((size_t)b * v.ctot + v.coff + c) * (size_t)hw;
 }
 
-template <int NPB, int MB>
+// Staging: a chunk (CK input channels of the halo tile + the matching packed weights) is fetched
+// with 16-byte global loads into REGISTERS right before the MFMA phase of the previous chunk and
+// written to LDS after it (issue early / write late), so that HBM/L2 latency overlaps the matrix
+// pipe.  The (channel, row, float4-column) decomposition of a thread's units does not depend on
+// the chunk and is computed once.
+template <int NPB, int MB, int WREG, int IREG>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK k) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* wl = smem;
@@ -48,7 +58,67 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK k) {
 
   const int hwin = p.Hin * p.Win;
   const int gy0 = ty * k.th * p.sy - p.pad_t;
-  const int gx0 = tx * k.tw * p.sx - p.pad_l;
+  const int gxs = tx * k.tw * p.sx - p.pad_l - k.xoff;  // 4-aligned start column (may be negative)
+
+  // ---- per-thread staging metadata ---------------------------------------------------------------
+  int u_lds[IREG], u_g[IREG], u_c[IREG];
+  unsigned u_m[IREG];
+#pragma unroll
+  for (int r = 0; r < IREG; ++r) {
+    const int u = tid + r * 256;
+    u_c[r] = -1; u_m[r] = 0; u_lds[r] = 0; u_g[r] = 0;
+    if (u < k.nunits) {
+      const int c = u / k.upc, rem = u - c * k.upc;
+      const int y = rem / k.twp4, x4 = rem - y * k.twp4;
+      const int gy = gy0 + y, gx = gxs + 4 * x4;
+      unsigned m = 0;
+      if ((unsigned)gy < (unsigned)p.Hin) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m |= ((unsigned)(gx + q) < (unsigned)p.Win) ? (1u << q) : 0u;
+      }
+      u_c[r] = c; u_m[r] = m;
+      u_lds[r] = c * k.chs + y * k.twp + 4 * x4;
+      u_g[r] = gy * p.Win + gx;
+    }
+  }
+  const int wchunk4 = k.wchunk >> 2;
+  float4 wreg[WREG], ireg[IREG];
+
+#define CONV_ISSUE(CH)                                                                                    \
+  {                                                                                                       \
+    const float4* src_ = (const float4*)(p.wpacked + ((size_t)(cog * k.nchunks + (CH))) * k.wchunk);      \
+    _Pragma("unroll") for (int r = 0; r < WREG; ++r) {                                                    \
+      const int e = tid + r * 256;                                                                        \
+      wreg[r] = e < wchunk4 ? src_[e] : make_float4(0.f, 0.f, 0.f, 0.f);                                  \
+    }                                                                                                     \
+    const int c0_ = (CH) * p.ck;                                                                          \
+    _Pragma("unroll") for (int r = 0; r < IREG; ++r) {                                                    \
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                         \
+      const int cg = c0_ + u_c[r];                                                                        \
+      if (u_c[r] >= 0 && cg < k.cin && u_m[r]) {                                                          \
+        const float* s_ =                                                                                 \
+            (cg < p.C0 ? view_ptr(p.in0, b, cg, hwin) : view_ptr(p.in1, b, cg - p.C0, hwin)) + u_g[r];    \
+        if (u_m[r] == 0xFu && k.vec_ok) {                                                                 \
+          v = *(const float4*)s_;                                                                         \
+        } else {                                                                                          \
+          if (u_m[r] & 1u) v.x = s_[0];                                                                   \
+          if (u_m[r] & 2u) v.y = s_[1];                                                                   \
+          if (u_m[r] & 4u) v.z = s_[2];                                                                   \
+          if (u_m[r] & 8u) v.w = s_[3];                                                                   \
+        }                                                                                                 \
+      }                                                                                                   \
+      ireg[r] = v;                                                                                        \
+    }                                                                                                     \
+  }
+#define CONV_COMMIT()                                                                                     \
+  {                                                                                                       \
+    float4* dst_ = (float4*)wl;                                                                           \
+    _Pragma("unroll") for (int r = 0; r < WREG; ++r) {                                                    \
+      const int e = tid + r * 256;                                                                        \
+      if (e < wchunk4) dst_[e] = wreg[r];                                                                 \
+    }                                                                                                     \
+    _Pragma("unroll") for (int r = 0; r < IREG; ++r) if (u_c[r] >= 0) *(float4*)(il + u_lds[r]) = ireg[r]; \
+  }
 
   f32x4 acc[NPB][MB];
 #pragma unroll
@@ -61,49 +131,30 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK k) {
 #pragma unroll
   for (int a = 0; a < NPB; ++a) {
     const int prow = wave * RPW + a / XB, pcol = (a % XB) * 16 + j;
-    pbase[a] = prow * p.sy * k.twi + pcol * p.sx;
+    pbase[a] = prow * p.sy * k.twp + pcol * p.sx + k.xoff;
   }
 
-  const int per = k.thi * k.twi;
-  const int tot = p.ck * per;
+  CONV_ISSUE(0);
   for (int ch = 0; ch < k.nchunks; ++ch) {
+    __syncthreads();  // every wave is done reading the previous chunk
+    CONV_COMMIT();
     __syncthreads();
-    {  // weights: straight copy of the packed chunk
-      const float4* src = (const float4*)(p.wpacked + ((size_t)(cog * k.nchunks + ch)) * k.wchunk);
-      float4* dst = (float4*)wl;
-      for (int e = tid; e < (k.wchunk >> 2); e += 256) dst[e] = src[e];
-    }
-    {  // input halo tile, zero filled outside the image / beyond Cin
-      const int c0 = ch * p.ck;
-      int c = tid / per, r = tid - c * per;
-      int y = r / k.twi, x = r - y * k.twi;
-      for (int e = tid; e < tot; e += 256) {
-        const int cg = c0 + c, gy = gy0 + y, gx = gx0 + x;
-        float v = 0.f;
-        if (cg < k.cin && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win) {
-          const float* s = cg < p.C0 ? view_ptr(p.in0, b, cg, hwin) : view_ptr(p.in1, b, cg - p.C0, hwin);
-          v = s[gy * p.Win + gx];
-        }
-        il[c * k.chs + y * k.twi + x] = v;
-        x += k.step_x;
-        if (x >= k.twi) { x -= k.twi; ++y; }
-        y += k.step_y;
-        if (y >= k.thi) { y -= k.thi; ++c; }
-        c += k.step_c;
-      }
-    }
-    __syncthreads();
+    if (ch + 1 < k.nchunks) CONV_ISSUE(ch + 1);
     for (int ky = 0; ky < p.kh; ++ky) {
       for (int kx = 0; kx < p.kw; ++kx) {
-        const float* wt = wl + (ky * p.kw + kx) * p.ck * k.wrow + j;
-        const float* it = il + ky * p.dil_y * k.twi + kx * p.dil_x;
+        const float* wp = wl + (ky * p.kw + kx) * p.ck * k.wrow + j + g * k.wrow;
+        const float* ip = il + ky * p.dil_y * k.twp + kx * p.dil_x + g * k.chs;
+        const int wstep = 4 * k.wrow, istep = 4 * k.chs;
+        // 4 k-steps per trip: the 4*(MB+NPB) LDS reads are issued ahead of the 4*MB*NPB MFMAs
+#pragma unroll 4
         for (int c4 = 0; c4 < p.ck; c4 += 4) {
-          const int c = c4 + g;
           float av[MB], bv[NPB];
 #pragma unroll
-          for (int m = 0; m < MB; ++m) av[m] = wt[c * k.wrow + m * 16];
+          for (int m = 0; m < MB; ++m) av[m] = wp[m * 16];
 #pragma unroll
-          for (int a = 0; a < NPB; ++a) bv[a] = it[c * k.chs + pbase[a]];
+          for (int a = 0; a < NPB; ++a) bv[a] = ip[pbase[a]];
+          wp += wstep;
+          ip += istep;
 #pragma unroll
           for (int a = 0; a < NPB; ++a)
 #pragma unroll
@@ -193,25 +244,39 @@ extern "C" int codd_conv2d_pack_weights(const float* w, float* wpacked, int Cout
                                      (long long)kh * kw, 1.f, stream);
 }
 
-template <int NPB, int MB>
+template <int NPB, int MB, int WREG, int IREG>
 static int launch_conv(const ConvK& k, size_t lds, int grid, hipStream_t s) {
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_mfma_kernel<NPB, MB>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_mfma_kernel<NPB, MB, WREG, IREG>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  conv_mfma_kernel<NPB, MB><<<grid, 256, lds, s>>>(k);
+  conv_mfma_kernel<NPB, MB, WREG, IREG><<<grid, 256, lds, s>>>(k);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }
 
+template <int NPB, int MB>
+static int launch_conv_regs(const ConvK& k, size_t lds, int grid, hipStream_t s) {
+  const int wr = cdiv(k.wchunk >> 2, 256), ir = cdiv(k.nunits, 256);
+  if (wr <= 4 && ir <= 4) return launch_conv<NPB, MB, 4, 4>(k, lds, grid, s);
+  if (wr <= 4 && ir <= 8) return launch_conv<NPB, MB, 4, 8>(k, lds, grid, s);
+  if (wr <= 12 && ir <= 4) return launch_conv<NPB, MB, 12, 4>(k, lds, grid, s);
+  if (wr <= 12 && ir <= 8) return launch_conv<NPB, MB, 12, 8>(k, lds, grid, s);
+  if (wr <= 16 && ir <= 8) return launch_conv<NPB, MB, 16, 8>(k, lds, grid, s);
+  return CODD_EUNSUPPORTED;
+}
+
+/* staging limits the host heuristics must respect: <= 16 float4 of weights and <= 8 float4 of input
+ * per thread and chunk (codd_conv2d returns CODD_EUNSUPPORTED otherwise) */
 extern "C" int codd_conv2d(const codd_conv_params* pp, void* stream) {
   if (!pp) return CODD_EINVAL;
   ConvK k;
   k.p = *pp;
   const codd_conv_params& p = k.p;
   if (!p.in0.ptr || !p.out || !p.wpacked || p.C0 <= 0 || p.C1 < 0 || (p.C1 > 0 && !p.in1.ptr)) return CODD_EINVAL;
-  if (p.ck < 4 || (p.ck & 3) || p.B < 1 || p.Cout < 1 || p.kh < 1 || p.kw < 1) return CODD_EINVAL;
+  if (p.ck < 4 || (p.ck & 3) || p.B < 1 || p.Cout < 1 || p.kh < 1 || p.kw < 1 || p.pad_l < 0 || p.pad_t < 0)
+    return CODD_EINVAL;
   if (!(p.mb == 1 || p.mb == 2 || p.mb == 4) || !(p.npb == 1 || p.npb == 2 || p.npb == 4)) return CODD_EINVAL;
   if (p.store_mode && (p.kh != 1 || p.kw != 1 || p.res1.ptr || p.res2.ptr || p.post.ptr)) return CODD_EUNSUPPORTED;
   k.cin = p.C0 + p.C1;
@@ -222,26 +287,29 @@ extern "C" int codd_conv2d(const codd_conv_params* pp, void* stream) {
   k.tw = 16 * xb;
   k.thi = (k.th - 1) * p.sy + (p.kh - 1) * p.dil_y + 1;
   k.twi = (k.tw - 1) * p.sx + (p.kw - 1) * p.dil_x + 1;
-  int per = k.thi * k.twi;
-  if (p.sx == 1) k.chs = ((per + 15) / 32) * 32 + 16;  // == 16 (mod 32), >= per
-  else k.chs = per | 1;
-  if (k.chs < per) k.chs += 32;
+  k.xoff = (4 - (p.pad_l % 4)) % 4;  // gx0 = tile*16k*sx - pad_l  ->  gx0 - xoff is a multiple of 4
+  k.twp = ((k.xoff + k.twi + 3) / 4) * 4;
+  k.twp4 = k.twp / 4;
+  k.upc = k.thi * k.twp4;
+  k.nunits = p.ck * k.upc;
+  const int per = k.thi * k.twp;
+  if (p.sx == 1) k.chs = ((per + 15) / 32) * 32 + 16;  // == 16 (mod 32): the two ci-groups of a half-wave hit disjoint banks
+  else k.chs = per + 4;                                // strided: 16-byte aligned, 2-way conflicts accepted
   k.wrow = wrow_of(p.mb);
   k.wchunk = k.ntaps * p.ck * k.wrow;
   k.tiles_x = cdiv(p.Wout, k.tw);
   k.tiles_y = cdiv(p.Hout, k.th);
   k.cout_eff = p.store_mode ? 4 * p.Cout : p.Cout;
   k.ncog = cdiv(k.cout_eff, 16 * p.mb);
-  k.step_c = 256 / per;
-  int rem = 256 - k.step_c * per;
-  k.step_y = rem / k.twi;
-  k.step_x = rem - k.step_y * k.twi;
+  const size_t hwb = (size_t)p.Hin * p.Win * sizeof(float);
+  k.vec_ok = (p.Win % 4 == 0) && ((uintptr_t)p.in0.ptr % 16 == 0) && (hwb % 16 == 0) &&
+             (p.C1 == 0 || (uintptr_t)p.in1.ptr % 16 == 0);
   size_t lds = ((size_t)k.wchunk + (size_t)p.ck * k.chs) * sizeof(float);
   if (lds > 160 * 1024) return CODD_EUNSUPPORTED;
   long long grid = (long long)k.tiles_x * k.tiles_y * k.ncog * p.B;
   if (grid <= 0 || grid > 0x7fffffffLL) return CODD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-#define CASE(N, M) if (p.npb == N && p.mb == M) return launch_conv<N, M>(k, lds, (int)grid, s)
+#define CASE(N, M) if (p.npb == N && p.mb == M) return launch_conv_regs<N, M>(k, lds, (int)grid, s)
   CASE(1, 1); CASE(1, 2); CASE(1, 4);
   CASE(2, 1); CASE(2, 2); CASE(2, 4);
   CASE(4, 1); CASE(4, 2); CASE(4, 4);

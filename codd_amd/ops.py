@@ -89,26 +89,43 @@ def _launch_conv(lib, p, stream):
     return lib.codd_conv2d(C.byref(p), stream)
 
 
+import os as _os
+_FORCE_NPB = int(_os.environ.get("CODD_NPB", "0"))
+
+
 def _wrow(mb):
     return 16 * mb + (0 if mb & 1 else 16)
 
 
-def _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx):
-    """(npb, ck): tile shape per wave and LDS chunk depth."""
+def _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl):
+    """(npb, ck): tile shape per wave and LDS chunk depth.
+
+    Measured on MI355X (tools/time_ops.py): the small 4x16-pixel tile (npb = 1) wins on every
+    layer with more than 16 output channels -- the kernel is latency / barrier bound, so more
+    resident workgroups beat operand re-use; 16-channel layers prefer 4x32.  The LDS chunk is sized
+    so that the whole grid is resident at once when possible (a 576-block grid at 2 blocks/CU runs
+    a second, nearly empty round: 112 us vs 67 us for 504 blocks).  Limits of the kernel's register
+    staging: <= 16 float4 of weights and <= 8 float4 of input per thread and chunk."""
     ncog = -(-pc.cout_eff // (16 * pc.mb))
-    nblk4 = (-(-Hout // 8)) * (-(-Wout // 32)) * ncog * B
-    nblk2 = (-(-Hout // 4)) * (-(-Wout // 32)) * ncog * B
-    npb = 4 if nblk4 >= 512 else (2 if nblk2 >= 384 else 1)
+    npb = 2 if pc.cout_eff <= 16 else 1
+    if _FORCE_NPB:
+        npb = _FORCE_NPB
     xb = 2 if npb >= 2 else 1
     th, tw = 4 * (npb // xb), 16 * xb
+    grid = (-(-Hout // th)) * (-(-Wout // tw)) * ncog * B
+    per_cu = min(max(-(-grid // 256), 2), 4)
+    budget = min(64 * 1024, (160 * 1024) // per_cu - 512)
     thi = (th - 1) * sy + (pc.kh - 1) * dy + 1
     twi = (tw - 1) * sx + (pc.kw - 1) * dx + 1
-    per = thi * twi
-    chs = ((per + 15) // 32) * 32 + 16 if sx == 1 else per | 1
+    xoff = (4 - pl % 4) % 4
+    twp = -(-(xoff + twi) // 4) * 4
+    per = thi * twp
+    chs = ((per + 15) // 32) * 32 + 16 if sx == 1 else per + 4
     cin_pad = -(-pc.cin // 4) * 4
     ck = min(cin_pad, 32)
-    budget = 64 * 1024
-    while ck > 4 and (pc.kh * pc.kw * ck * _wrow(pc.mb) + ck * chs) * 4 > budget:
+    taps = pc.kh * pc.kw
+    while ck > 4 and ((taps * ck * _wrow(pc.mb) + ck * chs) * 4 > budget or taps * ck * _wrow(pc.mb) > 16384
+                      or ck * thi * (twp // 4) > 2048):
         ck -= 4
     return npb, ck
 
@@ -145,7 +162,7 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
         out = torch.empty(B, pc.cout, Hout * up, Wout * up, device=xs.buf.device, dtype=torch.float32)
     os_ = _as_slice(out)
     assert os_.shape == (B, pc.cout, Hout * up, Wout * up), (os_.shape, (B, pc.cout, Hout * up, Wout * up))
-    npb, ck = _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx)
+    npb, ck = _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl)
     p = ConvParams()
     p.in0 = _view(xs)
     p.in1 = _view(x2)
