@@ -47,8 +47,11 @@ def log(msg):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--prewarm", type=int, default=30,
+                    help="untimed steady-state frames run before the W warm-up steps so that the GPU clocks and "
+                         "the captured graph are in steady state (reported in config.prewarm_frames)")
     ap.add_argument("--iters", type=int, default=16)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -182,11 +185,11 @@ def main():
     runner.step(l, r)
     torch.cuda.synchronize(device)
     log("frame 0 done")
-    for i in range(1, 1 + max(args.warmup, 1)):
+    for i in range(1, 1 + args.prewarm + max(args.warmup, 1)):
         l, r, _ = frame(i)
         runner.step(l, r)
-        torch.cuda.synchronize(device)
-        log(f"warm-up frame {i} done")
+    torch.cuda.synchronize(device)
+    log(f"{args.prewarm} pre-warm + {max(args.warmup, 1)} warm-up frames done")
     seqm = metrics.SequenceMetrics(metas[0][0], device)
 
     torch.cuda.synchronize(device)
@@ -195,7 +198,7 @@ def main():
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        l, r, g = frame(1 + args.warmup + i)
+        l, r, g = frame(1 + args.prewarm + args.warmup + i)
         d = runner.step(l, r)
         seqm.update(d[:, :, :raw_h, :raw_w], g[:, :, :raw_h, :raw_w])
     red = metrics.reduce_rows([seqm.row()], device)  # the job's only collective (RCCL all_reduce)
@@ -239,6 +242,7 @@ def main():
                                    f" {raw_w}x{raw_h} padded to {W}x{H}, max_disp=320, one video per GPU, "
                                    "steady-state frames (idx>=1), synthetic stereo sequence, random-init weights",
                        "hip_graph": bool(runner.graph is not None), "frames_per_gpu": args.steps,
+                       "prewarm_frames": args.prewarm,
                        "fps_per_gpu": round(fps / world, 3)},
             "epe_vs_synthetic_gt": red["epe"][0],
             "roofline": roof, "cpu_baseline": cpu,

@@ -8,41 +8,46 @@
 
 // ------------------------------------------------------------------------------------------------
 // InstanceNorm2d (affine = False, eps = 1e-5, biased variance) + residual + ReLU.
-// Two-pass statistics (mean, then centred second moment) per (b, c) by one workgroup.
+// Statistics: every (b, c) plane is split over `parts` workgroups that accumulate sum(x - K) and
+// sum((x - K)^2) around the pivot K = x[0] of the plane (shifted moments: no cancellation when
+// |mean| >> std); the apply kernel combines the partials in fp64 in a fixed order.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void instnorm_stats_kernel(const float* __restrict__ x, int HW, float* stats) {
-  __shared__ float red[4];
-  __shared__ float mean_s;
-  const float* p = x + (size_t)blockIdx.x * HW;
+#define IN_MAXPARTS 32
+__global__ __launch_bounds__(256) void instnorm_stats_kernel(const float* __restrict__ x, int HW, int parts,
+                                                             double* __restrict__ partial) {
+  __shared__ double red[2][4];
+  const int bc = blockIdx.y, part = blockIdx.x;
+  const float* p = x + (size_t)bc * HW;
+  const float K = p[0];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float s = 0.f;
-  for (int i = tid; i < HW; i += 256) s += p[i];
-  s = wave_sum(s);
-  if (lane == 0) red[wave] = s;
-  __syncthreads();
-  if (tid == 0) mean_s = (red[0] + red[1] + red[2] + red[3]) / (float)HW;
-  __syncthreads();
-  const float m = mean_s;
-  float v = 0.f;
-  for (int i = tid; i < HW; i += 256) { const float d = p[i] - m; v += d * d; }
-  v = wave_sum(v);
-  __syncthreads();
-  if (lane == 0) red[wave] = v;
+  const int per = (HW + parts - 1) / parts, i0 = part * per, i1 = min(HW, i0 + per);
+  float s = 0.f, q = 0.f;
+  for (int i = i0 + tid; i < i1; i += 256) { const float d = p[i] - K; s += d; q += d * d; }
+  double sd = (double)s, qd = (double)q;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sd += __shfl_xor(sd, o, 64); qd += __shfl_xor(qd, o, 64); }
+  if (lane == 0) { red[0][wave] = sd; red[1][wave] = qd; }
   __syncthreads();
   if (tid == 0) {
-    const float var = (red[0] + red[1] + red[2] + red[3]) / (float)HW;
-    stats[2 * blockIdx.x] = m;
-    stats[2 * blockIdx.x + 1] = 1.f / sqrtf(var + 1e-5f);
+    partial[((size_t)bc * parts + part) * 2] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    partial[((size_t)bc * parts + part) * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
   }
 }
 
-__global__ void instnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
-                                      const float* __restrict__ res, int HW, int relu, float* __restrict__ y,
-                                      long long total) {
-  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
-  const long long bc = e / HW;
-  float v = (x[e] - stats[2 * bc]) * stats[2 * bc + 1];
+__global__ void instnorm_apply_kernel(const float* __restrict__ x, const double* __restrict__ partial, int parts,
+                                      const float* __restrict__ res, int HW, int relu, float* __restrict__ y) {
+  const int bc = blockIdx.y;
+  const float* p = x + (size_t)bc * HW;
+  double s = 0.0, q = 0.0;
+  for (int i = 0; i < parts; ++i) { s += partial[((size_t)bc * parts + i) * 2]; q += partial[((size_t)bc * parts + i) * 2 + 1]; }
+  const double md = s / HW;                       // mean of (x - K)
+  const double var = fmax(q / HW - md * md, 0.0);  // shift invariant
+  const float mean = (float)((double)p[0] + md);
+  const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= HW) return;
+  const size_t e = (size_t)bc * HW + i;
+  float v = (x[e] - mean) * rstd;
   if (res) v += res[e];
   if (relu) v = fmaxf(v, 0.f);
   y[e] = v;
@@ -50,12 +55,15 @@ __global__ void instnorm_apply_kernel(const float* __restrict__ x, const float* 
 
 extern "C" int codd_instnorm(const float* x, int B, int C, int HW, float* stats, const float* res, int relu,
                              float* y, void* stream) {
-  if (!x || !stats || !y || B < 1 || C < 1 || HW < 1) return CODD_EINVAL;
+  if (!x || !stats || !y || B < 1 || C < 1 || HW < 1 || ((uintptr_t)stats & 7)) return CODD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  instnorm_stats_kernel<<<B * C, 256, 0, s>>>(x, HW, stats);
+  int parts = cdiv(2048, B * C);  // ~2048 workgroups in flight
+  parts = parts < 1 ? 1 : (parts > IN_MAXPARTS ? IN_MAXPARTS : parts);
+  if (parts > cdiv(HW, 1024)) parts = cdiv(HW, 1024);
+  double* partial = (double*)stats;
+  instnorm_stats_kernel<<<dim3(parts, B * C), 256, 0, s>>>(x, HW, parts, partial);
   CODD_LAUNCH_CHECK();
-  const long long total = (long long)B * C * HW;
-  instnorm_apply_kernel<<<cdiv(total, 256), 256, 0, s>>>(x, stats, res, HW, relu, y, total);
+  instnorm_apply_kernel<<<dim3(cdiv(HW, 256), B * C), 256, 0, s>>>(x, partial, parts, res, HW, relu, y);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }

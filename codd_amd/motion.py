@@ -121,12 +121,14 @@ class BasicUpdateBlock(nn.Module):
         mot = cv(self.flow_enc[0], minfo, act="relu")
         isum = cv(self.flow_enc[2], mot, res1=isum)  # (inp + cor) + mot
         net = self.gru.run(net, isum)
-        hid = ops.conv2d(net, packed_cat((self.ae[0], self.mask[0], self.delta[0], self.weight[0])), pad=1,
-                         act="relu")
+        # the four 3x3 head convs share their input: one 768/1024-channel conv; the mask head (576
+        # up-sampling weights) is only consumed after the last iteration (raft3d.py:267-273)
+        heads = (self.ae[0], self.delta[0], self.weight[0]) + ((self.mask[0],) if need_mask else ())
+        hid = ops.conv2d(net, packed_cat(heads), pad=1, act="relu")
         ae = cv(self.ae[2], Slice(hid, 0, 256))
-        mask = cv(self.mask[2], Slice(hid, 256, 256)) if need_mask else None
-        delta = cv(self.delta[2], Slice(hid, 512, 256))
-        weight = cv(self.weight[2], Slice(hid, 768, 256), act="sigmoid")
+        delta = cv(self.delta[2], Slice(hid, 256, 256))
+        weight = cv(self.weight[2], Slice(hid, 512, 256), act="sigmoid")
+        mask = cv(self.mask[2], Slice(hid, 768, 256)) if need_mask else None
         return net, mask, ae, delta, weight
 
 

@@ -125,7 +125,7 @@ int codd_hyp_select(const float* upd, codd_view cur, codd_view prev, int B, int 
  * --------------------------------------------------------------------------------------------- */
 /* InstanceNorm2d (affine=False, eps=1e-5) + optional residual + optional ReLU
  * (blocks/extractor.py:9-58,119-199):  y = relu?( (x - mean_c)/sqrt(var_c + eps) [+ res] ).
- * stats: scratch of 2*B*C floats. */
+ * stats: 8-byte aligned scratch of 128*B*C floats (fp64 partial moments, <= 32 parts per plane). */
 int codd_instnorm(const float* x, int B, int C, int HW, float* stats, const float* res, int relu,
                   float* y, void* stream);
 
