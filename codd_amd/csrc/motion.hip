@@ -657,6 +657,11 @@ __global__ void splat_gather_kernel(const SplatP p) {
   }
 }
 
+__global__ void zero_int_kernel(int* p, long long n) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) p[e] = 0;
+}
+
 extern "C" int codd_splat(const float* T, const float* depth, int HT, int WT, int oy, int ox, int ds,
                           const float* featA, int CA, const float* featB, int CB, int with_flow, int B, int H, int W,
                           float fx, float fy, float cx, float cy, float radius, float bf, float* out, float* zout,
@@ -672,8 +677,11 @@ extern "C" int codd_splat(const float* T, const float* depth, int HT, int WT, in
   p.R = radius * (float)(H < W ? H : W) / (2.f * (float)H);
   p.bf = bf; p.out = out; p.zout = zout;
   p.cnt = scratch; p.list = scratch + (size_t)B * H * W; p.cap = cap;
-  hipError_t e = hipMemsetAsync(p.cnt, 0, (size_t)B * H * W * sizeof(int), s);
-  if (e != hipSuccess) return (int)e;
+  // zero the per-pixel candidate counters with a kernel (a plain kernel node under graph capture;
+  // hipMemsetAsync becomes a memset node whose ordering against neighbouring kernel nodes is not
+  // relied upon)
+  zero_int_kernel<<<cdiv((long long)B * H * W, 256), 256, 0, s>>>(p.cnt, (long long)B * H * W);
+  CODD_LAUNCH_CHECK();
   dim3 grid(cdiv(H * W, 256), B);
   splat_scatter_kernel<<<grid, 256, 0, s>>>(p);
   CODD_LAUNCH_CHECK();

@@ -10,6 +10,8 @@ in static buffers that the graph reads at its head and overwrites at its tail.
 """
 import torch
 
+from . import ops
+
 
 class FrameRunner:
     """Runs ConsistentOnlineDynamicDepth frame by frame on one GPU, eagerly or by graph replay."""
@@ -56,8 +58,12 @@ class FrameRunner:
             s = st["state"]
             state = dict(memory=[s[0], s[1], s[2]], raft_feat=s[3], raft_netinp=s[4])
             out = self.est.consistent_online_depth_estimation(st["l"], st["r"], self.metas, state)
+            # state write-back with a KERNEL, not Tensor.copy_: under capture copy_/memset become
+            # memcpy/memset graph nodes, and on ROCm 7.2 a captured hipMemsetAsync node was observed
+            # to race with the neighbouring kernel nodes (GPU page faults after ~45 replays when
+            # eager work ran between replays).  Only kernel nodes are used inside the frame graph.
             for dst, src in zip(s, self._state_tensors(state)):
-                dst.copy_(src)
+                ops.add_relu(src.contiguous(), None, relu=False, out=dst)
             return out["pred_disp"]
 
         saved = [t.clone() for t in st["state"]]
