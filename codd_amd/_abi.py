@@ -60,8 +60,8 @@ SIGNATURES = {
                         _p, _p, _p, _i, _p]),
     "codd_resize_bilinear": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p]),
     "codd_add_relu": (_i, [_p, _p, _ll, _i, _p, _p]),
-    "codd_gru_rh": (_i, [_p, _p, _i, _i, _p, _p]),
-    "codd_gru_out": (_i, [_p, _p, _p, _i, _i, _p, _p]),
+    "codd_gru_gate_zr": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
+    "codd_gru_gate_q": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p]),
     "codd_fusion_cues_lr": (_i, [_p] * 6 + [_i] * 5 + [_p, _p, _i, _i, _p]),
     "codd_fusion_cues_fr": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "codd_fusion_blend": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),

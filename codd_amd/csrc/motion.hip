@@ -772,34 +772,51 @@ extern "C" int codd_add_relu(const float* a, const float* b, long long n, int re
 }
 
 // ------------------------------------------------------------------------------------------------
-// ConvGRU gate fusions (reference blocks/gru.py:26-34) and the context split (raft3d.py:183-186).
+// ConvGRU gate fusions (reference blocks/gru.py:17-34).  The six gate convolutions run as
+// independent launches (concurrently, on forked streams); these two kernels apply
+//   z|r = sigmoid(conv1 + conv2 + (inp + cor + mot)[0:256]),  rh = r * h
+//   q   = tanh   (conv1 + conv2 + (inp + cor + mot)[256:384]), h' = (1 - z) h + z q
+// with the three input streams inp / cor / mot [B,384,hw] summed in the reference's order.
 // ------------------------------------------------------------------------------------------------
-__global__ void gru_rh_kernel(const float* __restrict__ zr, const float* __restrict__ h, int hw, float* __restrict__ rh,
-                              long long total) {
+__global__ void gru_gate_zr_kernel(const float* __restrict__ t1, const float* __restrict__ t2,
+                                   const float* __restrict__ inp, const float* __restrict__ cor,
+                                   const float* __restrict__ mot, const float* __restrict__ h, int hw,
+                                   float* __restrict__ zr, float* __restrict__ rh, long long total) {
   long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
-  const long long b = e / (128LL * hw), r = e - b * 128LL * hw;
-  rh[e] = zr[b * 256LL * hw + 128LL * hw + r] * h[e];
+  if (e >= total) return;  // total = B*256*hw
+  const long long b = e / (256LL * hw), r = e - b * 256LL * hw;
+  const long long i3 = b * 384LL * hw + r;
+  const float isum = (inp[i3] + cor[i3]) + mot[i3];
+  const float v = 1.f / (1.f + expf(-((t1[e] + t2[e]) + isum)));
+  zr[e] = v;
+  if (r >= 128LL * hw) { const long long hi = b * 128LL * hw + (r - 128LL * hw); rh[hi] = v * h[hi]; }
 }
-__global__ void gru_out_kernel(const float* __restrict__ zr, const float* __restrict__ q, const float* __restrict__ h,
-                               int hw, float* __restrict__ ho, long long total) {
+__global__ void gru_gate_q_kernel(const float* __restrict__ t1, const float* __restrict__ t2,
+                                  const float* __restrict__ inp, const float* __restrict__ cor,
+                                  const float* __restrict__ mot, const float* __restrict__ zr,
+                                  const float* __restrict__ h, int hw, float* __restrict__ ho, long long total) {
   long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
+  if (e >= total) return;  // total = B*128*hw
   const long long b = e / (128LL * hw), r = e - b * 128LL * hw;
+  const long long i3 = b * 384LL * hw + 256LL * hw + r;
+  const float isum = (inp[i3] + cor[i3]) + mot[i3];
+  const float q = tanhf((t1[e] + t2[e]) + isum);
   const float z = zr[b * 256LL * hw + r];
-  ho[e] = (1.f - z) * h[e] + z * q[e];
+  ho[e] = (1.f - z) * h[e] + z * q;
 }
-extern "C" int codd_gru_rh(const float* zr, const float* h, int B, int hw, float* rh, void* stream) {
-  if (!zr || !h || !rh) return CODD_EINVAL;
-  const long long total = (long long)B * 128 * hw;
-  gru_rh_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(zr, h, hw, rh, total);
+extern "C" int codd_gru_gate_zr(const float* t1, const float* t2, const float* inp, const float* cor,
+                                const float* mot, const float* h, int B, int hw, float* zr, float* rh, void* stream) {
+  if (!t1 || !t2 || !inp || !cor || !mot || !h || !zr || !rh) return CODD_EINVAL;
+  const long long total = (long long)B * 256 * hw;
+  gru_gate_zr_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(t1, t2, inp, cor, mot, h, hw, zr, rh, total);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }
-extern "C" int codd_gru_out(const float* zr, const float* q, const float* h, int B, int hw, float* hout, void* stream) {
-  if (!zr || !q || !h || !hout) return CODD_EINVAL;
+extern "C" int codd_gru_gate_q(const float* t1, const float* t2, const float* inp, const float* cor, const float* mot,
+                               const float* zr, const float* h, int B, int hw, float* hout, void* stream) {
+  if (!t1 || !t2 || !inp || !cor || !mot || !zr || !h || !hout) return CODD_EINVAL;
   const long long total = (long long)B * 128 * hw;
-  gru_out_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(zr, q, h, hw, hout, total);
+  gru_gate_q_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(t1, t2, inp, cor, mot, zr, h, hw, hout, total);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }

@@ -33,6 +33,8 @@ class ConsistentOnlineDynamicDepth(nn.Module):
     def consistent_online_depth_estimation(self, left_img, right_img, img_metas, state):
         """reference model/codd.py:80-126 (eval: everything under no_grad)."""
         with torch.no_grad():
+            if self.motion is not None and hasattr(self.motion, "prefetch"):
+                self.motion.prefetch(left_img)  # image-only work overlaps the stereo network
             outputs = self.stereo.stereo_matching(left_img, right_img, img_metas, state)
             if self.motion is not None:
                 self.motion(state, outputs, img_metas=img_metas, train_mode=False)

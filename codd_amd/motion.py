@@ -84,15 +84,10 @@ class ConvGRU(nn.Module):
             setattr(self, f"conv{g}1", nn.Conv2d(hidden_dim, hidden_dim, 3, padding=1))
             setattr(self, f"conv{g}2", nn.Conv2d(hidden_dim, hidden_dim, 3, dilation=dilation, padding=dilation))
 
-    def run(self, h, isum):
-        """isum [B,384,h,w] = inp + cor + mot (z | r | q thirds)."""
-        t = ops.conv2d(h, packed_cat((self.convz1, self.convr1)), pad=1)
-        zr = ops.conv2d(h, packed_cat((self.convz2, self.convr2)), pad=4, dil=4, act="sigmoid", res1=t,
-                        res2=Slice(isum, 0, 256))
-        rh = ops.gru_rh(zr, h)
-        t = cv(self.convq1, rh)
-        q = cv(self.convq2, rh, act="tanh", res1=t, res2=Slice(isum, 256, 128))
-        return ops.gru_out(zr, q, h)
+    def convs_zr(self, h):
+        """The two z|r gate convolutions (each 128 -> 256: convz* and convr* stacked)."""
+        return (ops.conv2d(h, packed_cat((self.convz1, self.convr1)), pad=1),
+                ops.conv2d(h, packed_cat((self.convz2, self.convr2)), pad=4, dil=4))
 
 
 def _head(cout):
@@ -115,20 +110,45 @@ class BasicUpdateBlock(nn.Module):
         self.mask = _head(576)
 
     def run(self, net, inp, corr, minfo, need_mask):
-        cor = cv(self.corr_enc[0], corr, act="relu")
-        cor = cv(self.corr_enc[2], cor, act="relu")
-        isum = cv(self.corr_enc[4], cor, res1=inp)  # inp + cor
-        mot = cv(self.flow_enc[0], minfo, act="relu")
-        isum = cv(self.flow_enc[2], mot, res1=isum)  # (inp + cor) + mot
-        net = self.gru.run(net, isum)
+        """One update (reference raft3d.py:92-106).  Launch schedule: the correlation encoder chain,
+        the flow encoder chain and the two z|r gate convolutions only depend on data available at
+        the start of the update, so they are forked onto four streams; likewise the two q
+        convolutions and the three small 1x1 heads.  A 72x120 map gives 576-block grids (2.25
+        workgroups per CU): one launch at a time leaves a quarter of the CUs idle in its last
+        round, concurrent launches fill them."""
+        g = self.gru
+        dev = net.device
+        if getattr(self, "_fork", None) is None or self._fork.dev != dev:
+            self._fork = ops.Fork(dev, 3)
+        fk = self._fork
+
+        def corr_chain():
+            c = cv(self.corr_enc[0], corr, act="relu")
+            c = cv(self.corr_enc[2], c, act="relu")
+            return cv(self.corr_enc[4], c)
+
+        def flow_chain():
+            return cv(self.flow_enc[2], cv(self.flow_enc[0], minfo, act="relu"))
+
+        t2 = fk.run(0, lambda: ops.conv2d(net, packed_cat((g.convz2, g.convr2)), pad=4, dil=4))
+        t1 = fk.run(1, lambda: ops.conv2d(net, packed_cat((g.convz1, g.convr1)), pad=1))
+        mot = fk.run(2, flow_chain)
+        cor = corr_chain()
+        fk.join()
+        zr, rh = ops.gru_gate_zr(t1, t2, inp, cor, mot, net)
+        q2 = fk.run(0, lambda: cv(g.convq2, rh))
+        q1 = cv(g.convq1, rh)
+        fk.join()
+        net = ops.gru_gate_q(q1, q2, inp, cor, mot, zr, net)
         # the four 3x3 head convs share their input: one 768/1024-channel conv; the mask head (576
         # up-sampling weights) is only consumed after the last iteration (raft3d.py:267-273)
         heads = (self.ae[0], self.delta[0], self.weight[0]) + ((self.mask[0],) if need_mask else ())
         hid = ops.conv2d(net, packed_cat(heads), pad=1, act="relu")
+        delta = fk.run(0, lambda: cv(self.delta[2], Slice(hid, 256, 256)))
+        weight = fk.run(1, lambda: cv(self.weight[2], Slice(hid, 512, 256), act="sigmoid"))
+        mask = fk.run(2, lambda: cv(self.mask[2], Slice(hid, 768, 256))) if need_mask else None
         ae = cv(self.ae[2], Slice(hid, 0, 256))
-        delta = cv(self.delta[2], Slice(hid, 256, 256))
-        weight = cv(self.weight[2], Slice(hid, 512, 256), act="sigmoid")
-        mask = cv(self.mask[2], Slice(hid, 768, 256)) if need_mask else None
+        fk.join()
         return net, mask, ae, delta, weight
 
 
@@ -151,10 +171,38 @@ class RAFT3D(nn.Module):
     def context(self, image):
         return self.cnet[1](self.cnet[0](image))
 
+    # -- side-stream prefetch ------------------------------------------------------------------
+    # fnet(image) (needed before the correlation pyramid) and cnet(image) (only needed by the NEXT
+    # frame, raft3d.py:278) depend on nothing but the current left image, so they are issued on two
+    # side HIP streams before the stereo network starts and joined where they are consumed.  Their
+    # ~200 small launches fill the CUs that HITNet's coarse levels and the GRU loop's 576-block
+    # convolutions leave idle; under stream capture this becomes two parallel branches of the frame
+    # graph.
+    def prefetch(self, image):
+        dev = image.device
+        if getattr(self, "_side", None) is None or self._side[0].device != dev:
+            self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+        cur = torch.cuda.current_stream(dev)
+        out = {}
+        for key, stream, fn in (("fmap", self._side[0], self.fnet), ("netinp", self._side[1], self.context)):
+            stream.wait_stream(cur)
+            with torch.cuda.stream(stream):
+                out[key] = fn(image)
+        self._pending = out
+
+    def _join(self, key, dev):
+        pend = getattr(self, "_pending", None)
+        if not pend or key not in pend:
+            return None
+        torch.cuda.current_stream(dev).wait_stream(self._side[0] if key == "fmap" else self._side[1])
+        return pend.pop(key)
+
     def forward(self, image_curr, depth_prev, depth_curr, intrinsics, state, outputs, iters=12, train_mode=False):
+        dev = image_curr.device
         if "memory" not in state:
-            state["raft_feat"] = self.fnet(image_curr)
-            state["raft_netinp"] = self.context(image_curr)
+            fm, ni = self._join("fmap", dev), self._join("netinp", dev)
+            state["raft_feat"] = fm if fm is not None else self.fnet(image_curr)
+            state["raft_netinp"] = ni if ni is not None else self.context(image_curr)
             return
         B, _, H, W = image_curr.shape
         h, w = H // 8, W // 8
@@ -162,7 +210,9 @@ class RAFT3D(nn.Module):
         K8 = [float(v / np.float32(8.0)) for v in K]
         fmap_prev, net_inp = state["raft_feat"], state["raft_netinp"]
         T = ops.se3_identity(B, h, w, image_curr.device)
-        fmap_curr = self.fnet(image_curr)
+        fmap_curr = self._join("fmap", dev)
+        if fmap_curr is None:
+            fmap_curr = self.fnet(image_curr)
         pyr = ops.allpairs_corr(fmap_prev, fmap_curr)
         net, inp = ops.context_split(net_inp)
         d1 = depth_prev[:, 3::8, 3::8].contiguous()
@@ -177,7 +227,8 @@ class RAFT3D(nn.Module):
         outputs["Ts"] = T_up
         outputs["weight"] = ops.cvx_upsample(weight, mask, 2)
         state["raft_feat"] = fmap_curr
-        state["raft_netinp"] = self.context(image_curr)
+        ni = self._join("netinp", dev)
+        state["raft_netinp"] = ni if ni is not None else self.context(image_curr)
 
 
 @register
@@ -190,6 +241,10 @@ class Motion(nn.Module):
         self.iters = iters
         self.raft3d = MODELS.build(raft3d)
         self.loss = build_loss(loss) if loss is not None else None
+
+    def prefetch(self, left_img):
+        """Issue the image-only parts of the motion stage (fnet, cnet) on side streams."""
+        self.raft3d.prefetch(left_img)
 
     def forward(self, state, outputs, img_metas, train_mode=False, **kwargs):
         img_curr = outputs["left_img"]

@@ -96,6 +96,7 @@ def _launch_conv(lib, p, stream):
 import os as _os
 _FORCE_NPB = int(_os.environ.get("CODD_NPB", "0"))
 _FORCE_MB = int(_os.environ.get("CODD_MB", "0"))
+_FORCE_CK = int(_os.environ.get("CODD_CK", "0"))
 
 
 def _wrow(mb):
@@ -132,6 +133,8 @@ def _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl):
     while ck > 4 and ((taps * ck * _wrow(pc.mb) + ck * chs) * 4 > budget or taps * ck * _wrow(pc.mb) > 16384
                       or ck * thi * (twp // 4) > 2048):
         ck -= 4
+    if _FORCE_CK:
+        ck = min(ck, _FORCE_CK)
     return npb, ck
 
 
@@ -380,20 +383,49 @@ def add_relu(a, b=None, relu=True, out=None):
     return out
 
 
-def gru_rh(zr, h):
+def gru_gate_zr(t1, t2, inp, cor, mot, h):
     lib = _abi.load()
-    rh = torch.empty_like(h)
-    _abi.check(lib.codd_gru_rh(zr.data_ptr(), h.data_ptr(), h.shape[0], h.shape[2] * h.shape[3], rh.data_ptr(),
-                               _stream()), "gru_rh")
-    return rh
+    B, _, hh, ww = h.shape
+    zr, rh = _f32(B, 256, hh, ww, like=h), torch.empty_like(h)
+    _abi.check(lib.codd_gru_gate_zr(t1.data_ptr(), t2.data_ptr(), inp.data_ptr(), cor.data_ptr(), mot.data_ptr(),
+                                    h.data_ptr(), B, hh * ww, zr.data_ptr(), rh.data_ptr(), _stream()), "gru_gate_zr")
+    return zr, rh
 
 
-def gru_out(zr, q, h):
+def gru_gate_q(t1, t2, inp, cor, mot, zr, h):
     lib = _abi.load()
+    B, _, hh, ww = h.shape
     ho = torch.empty_like(h)
-    _abi.check(lib.codd_gru_out(zr.data_ptr(), q.data_ptr(), h.data_ptr(), h.shape[0], h.shape[2] * h.shape[3],
-                                ho.data_ptr(), _stream()), "gru_out")
+    _abi.check(lib.codd_gru_gate_q(t1.data_ptr(), t2.data_ptr(), inp.data_ptr(), cor.data_ptr(), mot.data_ptr(),
+                                   zr.data_ptr(), h.data_ptr(), B, hh * ww, ho.data_ptr(), _stream()), "gru_gate_q")
     return ho
+
+
+class Fork:
+    """Fork / join of independent launch chains over side HIP streams (parallel branches of the
+    captured frame graph).  Discipline: every branch starts by waiting on the caller's stream, only
+    the caller's stream consumes branch outputs, and ``join`` makes it wait for every branch used
+    since the last join -- so the stream-tagged block re-use of the caching allocator stays safe."""
+
+    def __init__(self, device, n):
+        self.dev = device
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(n)]
+        self.used = []
+
+    def run(self, i, fn, *a, **k):
+        cur = torch.cuda.current_stream(self.dev)
+        s = self.streams[i]
+        if s not in self.used:
+            s.wait_stream(cur)
+            self.used.append(s)
+        with torch.cuda.stream(s):
+            return fn(*a, **k)
+
+    def join(self):
+        cur = torch.cuda.current_stream(self.dev)
+        for s in self.used:
+            cur.wait_stream(s)
+        self.used = []
 
 
 # ----------------------------------------------------------------------------------------- fusion

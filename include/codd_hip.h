@@ -206,10 +206,15 @@ int codd_resize_bilinear(const float* in, int B, int C, int Hi, int Wi, int Ho, 
 /* y = relu?(a + b) elementwise (HRNet fuse sums), n floats. */
 int codd_add_relu(const float* a, const float* b, long long n, int relu, float* y, void* stream);
 
-/* ConvGRU gate fusions (blocks/gru.py:26-34): rh = r*h ; h' = (1-z)*h + z*q.
- * zr [B,256,hw] (z | r), h [B,128,hw]. */
-int codd_gru_rh(const float* zr, const float* h, int B, int hw, float* rh, void* stream);
-int codd_gru_out(const float* zr, const float* q, const float* h, int B, int hw, float* hout, void* stream);
+/* ConvGRU gate fusions (blocks/gru.py:17-34).  t1, t2: the two gate convolutions of a gate pair
+ * (3x3 and dilated 3x3, bias included); inp / cor / mot [B,384,hw]: the three input streams.
+ *   zr [B,256,hw] = sigmoid(t1 + t2 + (inp+cor+mot)[:, :256]);  rh [B,128,hw] = r * h
+ *   hout [B,128,hw] = (1 - z) h + z tanh(t1 + t2 + (inp+cor+mot)[:, 256:]) */
+int codd_gru_gate_zr(const float* t1, const float* t2, const float* inp, const float* cor,
+                     const float* mot, const float* h, int B, int hw, float* zr, float* rh, void* stream);
+int codd_gru_gate_q(const float* t1, const float* t2, const float* inp, const float* cor,
+                    const float* mot, const float* zr, const float* h, int B, int hw, float* hout,
+                    void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fusion
