@@ -9,6 +9,9 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libcodd_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# files built without SLP vectorisation: the Gauss-Newton builder feeds its VALU from SGPRs (scalar
+# loads); v_pk_* packing forces ~50 v_mov per neighbour to assemble register pairs
+NO_SLP = {"motion.hip"} if os.environ.get("CODD_NO_SLP", "1") == "1" else set()
 
 
 def sources():
@@ -37,6 +40,8 @@ def build(force=False, verbose=True):
                    # keep MFMA accumulators in VGPRs: without it hipcc (ROCm 7.2) copies all
                    # accumulators VGPR<->AGPR around EVERY k-step of the conv loop (10 VALU per MFMA)
                    "-mllvm", "-amdgpu-mfma-vgpr-form"]
+            if os.path.basename(src) in NO_SLP:
+                cmd.append("-fno-slp-vectorize")
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

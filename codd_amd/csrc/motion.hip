@@ -293,35 +293,53 @@ __global__ __launch_bounds__(64 * GN_WAVES) void se3_gn_build_kernel(
     const bool rowin = vi && abs(yj - yi) <= radius;
     const float* rrow = rec + (size_t)yj * w * GN_JS;
     for (int xj = xlo; xj <= xhi; ++xj) {
-      const float* rp = rrow + (size_t)xj * GN_JS;  // wave-uniform address -> scalar loads
-      const float Xx = rp[32], Xy = rp[33], Xz = rp[34];
+      // wave-uniform address -> scalar loads; the whole 176-byte record is fetched up front (one
+      // batch of s_load_dwordx4/x8, one wait) instead of three dependent round trips
+      const float4* rp4 = (const float4*)(rrow + (size_t)xj * GN_JS);
+      float4 rec4[11];
+#pragma unroll
+      for (int q = 0; q < 11; ++q) rec4[q] = rp4[q];
+      const float Xx = rec4[8].x, Xy = rec4[8].y, Xz = rec4[8].z;
       const float Yx = c0.x * Xx + c1.x * Xy + c2.x * Xz + Ti.t.x;
       const float Yy = c0.y * Xx + c1.y * Xy + c2.y * Xz + Ti.t.y;
       const float Yz = c0.z * Xx + c1.z * Xy + c2.z * Xz + Ti.t.z;
       const bool in = rowin && abs(xj - xi) <= radius && Xz >= MIN_DEPTH && Yz >= MIN_DEPTH;
       float dot = 0.f;
 #pragma unroll
-      for (int c = 0; c < GN_AE; ++c) dot += ai[c] * rp[c];
-      const float d2 = fmaxf(ai2 + rp[41] - 2.f * dot, 0.f);
+      for (int q = 0; q < 8; ++q)
+        dot += ai[4 * q] * rec4[q].x + ai[4 * q + 1] * rec4[q].y + ai[4 * q + 2] * rec4[q].z + ai[4 * q + 3] * rec4[q].w;
+      const float d2 = fmaxf(ai2 + rec4[10].y - 2.f * dot, 0.f);
       const float a = (in ? 1.f : 0.f) * __builtin_amdgcn_rcpf(1.f + __expf(d2));  // sigmoid(-d2), masked (branch-free)
+      // the affinity of most neighbours underflows against the accumulated sums: skip their geometry
+      // when every lane's weight is below 1e-9 (relative effect on H, b < 1e-9; wave-uniform branch)
+      if (__ballot(a > 1e-9f) == 0ull) continue;
       const float d = __builtin_amdgcn_rcpf(fmaxf(Yz, MIN_DEPTH));
       const float xn = Yx * d, yn = Yy * d;
       const float Jx[6] = {fx * d, 0.f, -fx * xn * d, -fx * xn * yn, fx * (1.f + xn * xn), -fx * yn};
       const float Jy[6] = {0.f, fy * d, -fy * yn * d, -fy * (1.f + yn * yn), fy * xn * yn, fy * xn};
       const float Jz[6] = {0.f, 0.f, -d * d, -yn * d, xn * d, 0.f};
-      const float rx = rp[35] - (fx * xn + cx);
-      const float ry_ = rp[36] - (fy * yn + cy);
-      const float rz = rp[37] - d;
-      const float wx = a * rp[38], wy = a * rp[39], wz = a * rp[40];
+      const float rx = rec4[8].w - (fx * xn + cx);
+      const float ry_ = rec4[9].x - (fy * yn + cy);
+      const float rz = rec4[9].y - d;
+      const float wx = a * rec4[9].z, wy = a * rec4[9].w, wz = a * rec4[10].x;
       float wJx[6], wJy[6], wJz[6];
 #pragma unroll
       for (int p = 0; p < 6; ++p) { wJx[p] = wx * Jx[p]; wJy[p] = wy * Jy[p]; wJz[p] = wz * Jz[p]; }
+      // one fma chain per residual row straight into the accumulators: the structural zeros of J
+      // (Jx[1], Jy[0], Jz[0], Jz[1], Jz[5]) fold away -> 36 + 13 fma instead of 63 + 18 mul/add
       int k = 0;
 #pragma unroll
       for (int p = 0; p < 6; ++p) {
 #pragma unroll
-        for (int qq = p; qq < 6; ++qq) { Hs[k] += wJx[p] * Jx[qq] + wJy[p] * Jy[qq] + wJz[p] * Jz[qq]; ++k; }
-        bs[p] += wJx[p] * rx + wJy[p] * ry_ + wJz[p] * rz;
+        for (int qq = p; qq < 6; ++qq) {
+          Hs[k] = fmaf(wJx[p], Jx[qq], Hs[k]);
+          Hs[k] = fmaf(wJy[p], Jy[qq], Hs[k]);
+          Hs[k] = fmaf(wJz[p], Jz[qq], Hs[k]);
+          ++k;
+        }
+        bs[p] = fmaf(wJx[p], rx, bs[p]);
+        bs[p] = fmaf(wJy[p], ry_, bs[p]);
+        bs[p] = fmaf(wJz[p], rz, bs[p]);
       }
     }
   }
