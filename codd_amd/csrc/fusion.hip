@@ -172,3 +172,60 @@ extern "C" int codd_fusion_blend(const float* pred_curr, const float* pred_warp,
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// On-device disparity metrics (reference model/codd.py:456-471, utils/metric.py:9-17,40-54):
+// per frame, over the valid mask lo < gt < hi of the cropped region [0,h) x [0,w):
+//   epe = mean |pred - gt|,  thN = mean (|pred - gt| > thr)
+// and the sequence meters accumulate the per-frame means (AverageMeter semantics):
+//   meters[0] += epe, meters[1] += th, meters[2] += 1   (only when the mask is non-empty)
+// Two launches, no atomics, no host sync: block partials in fp64, then a single-block finish.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void disp_metrics_partial_kernel(const float* __restrict__ pred,
+                                                                   const float* __restrict__ gt, int W, int h, int w,
+                                                                   float lo, float hi, float thr, long long HW,
+                                                                   double* __restrict__ partial) {
+  __shared__ double red[3][4];
+  const int b = blockIdx.y;
+  const long long n = (long long)h * w;
+  double se = 0.0, st = 0.0, sc = 0.0;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const int y = (int)(e / w), x = (int)(e - (long long)y * w);
+    const size_t idx = (size_t)b * HW + (size_t)y * W + x;
+    const float g = gt[idx];
+    if (g > lo && g < hi) {
+      const float err = fabsf(pred[idx] - g);
+      se += (double)err; st += err > thr ? 1.0 : 0.0; sc += 1.0;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { se += __shfl_xor(se, o, 64); st += __shfl_xor(st, o, 64); sc += __shfl_xor(sc, o, 64); }
+  if (lane == 0) { red[0][wave] = se; red[1][wave] = st; red[2][wave] = sc; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double* p = partial + ((size_t)b * gridDim.x + blockIdx.x) * 3;
+    for (int k = 0; k < 3; ++k) p[k] = red[k][0] + red[k][1] + red[k][2] + red[k][3];
+  }
+}
+__global__ void disp_metrics_finish_kernel(const double* __restrict__ partial, int nblk, int B,
+                                           double* __restrict__ meters) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int b = 0; b < B; ++b) {
+    double se = 0.0, st = 0.0, sc = 0.0;
+    for (int i = 0; i < nblk; ++i) { const double* p = partial + ((size_t)b * nblk + i) * 3; se += p[0]; st += p[1]; sc += p[2]; }
+    if (sc > 0.0) { meters[0] += se / sc; meters[1] += st / sc; meters[2] += 1.0; }
+  }
+}
+
+extern "C" int codd_disp_metrics(const float* pred, const float* gt, int B, int H, int W, int h, int w, float lo,
+                                 float hi, float thr, double* scratch, double* meters, void* stream) {
+  if (!pred || !gt || !scratch || !meters || h > H || w > W || h < 1 || w < 1) return CODD_EINVAL;
+  const int nblk = 128;
+  hipStream_t s = (hipStream_t)stream;
+  disp_metrics_partial_kernel<<<dim3(nblk, B), 256, 0, s>>>(pred, gt, W, h, w, lo, hi, thr, (long long)H * W, scratch);
+  CODD_LAUNCH_CHECK();
+  disp_metrics_finish_kernel<<<1, 64, 0, s>>>(scratch, nblk, B, meters);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}

@@ -71,6 +71,16 @@ class SequenceMetrics:
         self.prev = None
         self.device = device
 
+    def update_disparity_device(self, pred, gt, crop_hw):
+        """EPE / 3-px rate of one frame through the HIP metric kernel (2 launches, no torch ops, no
+        host sync).  pred, gt: full padded [B,1,H,W] device tensors; crop_hw = img_shape[:2]."""
+        from . import ops
+        if getattr(self, "_dev_meters", None) is None:
+            self._dev_meters = torch.zeros(3, device=self.device, dtype=torch.float64)
+            self._dev_scratch = torch.empty(3 * 128 * pred.shape[0], device=self.device, dtype=torch.float64)
+        ops.disp_metrics(pred, gt, crop_hw, self.meta["disp_range"][0], self.meta["disp_range"][1], 3.0,
+                         self._dev_meters, self._dev_scratch)
+
     def update(self, pred, gt, gt_flow=None):
         """pred, gt [B,1,h,w]; gt_flow [B,2,h,w] = flow from THIS frame to the next (reference
         state['gt_flow'][-2] semantics when the next frame arrives)."""
@@ -100,6 +110,11 @@ class SequenceMetrics:
         """[12] fp64 tensor; columns without data are NaN (reference nanmean semantics)."""
         nan = torch.full((), float("nan"), device=self.device, dtype=torch.float64)
         vals = [self.m[k].avg() for k in COLUMNS[:7]] + [nan] * 5
+        if getattr(self, "_dev_meters", None) is not None:  # HIP-kernel meters take precedence
+            dm = self._dev_meters
+            ok = dm[2] > 0
+            vals[0] = torch.where(ok, dm[0] / dm[2].clamp(min=1), nan)
+            vals[1] = torch.where(ok, dm[1] / dm[2].clamp(min=1), nan)
         return torch.stack(vals)
 
 

@@ -179,6 +179,9 @@ class RAFT3D(nn.Module):
     # convolutions leave idle; under stream capture this becomes two parallel branches of the frame
     # graph.
     def prefetch(self, image):
+        if ops.Fork.serial:
+            self._pending = None
+            return
         dev = image.device
         if getattr(self, "_side", None) is None or self._side[0].device != dev:
             self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))

@@ -407,12 +407,16 @@ class Fork:
     the caller's stream consumes branch outputs, and ``join`` makes it wait for every branch used
     since the last join -- so the stream-tagged block re-use of the caching allocator stays safe."""
 
+    serial = False  # debugging / per-launch timing: run every branch on the caller's stream
+
     def __init__(self, device, n):
         self.dev = device
         self.streams = [torch.cuda.Stream(device=device) for _ in range(n)]
         self.used = []
 
     def run(self, i, fn, *a, **k):
+        if Fork.serial:
+            return fn(*a, **k)
         cur = torch.cuda.current_stream(self.dev)
         s = self.streams[i]
         if s not in self.used:
@@ -459,3 +463,16 @@ def fusion_blend(pred_curr, pred_warp, wf_lr, wr, ds=4):
                                      B, H, W, ds, fused.data_ptr(), wf.data_ptr(), wro.data_ptr(), _stream()),
                "fusion_blend")
     return fused, wf, wro
+
+
+def disp_metrics(pred, gt, crop_hw, lo, hi, thr, meters, scratch=None):
+    """Accumulate EPE / threshold-rate of one frame into ``meters`` ([3] fp64 on the device)."""
+    lib = _abi.load()
+    _require_gpu(pred)
+    B, _, H, W = pred.shape
+    if scratch is None:
+        scratch = torch.empty(3 * 128 * B, device=pred.device, dtype=torch.float64)
+    _abi.check(lib.codd_disp_metrics(pred.data_ptr(), gt.data_ptr(), B, H, W, crop_hw[0], crop_hw[1], float(lo),
+                                     float(hi), float(thr), scratch.data_ptr(), meters.data_ptr(), _stream()),
+               "disp_metrics")
+    return meters

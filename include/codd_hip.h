@@ -239,6 +239,13 @@ int codd_fusion_blend(const float* pred_curr, const float* pred_warp, const floa
                       const float* wr_logit_sig, int B, int H, int W, int ds,
                       float* fused, float* wf_out, float* wr_out, void* stream);
 
+/* On-device disparity metrics (model/codd.py:456-471; utils/metric.py:9-17,40-54): over the mask
+ * lo < gt < hi of the crop [0,h) x [0,w) of [B,1,H,W] maps, adds the frame's EPE, its > thr rate and
+ * 1 to meters[0..2] (fp64, AverageMeter semantics) when the mask is non-empty.  No host sync.
+ * scratch: 3*128*B doubles. */
+int codd_disp_metrics(const float* pred, const float* gt, int B, int H, int W, int h, int w,
+                      float lo, float hi, float thr, double* scratch, double* meters, void* stream);
+
 int codd_abi_version(void);
 
 #ifdef __cplusplus

@@ -208,3 +208,18 @@ def test_full_codd_sequence(iters):
         epe = (got[:, f] - ref[:, f]).abs().mean().item()
         print(f"frame {f}: EPE delta {epe:.3e}  max {(got[:, f] - ref[:, f]).abs().max().item():.3e}")
         assert epe < 1e-3
+
+
+def test_disp_metrics_kernel_matches_torch_reference():
+    from codd_amd import metrics
+    H, W, h, w = 64, 96, 60, 90
+    meta = dict(disp_range=(1, 210))
+    sm_t, sm_d = metrics.SequenceMetrics(meta, torch.device("cpu")), metrics.SequenceMetrics(meta, torch.device(DEV))
+    for f in range(3):
+        gt = (rnd(1, 1, H, W, seed=f) * 40 + 60).clamp(0, 250)
+        gt[0, 0, 5:9, 7:30] = 0.0  # invalid
+        pred = gt + rnd(1, 1, H, W, seed=10 + f) * 3
+        sm_t.update(pred[:, :, :h, :w], gt[:, :, :h, :w])
+        sm_d.update_disparity_device(pred.to(DEV), gt.to(DEV), (h, w))
+    rt, rd = sm_t.row(), sm_d.row().cpu()
+    assert abs(rt[0].item() - rd[0].item()) < 1e-6 and abs(rt[1].item() - rd[1].item()) < 1e-9
