@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--stereo-only", action="store_true")
+    ap.add_argument("--serial-streams", action="store_true",
+                    help="disable the fork/join side streams (every launch on one stream) -- used for the "
+                         "rocprofv3 run whose per-kernel averages are compared with the roofline numbers")
     ap.add_argument("--height", type=int, default=PAD_H)
     ap.add_argument("--width", type=int, default=PAD_W)
     return ap.parse_args()
@@ -90,6 +93,7 @@ def conv_roofline(runner, frames, device):
         return rc
 
     ops._launch_conv = timed
+    serial_before = ops.Fork.serial
     ops.Fork.serial = True  # one launch at a time, so that every event pair brackets exactly one kernel
     try:
         l, r = frames
@@ -97,7 +101,7 @@ def conv_roofline(runner, frames, device):
         torch.cuda.synchronize(device)
     finally:
         ops._launch_conv = orig
-        ops.Fork.serial = False
+        ops.Fork.serial = serial_before
     t_ms = sum(s.elapsed_time(e) for s, e, _ in recs)
     flops = sum(f for _, _, f in recs)
     return dict(launches=len(recs), time_ms=t_ms, gflop=flops / 1e9)
@@ -169,6 +173,9 @@ def main():
     from codd_amd.runtime import FrameRunner
 
     est = build_model(args, device)
+    if args.serial_streams:
+        from codd_amd import ops as _ops
+        _ops.Fork.serial = True
     H, W = args.height, args.width
     MF = 6  # distinct synthetic frames, cycled (frame t+1 = frame t translated by a sub-pixel flow)
     img, r_img, gt = synth.stereo_sequence(H, W, MF)
@@ -244,7 +251,7 @@ def main():
                                    f" {raw_w}x{raw_h} padded to {W}x{H}, max_disp=320, one video per GPU, "
                                    "steady-state frames (idx>=1), synthetic stereo sequence, random-init weights",
                        "hip_graph": bool(runner.graph is not None), "frames_per_gpu": args.steps,
-                       "prewarm_frames": args.prewarm,
+                       "prewarm_frames": args.prewarm, "side_streams": not args.serial_streams,
                        "fps_per_gpu": round(fps / world, 3)},
             "epe_vs_synthetic_gt": red["epe"][0],
             "roofline": roof, "cpu_baseline": cpu,
