@@ -163,8 +163,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # launched by torch.distributed.run -> RCCL even at N = 1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -202,7 +204,7 @@ def main():
     seqm = metrics.SequenceMetrics(metas[0][0], device)
 
     torch.cuda.synchronize(device)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
@@ -212,11 +214,11 @@ def main():
         seqm.update_disparity_device(d, g, (raw_h, raw_w))  # on-device EPE meters: 2 HIP launches, no sync
     red = metrics.reduce_rows([seqm.row()], device)  # the job's only collective (RCCL all_reduce)
     torch.cuda.synchronize(device)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
@@ -257,7 +259,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

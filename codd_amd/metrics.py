@@ -133,7 +133,7 @@ def reduce_rows(rows, device=None, group=None):
         acc[0] += v
         acc[1] += v * v
         acc[2] += ok.double()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
     acc = acc.cpu()
     out = {}
