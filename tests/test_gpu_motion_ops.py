@@ -223,3 +223,49 @@ def test_disp_metrics_kernel_matches_torch_reference():
         sm_d.update_disparity_device(pred.to(DEV), gt.to(DEV), (h, w))
     rt, rd = sm_t.row(), sm_d.row().cpu()
     assert abs(rt[0].item() - rd[0].item()) < 1e-6 and abs(rt[1].item() - rd[1].item()) < 1e-9
+
+
+@pytest.mark.parametrize("H,W,intr", [(128, 384, (240.0, 240.0, 190.0, 62.0))])
+def test_full_codd_kitti_aspect_matches_oracle(H, W, intr):
+    """BASELINE config 4 aspect ratio (1242x375 -> 1280x384) scaled down, iters=4, through hipGraph replay.
+
+    With random-init weights the estimated motion is wild (|t| ~ 0.4 per frame), many splatted points
+    pass close to the camera and the warped disparity bf/z takes values of several hundred px: the
+    discontinuous selections of the path (nearest-z point, `disp_warp > W -> 0`, `pred_warp > 0`
+    masks; SURVEY.md section 7 'hard parts') then flip for a handful of pixels under 1e-6 input
+    differences and each flip costs hundreds of px.  The test therefore bounds the FRACTION of
+    flipped pixels and the EPE over the others (the north-star 1e-3 bound), and requires graph
+    replay to be bit-identical to eager execution."""
+    from codd_amd import synth
+    from codd_amd.runtime import FrameRunner
+    from oracle import codd as oc
+    est, sd = _model(4)
+    MF = 3
+    img, r_img, _ = synth.stereo_sequence(H, W, MF)
+    metas = synth.default_metas(H, W, intrinsics=intr)
+    ref = oc.inference(sd, img, r_img, metas, iters=4)
+    rg, re = FrameRunner(est, metas[0], use_graph=True), FrameRunner(est, metas[0], use_graph=False)
+    for f in range(MF):
+        l, r = img[:, f].to(DEV).contiguous(), r_img[:, f].to(DEV).contiguous()
+        d = rg.step(l, r).clone()
+        assert torch.equal(d, re.step(l, r)), "graph replay differs from eager execution"
+        diff = (d.cpu()[:, 0] - ref[:, f]).abs()
+        flipped = diff > 0.25
+        epe_rest = diff[~flipped].mean().item()
+        print(f"frame {f} (graph={rg.graph is not None}): flipped {flipped.float().mean().item():.2e}, "
+              f"EPE delta elsewhere {epe_rest:.3e}, raw EPE delta {diff.mean().item():.3e}")
+        assert flipped.float().mean().item() < 5e-3 and epe_rest < 1e-3
+
+
+@pytest.mark.parametrize("H,W,intr", [(384, 1280, (721.54, 721.54, 621.0, 187.5)), (512, 640, (320.0, 320.0, 320.0, 240.0))])
+def test_full_codd_runs_at_baseline_shapes(H, W, intr):
+    """BASELINE configs 4 / 5 padded shapes: the full path runs (graph replay) and stays finite."""
+    from codd_amd import synth
+    from codd_amd.runtime import FrameRunner
+    est, _ = _model(16)
+    img, r_img, _ = synth.stereo_sequence(H, W, 3)
+    metas = synth.default_metas(H, W, intrinsics=intr)
+    runner = FrameRunner(est, metas[0], use_graph=True)
+    for f in range(5):
+        d = runner.step(img[:, f % 3].to(DEV).contiguous(), r_img[:, f % 3].to(DEV).contiguous())
+    assert d.shape == (1, 1, H, W) and torch.isfinite(d).all()
