@@ -109,18 +109,31 @@ class BasicUpdateBlock(nn.Module):
         self.weight = _head(3)
         self.mask = _head(576)
 
-    def run(self, net, inp, corr, minfo, need_mask):
+    def zr_convs(self, net):
+        """Fork the two z|r gate convolutions of the NEXT update: they depend on the hidden state
+        only, so they run beside this update's head convolution and the (VALU-bound) Gauss-Newton
+        step instead of competing with the next correlation-encoder chain."""
+        g = self.gru
+        fk = self._forks(net.device)[1]
+        t2 = fk.run(0, lambda: ops.conv2d(net, packed_cat((g.convz2, g.convr2)), pad=4, dil=4))
+        t1 = fk.run(1, lambda: ops.conv2d(net, packed_cat((g.convz1, g.convr1)), pad=1))
+        return t1, t2
+
+    def _forks(self, dev):
+        if getattr(self, "_fk", None) is None or self._fk[0].dev != dev:
+            self._fk = (ops.Fork(dev, 3), ops.Fork(dev, 2))
+        return self._fk
+
+    def run(self, net, inp, corr, minfo, need_mask, zr=None, prefetch_next=False):
         """One update (reference raft3d.py:92-106).  Launch schedule: the correlation encoder chain,
         the flow encoder chain and the two z|r gate convolutions only depend on data available at
-        the start of the update, so they are forked onto four streams; likewise the two q
+        the start of the update, so they are forked onto side streams; likewise the two q
         convolutions and the three small 1x1 heads.  A 72x120 map gives 576-block grids (2.25
         workgroups per CU): one launch at a time leaves a quarter of the CUs idle in its last
-        round, concurrent launches fill them."""
+        round, concurrent launches fill them.  ``zr`` = z|r convolutions already forked by the
+        previous update (``prefetch_next``); returns (net, mask, ae, delta, weight, zr_next)."""
         g = self.gru
-        dev = net.device
-        if getattr(self, "_fork", None) is None or self._fork.dev != dev:
-            self._fork = ops.Fork(dev, 3)
-        fk = self._fork
+        fk, fkz = self._forks(net.device)
 
         def corr_chain():
             c = cv(self.corr_enc[0], corr, act="relu")
@@ -130,16 +143,19 @@ class BasicUpdateBlock(nn.Module):
         def flow_chain():
             return cv(self.flow_enc[2], cv(self.flow_enc[0], minfo, act="relu"))
 
-        t2 = fk.run(0, lambda: ops.conv2d(net, packed_cat((g.convz2, g.convr2)), pad=4, dil=4))
-        t1 = fk.run(1, lambda: ops.conv2d(net, packed_cat((g.convz1, g.convr1)), pad=1))
+        if zr is None:
+            zr = self.zr_convs(net)
+        t1, t2 = zr
         mot = fk.run(2, flow_chain)
         cor = corr_chain()
         fk.join()
-        zr, rh = ops.gru_gate_zr(t1, t2, inp, cor, mot, net)
+        fkz.join()
+        zr_g, rh = ops.gru_gate_zr(t1, t2, inp, cor, mot, net)
         q2 = fk.run(0, lambda: cv(g.convq2, rh))
         q1 = cv(g.convq1, rh)
         fk.join()
-        net = ops.gru_gate_q(q1, q2, inp, cor, mot, zr, net)
+        net = ops.gru_gate_q(q1, q2, inp, cor, mot, zr_g, net)
+        zr_next = self.zr_convs(net) if prefetch_next else None
         # the four 3x3 head convs share their input: one 768/1024-channel conv; the mask head (576
         # up-sampling weights) is only consumed after the last iteration (raft3d.py:267-273)
         heads = (self.ae[0], self.delta[0], self.weight[0]) + ((self.mask[0],) if need_mask else ())
@@ -149,7 +165,7 @@ class BasicUpdateBlock(nn.Module):
         mask = fk.run(2, lambda: cv(self.mask[2], Slice(hid, 768, 256))) if need_mask else None
         ae = cv(self.ae[2], Slice(hid, 0, 256))
         fk.join()
-        return net, mask, ae, delta, weight
+        return net, mask, ae, delta, weight, zr_next
 
 
 @register
@@ -220,11 +236,12 @@ class RAFT3D(nn.Module):
         net, inp = ops.context_split(net_inp)
         d1 = depth_prev[:, 3::8, 3::8].contiguous()
         d2 = depth_curr[:, 3::8, 3::8].contiguous()
-        mask = weight = None
+        mask = weight = zr = None
         for it in range(iters):
             xyz, minfo = ops.raft_geometry(T, d1, d2, K8)
             corr = ops.corr_lookup(pyr, xyz, h, w)
-            net, mask, ae, delta, weight = self.update_block.run(net, inp, corr, minfo, need_mask=it == iters - 1)
+            net, mask, ae, delta, weight, zr = self.update_block.run(net, inp, corr, minfo, need_mask=it == iters - 1,
+                                                                     zr=zr, prefetch_next=it < iters - 1)
             ops.se3_gn_step(T, ae, xyz, delta, weight, d1, K8, radius=32)
         T_up = ops.cvx_upsample(T, mask, 1)
         outputs["Ts"] = T_up
