@@ -229,3 +229,106 @@ extern "C" int codd_disp_metrics(const float* pred, const float* gt, int B, int 
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Temporal metrics (reference model/codd.py:473-521, utils/metric.py:19-37, utils/warp.py:69-92):
+// the current frame's (gt, pred, valid mask) are pulled back to the previous frame with the previous
+// frame's GT flow (nearest sampling, zeros outside), and over mask_prev & mask_warp & mask_curr
+//   tepe = |(pred_w - pred_prev) - (gt_w - gt_prev)|,  rel = tepe / (|gt_w - gt_prev| + 1e-3)
+// meters[0..3] += mean tepe, mean (tepe > 3), mean rel, mean (rel > 1); meters[4] += 1 (non-empty);
+// meters[5] += mean |flow|, meters[6] += 1.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tepe_partial_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                           const float* __restrict__ pred_prev,
+                                                           const float* __restrict__ gt_prev,
+                                                           const float* __restrict__ flow, int W, int h, int w, float lo,
+                                                           float hi, float bf, long long HW, double* __restrict__ partial) {
+  __shared__ double red[6][4];
+  const int b = blockIdx.y;
+  const long long n = (long long)h * w;
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const int y = (int)(e / w), x = (int)(e - (long long)y * w);
+    const size_t idx = (size_t)b * HW + (size_t)y * W + x;
+    const float fx = flow[(size_t)b * 2 * HW + (size_t)y * W + x], fy = flow[(size_t)b * 2 * HW + HW + (size_t)y * W + x];
+    s[5] += (double)sqrtf(fx * fx + fy * fy);
+    const float gp = gt_prev[idx];
+    const bool mprev = gp > lo && gp < hi;
+    // nearest sample of the cropped [h,w] maps at (x + fx, y + fy), align_corners = True
+    const float sx = nearbyintf((float)x + fx), sy = nearbyintf((float)y + fy);
+    if (!(sx >= 0.f && sx <= (float)(w - 1) && sy >= 0.f && sy <= (float)(h - 1))) continue;
+    const size_t sidx = (size_t)b * HW + (size_t)((int)sy) * W + (int)sx;
+    const float gw = gt[sidx], pw = pred[sidx];
+    // mask of the current frame (disp range & |flow| < BF) at the SAMPLED and at the UNWARPED position
+    const float fxs = flow[(size_t)b * 2 * HW + (size_t)((int)sy) * W + (int)sx];
+    const float fys = flow[(size_t)b * 2 * HW + HW + (size_t)((int)sy) * W + (int)sx];
+    const bool mw = gw > lo && gw < hi && sqrtf(fxs * fxs + fys * fys) < bf;
+    const float gc = gt[idx];
+    const bool mc = gc > lo && gc < hi && sqrtf(fx * fx + fy * fy) < bf;
+    if (!(mprev && mw && mc)) continue;
+    const float dgt = gw - gp;
+    const float te = fabsf((pw - pred_prev[idx]) - dgt);
+    const float rel = te / (fabsf(dgt) + 1e-3f);
+    s[0] += (double)te; s[1] += te > 3.f ? 1.0 : 0.0; s[2] += (double)rel; s[3] += rel > 1.f ? 1.0 : 0.0; s[4] += 1.0;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s[k] += __shfl_xor(s[k], o, 64);
+    if (lane == 0) red[k][wave] = s[k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double* p = partial + ((size_t)b * gridDim.x + blockIdx.x) * 6;
+    for (int k = 0; k < 6; ++k) p[k] = red[k][0] + red[k][1] + red[k][2] + red[k][3];
+  }
+}
+__global__ void tepe_finish_kernel(const double* __restrict__ partial, int nblk, int B, double npix,
+                                   double* __restrict__ meters) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int b = 0; b < B; ++b) {
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < nblk; ++i) for (int k = 0; k < 6; ++k) s[k] += partial[((size_t)b * nblk + i) * 6 + k];
+    if (s[4] > 0.0) { for (int k = 0; k < 4; ++k) meters[k] += s[k] / s[4]; meters[4] += 1.0; }
+    meters[5] += s[5] / npix; meters[6] += 1.0;
+  }
+}
+
+extern "C" int codd_tepe_metrics(const float* pred, const float* gt, const float* pred_prev, const float* gt_prev,
+                                 const float* flow_prev, int B, int H, int W, int h, int w, float lo, float hi,
+                                 float bf, double* scratch, double* meters, void* stream) {
+  if (!pred || !gt || !pred_prev || !gt_prev || !flow_prev || !scratch || !meters || h > H || w > W) return CODD_EINVAL;
+  const int nblk = 128;
+  hipStream_t s = (hipStream_t)stream;
+  tepe_partial_kernel<<<dim3(nblk, B), 256, 0, s>>>(pred, gt, pred_prev, gt_prev, flow_prev, W, h, w, lo, hi, bf,
+                                                    (long long)H * W, scratch);
+  CODD_LAUNCH_CHECK();
+  tepe_finish_kernel<<<1, 64, 0, s>>>(scratch, nblk, B, (double)h * w, meters);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Input pre-processing (reference datasets/transforms.py:147-161 Pad(size_divisor=64, reflect),
+// :373-427 Normalize(mean, std, to_rgb), datasets/formating.py:65-85): uint8 HWC BGR image ->
+// fp32 CHW RGB, (x - mean) / std, reflect-padded (cv2.BORDER_REFLECT_101) on the bottom / right.
+// ------------------------------------------------------------------------------------------------
+__global__ void preprocess_kernel(const unsigned char* __restrict__ img, int h, int w, int bgr, float m0, float m1,
+                                  float m2, float s0, float s1, float s2, int H, int W, float* __restrict__ out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  const int sx = x < w ? x : 2 * (w - 1) - x, sy = y < h ? y : 2 * (h - 1) - y;  // reflect without edge repeat
+  const unsigned char* p = img + ((size_t)sy * w + sx) * 3;
+  const float c0 = bgr ? p[2] : p[0], c1 = p[1], c2 = bgr ? p[0] : p[2];
+  const size_t N = (size_t)H * W, o = (size_t)y * W + x;
+  out[o] = (c0 - m0) / s0; out[N + o] = (c1 - m1) / s1; out[2 * N + o] = (c2 - m2) / s2;
+}
+extern "C" int codd_preprocess(const unsigned char* img, int h, int w, int bgr, const float* mean, const float* stdv,
+                               int H, int W, float* out, void* stream) {
+  if (!img || !mean || !stdv || !out || H < h || W < w || H - h >= h || W - w >= w) return CODD_EINVAL;
+  preprocess_kernel<<<dim3(cdiv(W, 256), H), 256, 0, (hipStream_t)stream>>>(img, h, w, bgr, mean[0], mean[1], mean[2],
+                                                                            stdv[0], stdv[1], stdv[2], H, W, out);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}

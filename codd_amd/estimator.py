@@ -66,12 +66,20 @@ class ConsistentOnlineDynamicDepth(nn.Module):
     def inference(self, img, r_img, img_meta, reciprocal=False, evaluate=False, rescale=True, **kwargs):
         """reference model/codd.py:290-398.  img, r_img: [B, MF, 3, H, W].  With evaluate=False
         returns disparities [B, MF, h, w] cropped to ``img_shape``."""
-        if evaluate:
-            raise NotImplementedError("use codd_amd.metrics.evaluate_sequence for on-device metrics")
         self.reset_inference_state()
         img_h, img_w = img_meta[0]["img_shape"][:2]
+        seqm, gt_disp, gt_flow = None, None, None
+        if evaluate:
+            # metrics stay on the device (HIP reduction kernels, no per-frame .item() syncs); the
+            # reference's calc_metric (model/codd.py:435-521) is restated in codd_amd.metrics.
+            from .metrics import SequenceMetrics
+            assert kwargs.get("gt_disp") is not None, "No ground truth provided"
+            gt_disp = [g.contiguous() for g in torch.unbind(kwargs["gt_disp"][0], 1)]
+            if kwargs.get("gt_flow") is not None:
+                gt_flow = [g.contiguous() for g in torch.unbind(kwargs["gt_flow"][0], 1)]
+            seqm = SequenceMetrics(img_meta[0], img.device)
         outputs = []
-        for l_img, r in zip(torch.unbind(img, 1), torch.unbind(r_img, 1)):
+        for idx, (l_img, r) in enumerate(zip(torch.unbind(img, 1), torch.unbind(r_img, 1))):
             out = self.consistent_online_depth_estimation(l_img.contiguous(), r.contiguous(), img_meta,
                                                           self.inference_state)
             pred = out["pred_disp"]
@@ -79,9 +87,37 @@ class ConsistentOnlineDynamicDepth(nn.Module):
                 pred = img_meta[0]["calib"] / pred
             self.inference_state["pred_disp"].append(pred)
             outputs.append(pred[:, :, :img_h, :img_w])
+            if evaluate:
+                seqm.update_disparity_device(pred, gt_disp[idx], (img_h, img_w))
+                if idx > 0 and gt_flow is not None:
+                    seqm.update_temporal_device(pred, gt_disp[idx], self.inference_state["pred_disp"][-2],
+                                                gt_disp[idx - 1], gt_flow[idx - 1], (img_h, img_w))
+        if evaluate:
+            from .metrics import COLUMNS
+            row = seqm.row()
+            return {k: row[i:i + 1] for i, k in enumerate(COLUMNS)}
         outputs = torch.cat(outputs, 1)
         assert outputs.dim() == 4, "Output shape is wrong"
         return outputs
+
+    def show_result(self, filename, result, show=False, out_file=None, running_stats=None, **kwargs):
+        """reference model/codd.py:577-599: push the metric row, or write ``<out_file>.disp.pred.npz``."""
+        import os.path as osp
+        import numpy as np
+        if not show:
+            if running_stats is not None:
+                result = result[0]
+                if running_stats.header is None:
+                    running_stats.header = ["filename"] + list(result.keys())
+                running_stats.push(filename, [result[k].cpu().item() for k in result.keys()])
+        else:
+            disp = result[0].cpu().numpy()
+            os_dir = osp.dirname(out_file)
+            if os_dir:
+                import os
+                os.makedirs(os_dir, exist_ok=True)
+            with open(out_file.replace(osp.splitext(out_file)[1], ".disp.pred.npz"), "wb") as f:
+                np.savez_compressed(f, disp=disp)
 
     def train(self, mode=True):
         """reference model/codd.py:601-612 overrides train(); kept chainable here."""

@@ -81,6 +81,16 @@ class SequenceMetrics:
         ops.disp_metrics(pred, gt, crop_hw, self.meta["disp_range"][0], self.meta["disp_range"][1], 3.0,
                          self._dev_meters, self._dev_scratch)
 
+    def update_temporal_device(self, pred, gt, pred_prev, gt_prev, flow_prev, crop_hw):
+        """TEPE family + flow magnitude of one frame pair through the HIP kernel (no host sync).
+        flow_prev [B,2,H,W]: GT flow of the PREVIOUS frame (reference state['gt_flow'][-2])."""
+        from . import ops
+        if getattr(self, "_dev_tmeters", None) is None:
+            self._dev_tmeters = torch.zeros(7, device=self.device, dtype=torch.float64)
+            self._dev_tscratch = torch.empty(6 * 128 * pred.shape[0], device=self.device, dtype=torch.float64)
+        ops.tepe_metrics(pred, gt, pred_prev, gt_prev, flow_prev, crop_hw, self.meta["disp_range"][0],
+                         self.meta["disp_range"][1], BF_DEFAULT, self._dev_tmeters, self._dev_tscratch)
+
     def update(self, pred, gt, gt_flow=None):
         """pred, gt [B,1,h,w]; gt_flow [B,2,h,w] = flow from THIS frame to the next (reference
         state['gt_flow'][-2] semantics when the next frame arrives)."""
@@ -115,6 +125,12 @@ class SequenceMetrics:
             ok = dm[2] > 0
             vals[0] = torch.where(ok, dm[0] / dm[2].clamp(min=1), nan)
             vals[1] = torch.where(ok, dm[1] / dm[2].clamp(min=1), nan)
+        if getattr(self, "_dev_tmeters", None) is not None:
+            tm = self._dev_tmeters
+            ok = tm[4] > 0
+            for col, k in ((2, 0), (3, 1), (4, 2), (5, 3)):  # tepe, th3_tepe, tepe_rel, th1_tepe_rel
+                vals[col] = torch.where(ok, tm[k] / tm[4].clamp(min=1), nan)
+            vals[6] = torch.where(tm[6] > 0, tm[5] / tm[6].clamp(min=1), nan)
         return torch.stack(vals)
 
 

@@ -476,3 +476,34 @@ def disp_metrics(pred, gt, crop_hw, lo, hi, thr, meters, scratch=None):
                                      float(hi), float(thr), scratch.data_ptr(), meters.data_ptr(), _stream()),
                "disp_metrics")
     return meters
+
+
+def tepe_metrics(pred, gt, pred_prev, gt_prev, flow_prev, crop_hw, lo, hi, bf, meters, scratch=None):
+    """Accumulate the temporal metrics of one frame pair into ``meters`` ([7] fp64 on the device)."""
+    lib = _abi.load()
+    _require_gpu(pred)
+    B, _, H, W = pred.shape
+    if scratch is None:
+        scratch = torch.empty(6 * 128 * B, device=pred.device, dtype=torch.float64)
+    _abi.check(lib.codd_tepe_metrics(pred.data_ptr(), gt.data_ptr(), pred_prev.data_ptr(), gt_prev.data_ptr(),
+                                     flow_prev.data_ptr(), B, H, W, crop_hw[0], crop_hw[1], float(lo), float(hi),
+                                     float(bf), scratch.data_ptr(), meters.data_ptr(), _stream()), "tepe_metrics")
+    return meters
+
+
+IMAGENET_MEAN = (123.675, 116.28, 103.53)  # reference configs/datasets/custom.py:9
+IMAGENET_STD = (58.395, 57.12, 57.375)
+
+
+def preprocess(img_u8, bgr=True, mean=IMAGENET_MEAN, std=IMAGENET_STD, divisor=64):
+    """uint8 [h,w,3] device image -> normalised, reflect-padded fp32 [1,3,H,W] (H, W multiples of 64)."""
+    lib = _abi.load()
+    _require_gpu(img_u8)
+    assert img_u8.dtype == torch.uint8 and img_u8.dim() == 3 and img_u8.shape[2] == 3 and img_u8.is_contiguous()
+    h, w = img_u8.shape[:2]
+    H, W = -(-h // divisor) * divisor, -(-w // divisor) * divisor
+    out = torch.empty(1, 3, H, W, device=img_u8.device, dtype=torch.float32)
+    m, s = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    _abi.check(lib.codd_preprocess(img_u8.data_ptr(), h, w, int(bgr), m, s, H, W, out.data_ptr(), _stream()),
+               "preprocess")
+    return out

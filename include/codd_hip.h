@@ -246,6 +246,20 @@ int codd_fusion_blend(const float* pred_curr, const float* pred_warp, const floa
 int codd_disp_metrics(const float* pred, const float* gt, int B, int H, int W, int h, int w,
                       float lo, float hi, float thr, double* scratch, double* meters, void* stream);
 
+/* Temporal metrics (model/codd.py:473-521; utils/metric.py:19-37; utils/warp.py:69-92): pulls the current
+ * (gt, pred, mask) back with the previous frame's GT flow [B,2,H,W] (nearest, zeros) and adds the
+ * frame's mean TEPE, (TEPE>3) rate, relative TEPE, (rel>1) rate and 1 to meters[0..4] (when the joint mask
+ * is non-empty), mean |flow| and 1 to meters[5..6].  scratch: 6*128*B doubles.  No host sync. */
+int codd_tepe_metrics(const float* pred, const float* gt, const float* pred_prev, const float* gt_prev,
+                      const float* flow_prev, int B, int H, int W, int h, int w, float lo, float hi,
+                      float bf, double* scratch, double* meters, void* stream);
+
+/* Input pre-processing (datasets/transforms.py:147-161,373-427; formating.py:65-85): uint8 HWC image
+ * (device) -> fp32 CHW RGB, (x - mean)/std, reflect-padded bottom/right to [3,H,W].  mean/stdv: host
+ * pointers to 3 floats in RGB order. */
+int codd_preprocess(const unsigned char* img, int h, int w, int bgr, const float* mean, const float* stdv,
+                    int H, int W, float* out, void* stream);
+
 int codd_abi_version(void);
 
 #ifdef __cplusplus

@@ -1,4 +1,5 @@
 """GPU parity of the Motion / RAFT3D / Fusion kernels against the CPU oracle (fp32)."""
+import os
 import pytest
 import torch
 import torch.nn.functional as F
@@ -269,3 +270,98 @@ def test_full_codd_runs_at_baseline_shapes(H, W, intr):
     for f in range(5):
         d = runner.step(img[:, f % 3].to(DEV).contiguous(), r_img[:, f % 3].to(DEV).contiguous())
     assert d.shape == (1, 1, H, W) and torch.isfinite(d).all()
+
+
+def test_tepe_metrics_kernel_matches_torch_reference():
+    from codd_amd import metrics
+    H, W, h, w = 64, 96, 60, 90
+    meta = dict(disp_range=(1, 210))
+    sm_t, sm_d = metrics.SequenceMetrics(meta, torch.device("cpu")), metrics.SequenceMetrics(meta, torch.device(DEV))
+    prev = None
+    for f in range(4):
+        gt = (rnd(1, 1, H, W, seed=f) * 40 + 60).clamp(0, 250)
+        gt[0, 0, 5:9, 7:30] = 0.0
+        pred = gt + rnd(1, 1, H, W, seed=10 + f) * 3
+        flow = rnd(1, 2, H, W, seed=20 + f) * 2.5
+        sm_t.update(pred[:, :, :h, :w], gt[:, :, :h, :w], flow[:, :, :h, :w])
+        pd, gd, fd = pred.to(DEV), gt.to(DEV), flow.to(DEV)
+        sm_d.update_disparity_device(pd, gd, (h, w))
+        if prev is not None:
+            sm_d.update_temporal_device(pd, gd, prev[0], prev[1], prev[2], (h, w))
+        prev = (pd, gd, fd)
+    rt, rd = sm_t.row(), sm_d.row().cpu()
+    for i in range(7):
+        assert abs(rt[i].item() - rd[i].item()) < 1e-5 * max(1.0, abs(rt[i].item())), (metrics.COLUMNS[i], rt[i], rd[i])
+
+
+def test_preprocess_matches_numpy_restatement():
+    import numpy as np
+    from codd_amd import ops
+    g = np.random.RandomState(0)
+    img = g.randint(0, 256, size=(100, 150, 3), dtype=np.uint8)  # BGR HWC like cv2.imread
+    out = ops.preprocess(torch.from_numpy(img).to(DEV), bgr=True).cpu().numpy()[0]
+    rgb = img[:, :, ::-1].astype(np.float32)
+    norm = (rgb - np.array(ops.IMAGENET_MEAN, np.float32)) / np.array(ops.IMAGENET_STD, np.float32)
+    ref = np.pad(norm, ((0, 28), (0, 42), (0, 0)), mode="reflect").transpose(2, 0, 1)  # -> 128 x 192
+    assert out.shape == ref.shape == (3, 128, 192)
+    assert np.abs(out - ref).max() < 1e-5
+
+
+def test_eval_harness_on_device_metrics_match_torch_restatement(tmp_path):
+    """apis.single_gpu_inference(evaluate=True) on two synthetic videos: the HIP metric kernels inside
+    estimator.inference must give the same row as the torch restatement applied to the disparities
+    returned by evaluate=False; a checkpoint round trip through apis.load_checkpoint must not change them."""
+    from codd_amd import apis, configs, metrics, synth
+    from codd_amd.registry import build_estimator
+    H, W, MF = 128, 256, 3
+    est = build_estimator(configs.codd(iters=2)).to(DEV).eval()
+    synth.load_synthetic_weights(est, gain=1.4)
+    videos, rows_ref = [], []
+    for v in range(2):
+        left, right, disp = synth.stereo_sequence(H, W, MF, 32.0, flow=(0.75 + v, 0.25))
+        metas = synth.default_metas(H, W, img_shape=(120, 250))
+        metas[0][0].update(filename="vid%d" % v, ori_filename="vid%d.png" % v, disp_range=(1, 210))
+        flow = rnd(1, MF, 2, H, W, seed=50 + v) * 2
+        videos.append(dict(img=[left.to(DEV)], r_img=[right.to(DEV)], img_metas=metas,
+                           gt_disp=[(disp + v).to(DEV)], gt_flow=[flow.to(DEV)]))
+    torch.save(dict(state_dict=est.state_dict()), str(tmp_path / "w.pth"))
+    apis.load_checkpoint(est, str(tmp_path / "w.pth"), strict=True)
+    summary = apis.single_gpu_inference(est, videos, out_dir=str(tmp_path), evaluate=True)
+    for d in videos:
+        pred = est(img=d["img"], r_img=d["r_img"], img_metas=d["img_metas"], return_loss=False, evaluate=False)[0]
+        sm = metrics.SequenceMetrics(d["img_metas"][0][0], torch.device(DEV))
+        for f in range(MF):
+            sm.update(pred[:, f:f + 1], d["gt_disp"][0][:, f, :, :120, :250], d["gt_flow"][0][:, f, :, :120, :250])
+        rows_ref.append(sm.row().cpu())
+    ref = metrics.reduce_rows(rows_ref, torch.device("cpu"))
+    for k in metrics.COLUMNS[:7]:
+        assert abs(summary[k][0] - ref[k][0]) < 1e-5 * max(1.0, abs(ref[k][0])), (k, summary[k], ref[k])
+    assert (tmp_path / "stats.csv").exists()
+
+
+def test_cli_folder_of_frames_writes_disparities(tmp_path):
+    """codd_amd.inference on a folder of PNG frames == the estimator called on the same pre-processed
+    tensors (reference inference.py --img-dir/--r-img-dir/--show)."""
+    import numpy as np
+    from PIL import Image
+    from codd_amd import configs, inference, ops, synth
+    from codd_amd.registry import build_estimator
+    h, w, MF = 120, 250, 3
+    left, right, _ = synth.stereo_sequence(h, w, MF, 24.0)
+    for side, seq in (("l", left), ("r", right)):
+        os.makedirs(tmp_path / side / "clip7")
+        for f in range(MF):
+            u8 = ((seq[0, f] - seq.min()) / (seq.max() - seq.min()) * 255).permute(1, 2, 0).byte().numpy()
+            Image.fromarray(u8).save(tmp_path / side / "clip7" / ("%04d.png" % f))
+    out_dir = tmp_path / "out"
+    inference.main(["--img-dir", str(tmp_path / "l"), "--r-img-dir", str(tmp_path / "r"), "--iters", "2", "--show",
+                    "--show-dir", str(out_dir)])
+    got = np.load(out_dir / "clip7.disp.pred.npz")["disp"]
+    assert got.shape == (MF, h, w) or got.shape == (1, MF, h, w)
+    est = build_estimator(configs.codd(iters=2)).to(DEV).eval()
+    synth.load_synthetic_weights(est, gain=1.4)
+    vids = inference.list_videos(str(tmp_path / "l"), str(tmp_path / "r"), ".png")
+    data = inference.make_sample(*vids[0], torch.device(DEV))
+    assert data["img"][0].shape == (1, MF, 3, 128, 256)
+    ref = est(return_loss=False, evaluate=False, **data)[0].cpu().numpy()
+    assert np.array_equal(got.reshape(ref.shape), ref)
