@@ -89,7 +89,8 @@ def conv_roofline(runner, frames, device):
         rc = orig(lib, p, stream)
         e.record(torch.cuda.current_stream(device))
         cout = p.Cout * (4 if p.store_mode else 1)
-        recs.append((s, e, 2.0 * (p.C0 + p.C1) * cout * p.kh * p.kw * p.Hout * p.Wout * p.B))
+        recs.append((s, e, 2.0 * (p.C0 + p.C1) * cout * p.kh * p.kw * p.Hout * p.Wout * p.B,
+                     (p.B, p.C0 + p.C1, cout, p.kh, p.kw, p.Hout, p.Wout, p.sy, p.store_mode)))
         return rc
 
     ops._launch_conv = timed
@@ -102,8 +103,16 @@ def conv_roofline(runner, frames, device):
     finally:
         ops._launch_conv = orig
         ops.Fork.serial = serial_before
-    t_ms = sum(s.elapsed_time(e) for s, e, _ in recs)
-    flops = sum(f for _, _, f in recs)
+    t_ms = sum(s.elapsed_time(e) for s, e, _, _ in recs)
+    flops = sum(f for _, _, f, _ in recs)
+    if os.environ.get("CODD_BENCH_VERBOSE"):  # per-shape table (dev aid): count, total ms, TFLOP/s
+        by = {}
+        for s, e, f, key in recs:
+            c = by.setdefault(key, [0, 0.0, 0.0])
+            c[0] += 1; c[1] += s.elapsed_time(e); c[2] += f
+        for key, (n, ms, f) in sorted(by.items(), key=lambda kv: -kv[1][1]):
+            log("conv B%d Cin%-4d Cout%-4d k%dx%d out %3dx%-3d s%d m%d : n=%3d  %7.3f ms  %6.1f us/launch  %5.1f TF"
+                % (*key, n, ms, ms / n * 1e3, f / ms / 1e9))
     return dict(launches=len(recs), time_ms=t_ms, gflop=flops / 1e9)
 
 

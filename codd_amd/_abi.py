@@ -24,7 +24,7 @@ class ConvParams(C.Structure):
         ("Cout", C.c_int), ("Hout", C.c_int), ("Wout", C.c_int),
         ("kh", C.c_int), ("kw", C.c_int), ("sy", C.c_int), ("sx", C.c_int),
         ("pad_t", C.c_int), ("pad_l", C.c_int), ("dil_y", C.c_int), ("dil_x", C.c_int),
-        ("act", C.c_int), ("store_mode", C.c_int), ("mb", C.c_int), ("npb", C.c_int), ("ck", C.c_int),
+        ("act", C.c_int), ("store_mode", C.c_int), ("mb", C.c_int), ("npb", C.c_int), ("nw", C.c_int), ("ck", C.c_int),
     ]
 
 

@@ -18,34 +18,46 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
+def headers():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [
+        os.path.join(ROOT, "include", "codd_hip.h")]
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = sources() + [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "codd_hip.h")]
+    deps = sources() + headers()
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
-    objs = []
+    from concurrent.futures import ThreadPoolExecutor
+    objs, jobs = [], []
+    newest_hdr = max(os.path.getmtime(h) for h in headers())
     for src in sources():
         obj = src[:-4] + ".o"
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
-                os.path.getmtime(src), os.path.getmtime(os.path.join(CSRC, "common.h")),
-                os.path.getmtime(os.path.join(ROOT, "include", "codd_hip.h"))):
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_hdr):
             cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
                    "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wno-unused-result", "-Wno-pass-failed",
                    # keep MFMA accumulators in VGPRs: without it hipcc (ROCm 7.2) copies all
                    # accumulators VGPR<->AGPR around EVERY k-step of the conv loop (10 VALU per MFMA)
                    "-mllvm", "-amdgpu-mfma-vgpr-form"]
+            cmd += os.environ.get("CODD_EXTRA_FLAGS", "").split()  # dev builds, e.g. -DCONV_PROFILE
             if os.path.basename(src) in NO_SLP:
                 cmd.append("-fno-slp-vectorize")
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            jobs.append(cmd)
         objs.append(obj)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1, 16))) as ex:
+        list(ex.map(run, jobs))  # translation units are independent: compile them in parallel
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -12,193 +12,12 @@
 // channels and the matching weight chunk are staged in LDS per chunk; channel stride of the
 // LDS image is padded to 16 (mod 32) floats so that the two ci-groups of a 32-lane half hit
 // disjoint banks.
-#include "common.h"
-#include <string.h>
+#include "conv_kernel.h"
+#include <stdio.h>
+#include <stdlib.h>
 
-struct ConvK {
-  codd_conv_params p;
-  int cin, nchunks, ntaps;
-  int th, tw, thi, twi, chs;
-  int wrow, wchunk;
-  int tiles_x, tiles_y, ncog;
-  int cout_eff;
-  int twp;     // LDS row stride (floats, multiple of 4) of the input tile
-  int xoff;    // column of the tile's first input pixel inside the 4-aligned LDS row
-  int twp4;    // float4 units per LDS row
-  int upc;     // float4 units per channel = thi * twp4
-  int nunits;  // ck * upc
-  int vec_ok;  // 16-byte global loads allowed (Win % 4 == 0 and 16-byte aligned bases)
-};
+CONV_ALL_GROUPS(CONV_DECLARE)
 
-__device__ __forceinline__ const float* view_ptr(const codd_view& v, int b, int c, int hw) {
-  return v.ptr + ((size_t)b * v.ctot + v.coff + c) * (size_t)hw;
-}
-
-// Staging: a chunk (CK input channels of the halo tile + the matching packed weights) is fetched
-// with 16-byte global loads into REGISTERS right before the MFMA phase of the previous chunk and
-// written to LDS after it (issue early / write late), so that HBM/L2 latency overlaps the matrix
-// pipe.  The (channel, row, float4-column) decomposition of a thread's units does not depend on
-// the chunk and is computed once.
-template <int NPB, int MB, int WREG, int IREG>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvK k) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* wl = smem;
-  float* il = smem + k.wchunk;
-  const codd_conv_params& p = k.p;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 4, j = lane & 15;
-  constexpr int XB = NPB >= 2 ? 2 : 1;  // 16-pixel blocks along x in the tile
-  constexpr int RPW = NPB / XB;         // tile rows per wave
-
-  int bid = blockIdx.x;
-  const int tx = bid % k.tiles_x; bid /= k.tiles_x;
-  const int ty = bid % k.tiles_y; bid /= k.tiles_y;
-  const int cog = bid % k.ncog;
-  const int b = bid / k.ncog;
-
-  const int hwin = p.Hin * p.Win;
-  const int gy0 = ty * k.th * p.sy - p.pad_t;
-  const int gxs = tx * k.tw * p.sx - p.pad_l - k.xoff;  // 4-aligned start column (may be negative)
-
-  // ---- per-thread staging metadata ---------------------------------------------------------------
-  int u_lds[IREG], u_g[IREG], u_c[IREG];
-  unsigned u_m[IREG];
-#pragma unroll
-  for (int r = 0; r < IREG; ++r) {
-    const int u = tid + r * 256;
-    u_c[r] = -1; u_m[r] = 0; u_lds[r] = 0; u_g[r] = 0;
-    if (u < k.nunits) {
-      const int c = u / k.upc, rem = u - c * k.upc;
-      const int y = rem / k.twp4, x4 = rem - y * k.twp4;
-      const int gy = gy0 + y, gx = gxs + 4 * x4;
-      unsigned m = 0;
-      if ((unsigned)gy < (unsigned)p.Hin) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) m |= ((unsigned)(gx + q) < (unsigned)p.Win) ? (1u << q) : 0u;
-      }
-      u_c[r] = c; u_m[r] = m;
-      u_lds[r] = c * k.chs + y * k.twp + 4 * x4;
-      u_g[r] = gy * p.Win + gx;
-    }
-  }
-  const int wchunk4 = k.wchunk >> 2;
-  float4 wreg[WREG], ireg[IREG];
-
-#define CONV_ISSUE(CH)                                                                                    \
-  {                                                                                                       \
-    const float4* src_ = (const float4*)(p.wpacked + ((size_t)(cog * k.nchunks + (CH))) * k.wchunk);      \
-    _Pragma("unroll") for (int r = 0; r < WREG; ++r) {                                                    \
-      const int e = tid + r * 256;                                                                        \
-      wreg[r] = e < wchunk4 ? src_[e] : make_float4(0.f, 0.f, 0.f, 0.f);                                  \
-    }                                                                                                     \
-    const int c0_ = (CH) * p.ck;                                                                          \
-    _Pragma("unroll") for (int r = 0; r < IREG; ++r) {                                                    \
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                         \
-      const int cg = c0_ + u_c[r];                                                                        \
-      if (u_c[r] >= 0 && cg < k.cin && u_m[r]) {                                                          \
-        const float* s_ =                                                                                 \
-            (cg < p.C0 ? view_ptr(p.in0, b, cg, hwin) : view_ptr(p.in1, b, cg - p.C0, hwin)) + u_g[r];    \
-        if (u_m[r] == 0xFu && k.vec_ok) {                                                                 \
-          v = *(const float4*)s_;                                                                         \
-        } else {                                                                                          \
-          if (u_m[r] & 1u) v.x = s_[0];                                                                   \
-          if (u_m[r] & 2u) v.y = s_[1];                                                                   \
-          if (u_m[r] & 4u) v.z = s_[2];                                                                   \
-          if (u_m[r] & 8u) v.w = s_[3];                                                                   \
-        }                                                                                                 \
-      }                                                                                                   \
-      ireg[r] = v;                                                                                        \
-    }                                                                                                     \
-  }
-#define CONV_COMMIT()                                                                                     \
-  {                                                                                                       \
-    float4* dst_ = (float4*)wl;                                                                           \
-    _Pragma("unroll") for (int r = 0; r < WREG; ++r) {                                                    \
-      const int e = tid + r * 256;                                                                        \
-      if (e < wchunk4) dst_[e] = wreg[r];                                                                 \
-    }                                                                                                     \
-    _Pragma("unroll") for (int r = 0; r < IREG; ++r) if (u_c[r] >= 0) *(float4*)(il + u_lds[r]) = ireg[r]; \
-  }
-
-  f32x4 acc[NPB][MB];
-#pragma unroll
-  for (int a = 0; a < NPB; ++a)
-#pragma unroll
-    for (int m = 0; m < MB; ++m) acc[a][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // per pixel-block LDS base offset (row / col part that does not depend on the tap)
-  int pbase[NPB];
-#pragma unroll
-  for (int a = 0; a < NPB; ++a) {
-    const int prow = wave * RPW + a / XB, pcol = (a % XB) * 16 + j;
-    pbase[a] = prow * p.sy * k.twp + pcol * p.sx + k.xoff;
-  }
-
-  CONV_ISSUE(0);
-  for (int ch = 0; ch < k.nchunks; ++ch) {
-    __syncthreads();  // every wave is done reading the previous chunk
-    CONV_COMMIT();
-    __syncthreads();
-    if (ch + 1 < k.nchunks) CONV_ISSUE(ch + 1);
-    for (int ky = 0; ky < p.kh; ++ky) {
-      for (int kx = 0; kx < p.kw; ++kx) {
-        const float* wp = wl + (ky * p.kw + kx) * p.ck * k.wrow + j + g * k.wrow;
-        const float* ip = il + ky * p.dil_y * k.twp + kx * p.dil_x + g * k.chs;
-        const int wstep = 4 * k.wrow, istep = 4 * k.chs;
-        // 4 k-steps per trip: the 4*(MB+NPB) LDS reads are issued ahead of the 4*MB*NPB MFMAs
-#pragma unroll 4
-        for (int c4 = 0; c4 < p.ck; c4 += 4) {
-          float av[MB], bv[NPB];
-#pragma unroll
-          for (int m = 0; m < MB; ++m) av[m] = wp[m * 16];
-#pragma unroll
-          for (int a = 0; a < NPB; ++a) bv[a] = ip[pbase[a]];
-          wp += wstep;
-          ip += istep;
-#pragma unroll
-          for (int a = 0; a < NPB; ++a)
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-              acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[a], acc[a][m], 0, 0, 0);
-        }
-      }
-    }
-  }
-
-  // epilogue
-  const int hwout = p.Hout * p.Wout;
-#pragma unroll
-  for (int a = 0; a < NPB; ++a) {
-    const int oy = ty * k.th + wave * RPW + a / XB;
-    const int ox = tx * k.tw + (a % XB) * 16 + j;
-    if (oy >= p.Hout || ox >= p.Wout) continue;
-    const int pix = oy * p.Wout + ox;
-#pragma unroll
-    for (int m = 0; m < MB; ++m) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = (cog * MB + m) * 16 + 4 * g + r;
-        if (co >= k.cout_eff) continue;
-        float v = acc[a][m][r];
-        if (p.store_mode == 0) {
-          if (p.bias) v += p.bias[co];
-          if (p.res1.ptr) v += view_ptr(p.res1, b, co, hwout)[pix];
-          if (p.res2.ptr) v += view_ptr(p.res2, b, co, hwout)[pix];
-          v = act_apply(v, p.act, co);
-          if (p.post.ptr) v += view_ptr(p.post, b, co, hwout)[pix];
-          p.out[((size_t)b * p.out_ctot + p.out_coff + co) * (size_t)hwout + pix] = v;
-        } else {  // ConvTranspose2d k=2 s=2: co = (a2*2+b2)*Cout + c
-          const int q = co / p.Cout, c = co - q * p.Cout;
-          if (p.bias) v += p.bias[c];
-          v = act_apply(v, p.act, c);
-          const int W2 = 2 * p.Wout;
-          p.out[((size_t)b * p.out_ctot + p.out_coff + c) * (size_t)(4 * hwout) +
-                (size_t)(2 * oy + (q >> 1)) * W2 + 2 * ox + (q & 1)] = v;
-        }
-      }
-    }
-  }
-}
 
 __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int ntaps,
                                  int mb, int ck, int wrow, int nchunks, long long total, long long co_stride,
@@ -244,14 +63,21 @@ extern "C" int codd_conv2d_pack_weights(const float* w, float* wpacked, int Cout
                                      (long long)kh * kw, 1.f, stream);
 }
 
-template <int NPB, int MB, int WREG, int IREG>
+template <int NW, int NPB, int MB, int WREG, int IREG>
 static int launch_conv(const ConvK& k, size_t lds, int grid, hipStream_t s) {
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_mfma_kernel<NPB, MB, WREG, IREG>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_mfma_kernel<NW, NPB, MB, WREG, IREG>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  conv_mfma_kernel<NPB, MB, WREG, IREG><<<grid, 256, lds, s>>>(k);
+  static const bool debug = getenv("CODD_CONV_DEBUG") != nullptr;  // dev aid: resident workgroups per CU
+  if (debug) {
+    int nb = -1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)conv_mfma_kernel<NW, NPB, MB, WREG, IREG>, NW * 64, lds);
+    fprintf(stderr, "conv<%d,%d,%d,%d,%d> grid %d lds %zu ck %d: %d workgroups/CU\n", NW, NPB, MB, WREG, IREG, grid, lds,
+            k.p.ck, nb);
+  }
+  conv_mfma_kernel<NW, NPB, MB, WREG, IREG><<<grid, NW * 64, lds, s>>>(k);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }
@@ -259,11 +85,22 @@ static int launch_conv(const ConvK& k, size_t lds, int grid, hipStream_t s) {
 template <int NPB, int MB>
 static int launch_conv_regs(const ConvK& k, size_t lds, int grid, hipStream_t s) {
   const int wr = cdiv(k.wchunk >> 2, 256), ir = cdiv(k.nunits, 256);
-  if (wr <= 4 && ir <= 4) return launch_conv<NPB, MB, 4, 4>(k, lds, grid, s);
-  if (wr <= 4 && ir <= 8) return launch_conv<NPB, MB, 4, 8>(k, lds, grid, s);
-  if (wr <= 12 && ir <= 4) return launch_conv<NPB, MB, 12, 4>(k, lds, grid, s);
-  if (wr <= 12 && ir <= 8) return launch_conv<NPB, MB, 12, 8>(k, lds, grid, s);
-  if (wr <= 16 && ir <= 8) return launch_conv<NPB, MB, 16, 8>(k, lds, grid, s);
+  if (wr <= 4 && ir <= 4) return launch_conv<4, NPB, MB, 4, 4>(k, lds, grid, s);
+  if (wr <= 4 && ir <= 8) return launch_conv<4, NPB, MB, 4, 8>(k, lds, grid, s);
+  if (wr <= 12 && ir <= 4) return launch_conv<4, NPB, MB, 12, 4>(k, lds, grid, s);
+  if (wr <= 12 && ir <= 8) return launch_conv<4, NPB, MB, 12, 8>(k, lds, grid, s);
+  if (wr <= 16 && ir <= 8) return launch_conv<4, NPB, MB, 16, 8>(k, lds, grid, s);
+  return CODD_EUNSUPPORTED;
+}
+
+// Workgroups of 9 waves (9 tile rows of 16 pixels): for maps where a 4-row tiling leaves the last round of
+// workgroups nearly empty (72 rows x 8 column tiles x 4 channel groups = 576 blocks = 2.25 per CU with 4
+// waves, exactly 256 with 9: the weights of a chunk are then fetched once per 9 rows instead of per 4).
+template <int MB>
+static int launch_conv_nw9(const ConvK& k, size_t lds, int grid, hipStream_t s) {
+  const int wr = cdiv(k.wchunk >> 2, 9 * 64), ir = cdiv(k.nunits, 9 * 64);
+  if (wr <= 8 && ir <= 4) return launch_conv<9, 1, MB, 8, 4>(k, lds, grid, s);
+  if (wr <= 16 && ir <= 4) return launch_conv<9, 1, MB, 16, 4>(k, lds, grid, s);
   return CODD_EUNSUPPORTED;
 }
 
@@ -283,7 +120,9 @@ extern "C" int codd_conv2d(const codd_conv_params* pp, void* stream) {
   k.nchunks = cdiv(k.cin, p.ck);
   k.ntaps = p.kh * p.kw;
   const int xb = p.npb >= 2 ? 2 : 1, rpw = p.npb / xb;
-  k.th = 4 * rpw;
+  const int nw = p.nw ? p.nw : 4;
+  if (nw != 4 && (nw != 9 || p.npb != 1 || p.mb == 1)) return CODD_EUNSUPPORTED;
+  k.th = nw * rpw;
   k.tw = 16 * xb;
   k.thi = (k.th - 1) * p.sy + (p.kh - 1) * p.dil_y + 1;
   k.twi = (k.tw - 1) * p.sx + (p.kw - 1) * p.dil_x + 1;
@@ -309,6 +148,7 @@ extern "C" int codd_conv2d(const codd_conv_params* pp, void* stream) {
   long long grid = (long long)k.tiles_x * k.tiles_y * k.ncog * p.B;
   if (grid <= 0 || grid > 0x7fffffffLL) return CODD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  if (nw == 9) return p.mb == 2 ? launch_conv_nw9<2>(k, lds, (int)grid, s) : launch_conv_nw9<4>(k, lds, (int)grid, s);
 #define CASE(N, M) if (p.npb == N && p.mb == M) return launch_conv_regs<N, M>(k, lds, (int)grid, s)
   CASE(1, 1); CASE(1, 2); CASE(1, 4);
   CASE(2, 1); CASE(2, 2); CASE(2, 4);

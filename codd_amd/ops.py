@@ -97,14 +97,30 @@ import os as _os
 _FORCE_NPB = int(_os.environ.get("CODD_NPB", "0"))
 _FORCE_MB = int(_os.environ.get("CODD_MB", "0"))
 _FORCE_CK = int(_os.environ.get("CODD_CK", "0"))
+_FORCE_NW = int(_os.environ.get("CODD_NW", "0"))
 
 
 def _wrow(mb):
     return 16 * mb + (0 if mb & 1 else 16)
 
 
+def _pick_nw(pc, npb, Hout, Wout, B, ncog):
+    """Waves (= 16-pixel tile rows) per workgroup: 4, or 9 where that removes a nearly empty last round.
+    The 256 CUs take workgroups round-robin, so a launch lasts about ceil(grid / 256) rounds of nw rows;
+    the 72-row GRU maps with 4 channel groups give 576 blocks = 3 rounds x 4 rows with nw = 4 and 256 blocks
+    = 1 round x 9 rows with nw = 9 (measured 88 -> 82, 165 -> 153, 133 -> 125 us on the 128/256/196 -> 256
+    3x3 layers; tools/time_conv_sweep.py).  Only for the plain 4x16 tile with >= 32 channels per group."""
+    if _FORCE_NW:
+        return _FORCE_NW if (npb == 1 and pc.mb >= 2) else 4
+    if npb != 1 or pc.mb < 2 or Hout * Wout > 16384:
+        return 4
+    tx = -(-Wout // 16)
+    cost = {nw: -(-(-(-Hout // nw) * tx * ncog * B) // 256) * nw for nw in (4, 9)}
+    return 9 if cost[9] * 1.2 <= cost[4] else 4
+
+
 def _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl):
-    """(npb, ck): tile shape per wave and LDS chunk depth.
+    """(npb, nw, ck): tile shape per wave, waves per workgroup and LDS chunk depth.
 
     Measured on MI355X (tools/time_ops.py): the small 4x16-pixel tile (npb = 1) wins on every
     layer with more than 16 output channels -- the kernel is latency / barrier bound, so more
@@ -116,10 +132,12 @@ def _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl):
     npb = 2 if pc.cout_eff <= 16 else 1
     if _FORCE_NPB:
         npb = _FORCE_NPB
+    nw = _pick_nw(pc, npb, Hout, Wout, B, ncog)
+    nt = 64 * nw
     xb = 2 if npb >= 2 else 1
-    th, tw = 4 * (npb // xb), 16 * xb
+    th, tw = nw * (npb // xb), 16 * xb
     grid = (-(-Hout // th)) * (-(-Wout // tw)) * ncog * B
-    per_cu = min(max(-(-grid // 256), 2), 4)
+    per_cu = min(max(-(-grid // 256), 2 if nw == 4 else 1), 4)
     budget = min(64 * 1024, (160 * 1024) // per_cu - 512)
     thi = (th - 1) * sy + (pc.kh - 1) * dy + 1
     twi = (tw - 1) * sx + (pc.kw - 1) * dx + 1
@@ -130,12 +148,12 @@ def _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl):
     cin_pad = -(-pc.cin // 4) * 4
     ck = min(cin_pad, 32)
     taps = pc.kh * pc.kw
-    while ck > 4 and ((taps * ck * _wrow(pc.mb) + ck * chs) * 4 > budget or taps * ck * _wrow(pc.mb) > 16384
-                      or ck * thi * (twp // 4) > 2048):
+    while ck > 4 and ((taps * ck * _wrow(pc.mb) + ck * chs) * 4 > budget or taps * ck * _wrow(pc.mb) > 64 * nt
+                      or ck * thi * (twp // 4) > (8 if nw == 4 else 4) * nt):
         ck -= 4
     if _FORCE_CK:
         ck = min(ck, _FORCE_CK)
-    return npb, ck
+    return npb, nw, ck
 
 
 def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=None, post=None,
@@ -170,7 +188,7 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
         out = torch.empty(B, pc.cout, Hout * up, Wout * up, device=xs.buf.device, dtype=torch.float32)
     os_ = _as_slice(out)
     assert os_.shape == (B, pc.cout, Hout * up, Wout * up), (os_.shape, (B, pc.cout, Hout * up, Wout * up))
-    npb, ck = _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl)
+    npb, nw, ck = _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl)
     p = ConvParams()
     p.in0 = _view(xs)
     p.in1 = _view(x2)
@@ -183,7 +201,7 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
     p.kh, p.kw, p.sy, p.sx, p.pad_t, p.pad_l, p.dil_y, p.dil_x = pc.kh, pc.kw, sy, sx, pt, pl, dy, dx
     p.act = ACT[act]
     p.store_mode = 1 if pc.deconv else 0
-    p.mb, p.npb, p.ck = pc.mb, npb, ck
+    p.mb, p.npb, p.nw, p.ck = pc.mb, npb, nw, ck
     _abi.check(_launch_conv(lib, p, _stream()), "codd_conv2d")
     return out
 
