@@ -10,6 +10,7 @@ from . import hrnet  # noqa: F401
 from . import motion  # noqa: F401
 from . import fusion  # noqa: F401
 from . import estimator  # noqa: F401
+from . import ablation  # noqa: F401
 from .registry import MODELS, build_estimator  # noqa: F401
 
 __all__ = ["MODELS", "build_estimator"]

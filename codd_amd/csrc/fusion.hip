@@ -332,3 +332,99 @@ extern "C" int codd_preprocess(const unsigned char* img, int h, int w, int bgr, 
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Ablation plug-ins (reference model/fusion/others.py:40-168, model/motion/others.py:11-66).
+// ------------------------------------------------------------------------------------------------
+// mode 0: KalmanFusion with the reference's constant gain K (its P is never updated);
+// mode 1: GTFusion -- pick the estimate closer to the ground truth (gt [B,1,hg,wg], zero outside).
+__global__ void fusion_select_kernel(int mode, const float* __restrict__ cur, const float* __restrict__ warp,
+                                     const float* __restrict__ gt, int H, int W, int hg, int wg, float K,
+                                     float* __restrict__ out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  if (x >= W) return;
+  const size_t i = ((size_t)b * H + y) * W + x;
+  const float c = cur[i], w = warp[i];
+  float v;
+  if (mode == 0) {
+    v = w + K * (c - w);
+    if (w <= 0.f) v = c;
+    if (fabsf(w - c) > 1.f) v = c;
+  } else {
+    const float g = (y < hg && x < wg) ? gt[((size_t)b * hg + y) * wg + x] : 0.f;
+    const float d = fabsf(c - g) - fabsf(w - g);
+    v = d < -1.f ? c : (d > 1.f ? w : (c + w) / 2.f);
+    if (w <= 0.f) v = c;
+    if (!(g > 0.f)) v = c;
+  }
+  out[i] = v;
+}
+extern "C" int codd_fusion_select(int mode, const float* cur, const float* warp, const float* gt, int B, int H,
+                                  int W, int hg, int wg, float K, float* out, void* stream) {
+  if (!cur || !warp || !out || (mode == 1 && !gt) || mode < 0 || mode > 1) return CODD_EINVAL;
+  fusion_select_kernel<<<dim3(cdiv(W, 256), H, B), 256, 0, (hipStream_t)stream>>>(mode, cur, warp, gt, H, W, hg, wg,
+                                                                                   K, out);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+// GTMotion: move the previous frame's image / disparity (full resolution) and features (1/4 resolution)
+// with the ground-truth flow (nearest sampling, zeros outside; occluded pixels and pixels whose source lies
+// outside become 0); disparity additionally minus the GT disparity change.  Quarter-resolution features use
+// the FULL-resolution flow sampled at [2::4, 2::4], unscaled, exactly like the reference.
+__global__ void gt_motion_full_kernel(const float* __restrict__ img, const float* __restrict__ disp,
+                                      const float* __restrict__ flow, const float* __restrict__ dchange,
+                                      const unsigned char* __restrict__ occ, int H, int W, int hg, int wg,
+                                      float* __restrict__ img_w, float* __restrict__ disp_w,
+                                      float* __restrict__ flow3, float* __restrict__ conf) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  if (x >= W) return;
+  const size_t HW = (size_t)H * W, i = (size_t)y * W + x;
+  const bool in = y < hg && x < wg;
+  const size_t gi = in ? ((size_t)b * hg + y) * wg + x : 0;
+  const size_t ghw = (size_t)hg * wg;
+  const float fx = in ? flow[(size_t)b * 2 * ghw + (size_t)y * wg + x] : 0.f;
+  const float fy = in ? flow[(size_t)b * 2 * ghw + ghw + (size_t)y * wg + x] : 0.f;
+  const float dc = in ? dchange[gi] : 0.f;
+  const bool oc = in && occ[gi] != 0;
+  const float sx = nearbyintf((float)x + fx), sy = nearbyintf((float)y + fy);
+  const bool ok = sx >= 0.f && sx <= (float)(W - 1) && sy >= 0.f && sy <= (float)(H - 1) && !oc;
+  const size_t s = ok ? (size_t)((int)sy) * W + (int)sx : 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) img_w[((size_t)b * 3 + c) * HW + i] = ok ? img[((size_t)b * 3 + c) * HW + s] : 0.f;
+  disp_w[(size_t)b * HW + i] = ok ? disp[(size_t)b * HW + s] - dc : 0.f;
+  flow3[((size_t)b * 3 + 0) * HW + i] = fx; flow3[((size_t)b * 3 + 1) * HW + i] = fy; flow3[((size_t)b * 3 + 2) * HW + i] = dc;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) conf[((size_t)b * 3 + c) * HW + i] = 1.f;
+}
+__global__ void gt_motion_feat_kernel(const float* __restrict__ feat, const float* __restrict__ flow, int C, int Hq,
+                                      int Wq, int hg, int wg, float* __restrict__ feat_w) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  if (x >= Wq) return;
+  const int fy_ = 2 + 4 * y, fx_ = 2 + 4 * x;
+  const bool in = fy_ < hg && fx_ < wg;
+  const size_t ghw = (size_t)hg * wg;
+  const float fx = in ? flow[(size_t)b * 2 * ghw + (size_t)fy_ * wg + fx_] : 0.f;
+  const float fy = in ? flow[(size_t)b * 2 * ghw + ghw + (size_t)fy_ * wg + fx_] : 0.f;
+  const float sx = nearbyintf((float)x + fx), sy = nearbyintf((float)y + fy);
+  const bool ok = sx >= 0.f && sx <= (float)(Wq - 1) && sy >= 0.f && sy <= (float)(Hq - 1);
+  const size_t hw = (size_t)Hq * Wq, i = (size_t)y * Wq + x, s = ok ? (size_t)((int)sy) * Wq + (int)sx : 0;
+  for (int c = 0; c < C; ++c) feat_w[((size_t)b * C + c) * hw + i] = ok ? feat[((size_t)b * C + c) * hw + s] : 0.f;
+}
+extern "C" int codd_gt_motion(const float* img_prev, const float* disp_prev, const float* feat_prev, int C,
+                              const float* gt_flow, const float* gt_disp_change, const unsigned char* gt_flow_occ,
+                              int B, int H, int W, int hg, int wg, float* img_warp, float* feat_warp, float* conf,
+                              float* disp_warp, float* flow3, void* stream) {
+  if (!img_prev || !disp_prev || !feat_prev || !gt_flow || !gt_disp_change || !gt_flow_occ || !img_warp ||
+      !feat_warp || !conf || !disp_warp || !flow3 || hg > H || wg > W || (H & 3) || (W & 3))
+    return CODD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  gt_motion_full_kernel<<<dim3(cdiv(W, 256), H, B), 256, 0, s>>>(img_prev, disp_prev, gt_flow, gt_disp_change,
+                                                                 gt_flow_occ, H, W, hg, wg, img_warp, disp_warp, flow3,
+                                                                 conf);
+  CODD_LAUNCH_CHECK();
+  gt_motion_feat_kernel<<<dim3(cdiv(W / 4, 64), H / 4, B), 64, 0, s>>>(feat_prev, gt_flow, C, H / 4, W / 4, hg, wg,
+                                                                       feat_warp);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}

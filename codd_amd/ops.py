@@ -525,3 +525,33 @@ def preprocess(img_u8, bgr=True, mean=IMAGENET_MEAN, std=IMAGENET_STD, divisor=6
     _abi.check(lib.codd_preprocess(img_u8.data_ptr(), h, w, int(bgr), m, s, H, W, out.data_ptr(), _stream()),
                "preprocess")
     return out
+
+
+def fusion_select(mode, cur, warp, gt=None, K=0.5):
+    """mode 'kalman' / 'gt' (ablation fusions).  cur, warp [B,1,H,W]; gt [B,1,hg,wg]."""
+    lib = _abi.load()
+    _require_gpu(cur)
+    B, _, H, W = cur.shape
+    out = torch.empty_like(cur)
+    hg, wg = (gt.shape[-2], gt.shape[-1]) if gt is not None else (0, 0)
+    _abi.check(lib.codd_fusion_select(0 if mode == "kalman" else 1, cur.data_ptr(), warp.data_ptr(),
+                                      gt.data_ptr() if gt is not None else None, B, H, W, hg, wg, float(K),
+                                      out.data_ptr(), _stream()), "fusion_select")
+    return out
+
+
+def gt_motion(img_prev, feat_prev, disp_prev, gt_flow, gt_disp_change, gt_flow_occ):
+    """-> [img_warp, feat_warp, conf, disp_warp [B,1,H,W], flow3] (GTMotion ablation)."""
+    lib = _abi.load()
+    _require_gpu(img_prev)
+    B, _, H, W = img_prev.shape
+    hg, wg = gt_flow.shape[-2:]
+    occ = gt_flow_occ.to(torch.uint8).contiguous()
+    img_w, feat_w = torch.empty_like(img_prev), torch.empty_like(feat_prev)
+    conf, flow3 = torch.empty_like(img_prev), torch.empty_like(img_prev)
+    disp_w = torch.empty(B, 1, H, W, device=img_prev.device, dtype=torch.float32)
+    _abi.check(lib.codd_gt_motion(img_prev.data_ptr(), disp_prev.data_ptr(), feat_prev.data_ptr(), feat_prev.shape[1],
+                                  gt_flow.data_ptr(), gt_disp_change.data_ptr(), occ.data_ptr(), B, H, W, hg, wg,
+                                  img_w.data_ptr(), feat_w.data_ptr(), conf.data_ptr(), disp_w.data_ptr(),
+                                  flow3.data_ptr(), _stream()), "gt_motion")
+    return [img_w, feat_w, conf, disp_w, flow3]

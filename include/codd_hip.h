@@ -261,6 +261,21 @@ int codd_tepe_metrics(const float* pred, const float* gt, const float* pred_prev
 int codd_preprocess(const unsigned char* img, int h, int w, int bgr, const float* mean, const float* stdv,
                     int H, int W, float* out, void* stream);
 
+/* Ablation plug-ins.  codd_fusion_select: mode 0 = KalmanFusion (model/fusion/others.py:124-153; constant
+ * gain K = Q/(Q+R), the reference never updates P), mode 1 = GTFusion (:54-86; gt [B,1,hg,wg], zero-padded).
+ * cur, warp, out: [B,1,H,W]. */
+int codd_fusion_select(int mode, const float* cur, const float* warp, const float* gt, int B, int H,
+                       int W, int hg, int wg, float K, float* out, void* stream);
+/* GTMotion (model/motion/others.py:17-61): nearest warp of the previous image [B,3,H,W], disparity [B,H,W]
+ * and features [B,C,H/4,W/4] by the ground-truth flow [B,2,hg,wg] (zero-padded), disparity minus
+ * gt_disp_change [B,1,hg,wg], occluded (gt_flow_occ [B,1,hg,wg] bytes != 0) or out-of-image sources -> 0.
+ * Outputs = the 5-entry memory: img_warp [B,3,H,W], feat_warp, conf (ones) [B,3,H,W], disp_warp [B,1,H,W],
+ * flow3 = [flow, disp change] [B,3,H,W]. */
+int codd_gt_motion(const float* img_prev, const float* disp_prev, const float* feat_prev, int C,
+                   const float* gt_flow, const float* gt_disp_change, const unsigned char* gt_flow_occ,
+                   int B, int H, int W, int hg, int wg, float* img_warp, float* feat_warp, float* conf,
+                   float* disp_warp, float* flow3, void* stream);
+
 int codd_abi_version(void);
 
 #ifdef __cplusplus

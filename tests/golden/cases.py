@@ -72,3 +72,32 @@ def proj_inputs(h=8, w=16):
 def warp_inputs(h=16, w=32):
     R = _gen(600)
     return R(1, 24, h, w), R(1, 1, h, w).abs() * 4
+
+
+def metric_case(H=128, W=192, MF=3, h=120, w=180):
+    """Stereo sequence + ground truth for the reference's calc_metric (EPE / TEPE family)."""
+    img, r_img, disp = synth.stereo_sequence(H, W, MF, dmax=24.0)
+    R = _gen(700)
+    gt = disp.clone() + 0.3 * R(1, MF, 1, H, W)
+    gt[:, :, :, 20:30, 40:80] = 0.0  # invalid ground truth (below disp_range[0])
+    gt[:, 1, :, 60:70, 100:120] = 250.0  # above disp_range[1]
+    flow = 2.5 * R(1, MF, 2, H, W)
+    flow[:, :, :, 90:100, 10:30] = 300.0  # |flow| >= BF_DEFAULT: excluded by compute_valid_mask
+    meta = [dict(img_shape=(h, w, 3), disp_range=(1, 210), intrinsics=[100.0, 100.0, W / 2.0, H / 2.0])]
+    return img, r_img, gt, flow, meta
+
+
+def ablation_case(H=32, W=48, hg=30, wg=44):
+    """Inputs of the GT / Kalman ablation plug-ins (model/fusion/others.py, model/motion/others.py)."""
+    R = _gen(800)
+    pred = (R(1, 1, H, W) * 3 + 12).abs()
+    warp = pred + 0.8 * R(1, 1, H, W)
+    warp[:, :, 5:9, 7:15] = 0.0  # holes
+    gt = (pred + R(1, 1, H, W))[:, :, :hg, :wg].contiguous()
+    gt[:, :, 12:15, 20:30] = 0.0
+    img_prev, feat_prev, disp_prev = R(1, 3, H, W), R(1, 32, H // 4, W // 4), (R(1, H, W) * 3 + 12).abs()
+    gt_flow = 3.0 * R(1, 2, hg, wg)
+    gt_dc = 0.5 * R(1, 1, hg, wg)
+    occ = (R(1, 1, hg, wg) > 1.0)
+    return dict(pred=pred, warp=warp, gt=gt, img_prev=img_prev, feat_prev=feat_prev, disp_prev=disp_prev,
+                gt_flow=gt_flow, gt_disp_change=gt_dc, gt_flow_occ=occ, left_feat=R(1, 24, H // 4, W // 4))

@@ -99,8 +99,42 @@ def main():
         out["depth_sampler"] = depth_sampler(depth, coords)[0]
         img, disp = cases.warp_inputs()
         out["disp_warp"] = disp_warp(img, disp, padding_mode="zeros")[0]
+        # ---- evaluation metrics: the reference's own inference(evaluate=True) on a stereo-only model ----
+        img, r_img, gt, flow, meta = cases.metric_case()
+        est.reset_inference_state()
+        res = est.inference(img, r_img, meta, evaluate=True, gt_disp=[gt], gt_flow=[flow])
+        est2 = est.inference(img, r_img, meta, evaluate=False)
+        out["metric_pred_disp"] = est2
+        out["metric_names"] = None
+        names = [k for k in res.keys()]
+        out["metric_values"] = torch.stack([res[k].double().reshape(()) for k in names]).float()
+        globals()["_METRIC_NAMES"] = names
+        # ---- ablation plug-ins (GT / Kalman) ---------------------------------------------------------
+        from model.fusion.others import GTFusion, KalmanFusion, NullFusion  # noqa: E402
+        from model.motion.others import GTMotion  # noqa: E402
+        c = cases.ablation_case()
+        mem5 = [c["img_prev"], c["feat_prev"], torch.ones(1, 3, 32, 48), c["warp"], torch.zeros(1, 3, 32, 48)]
+        kf = KalmanFusion()
+        kf.memory_query(dict(pred_disp=c["pred"].clone()), {})  # first frame: resets P
+        o = dict(pred_disp=c["pred"].clone())
+        kf.memory_query(o, dict(memory=mem5))
+        out["ablation_kalman"] = o["pred_disp"]
+        o = dict(pred_disp=c["pred"].clone())
+        GTFusion().memory_query(o, dict(memory=mem5, gt_disp=[c["gt"]]))
+        out["ablation_gtfusion"] = o["pred_disp"]
+        st = dict(memory=[c["img_prev"], c["feat_prev"], c["disp_prev"]], gt_disp_change=[c["gt_disp_change"]],
+                  gt_flow=[c["gt_flow"]], gt_flow_occ=[c["gt_flow_occ"]])
+        try:
+            GTMotion()(st, {}, None)
+        except Exception as e:  # the lietorch stub cannot build SE3.Identity; memory is written before that
+            print("GTMotion tail:", type(e).__name__, e)
+        for i, k in enumerate(("img", "feat", "conf", "disp", "flow")):
+            out[f"ablation_gtmotion_{k}"] = st["memory"][i]
     path = os.path.join(HERE, "reference_outputs.npz")
-    np.savez_compressed(path, **{k: v.detach().cpu().numpy().astype(np.float32) for k, v in out.items()})
+    out.pop("metric_names")
+    arrays = {k: v.detach().cpu().numpy().astype(np.float32) for k, v in out.items()}
+    arrays["metric_names"] = np.array(globals()["_METRIC_NAMES"])
+    np.savez_compressed(path, **arrays)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
 
 

@@ -365,3 +365,65 @@ def test_cli_folder_of_frames_writes_disparities(tmp_path):
     assert data["img"][0].shape == (1, MF, 3, 128, 256)
     ref = est(return_loss=False, evaluate=False, **data)[0].cpu().numpy()
     assert np.array_equal(got.reshape(ref.shape), ref)
+
+
+def test_ablation_plugins_match_oracle_and_golden():
+    """KalmanFusion / GTFusion / GTMotion through the registry: bit-exact against the CPU restatement and
+    the reference's own outputs (tests/golden ablation_* arrays)."""
+    import numpy as np
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    import sys
+    sys.path.insert(0, sys_path)
+    import cases
+    from codd_amd.registry import MODELS
+    from oracle import ablation as oab
+    G = np.load(os.path.join(sys_path, "reference_outputs.npz"))
+    c = {k: v.to(DEV) for k, v in cases.ablation_case().items()}
+    mem5 = [c["img_prev"], c["feat_prev"], torch.ones(1, 3, 32, 48, device=DEV), c["warp"], torch.zeros(1, 3, 32, 48, device=DEV)]
+    kf = MODELS.build(dict(type="KalmanFusion"))
+    o = dict(pred_disp=c["pred"].clone())
+    kf.memory_query(o, dict(memory=mem5))
+    assert torch.equal(o["pred_disp"].cpu(), torch.from_numpy(G["ablation_kalman"]))
+    assert torch.equal(o["pred_disp"].cpu(), oab.kalman_fuse(c["pred"].cpu(), c["warp"].cpu()))
+    o = dict(pred_disp=c["pred"].clone())
+    MODELS.build(dict(type="GTFusion")).memory_query(o, dict(memory=mem5, gt_disp=[c["gt"]]))
+    assert torch.equal(o["pred_disp"].cpu(), torch.from_numpy(G["ablation_gtfusion"]))
+    st = dict(memory=[c["img_prev"], c["feat_prev"], c["disp_prev"]], gt_disp_change=[c["gt_disp_change"]],
+              gt_flow=[c["gt_flow"]], gt_flow_occ=[c["gt_flow_occ"]])
+    out = {}
+    MODELS.build(dict(type="GTMotion"))(st, out, None)
+    for t, k in zip(st["memory"], ("img", "feat", "conf", "disp", "flow")):
+        assert torch.equal(t.cpu().reshape(G[f"ablation_gtmotion_{k}"].shape), torch.from_numpy(G[f"ablation_gtmotion_{k}"])), k
+    assert out["Ts"].shape == (1, 32, 48, 7)
+    nf = MODELS.build(dict(type="NullFusion"))
+    s2 = {}
+    nf.memory_update(dict(left_img=c["img_prev"], left_feat=c["left_feat"], pred_disp=c["pred"]), s2)
+    assert len(s2["memory"]) == 3 and s2["memory"][2].shape == (1, 32, 48)
+
+
+def test_metric_kernels_match_reference_calc_metric():
+    """HIP metric kernels fed with the reference's own predictions reproduce the reference's metric dict
+    (tests/golden metric_* arrays: model/codd.py:435-521 run in the build container)."""
+    import numpy as np
+    import sys
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gdir)
+    import cases
+    from codd_amd import metrics
+    G = np.load(os.path.join(gdir, "reference_outputs.npz"))
+    img, r_img, gt, flow, meta = cases.metric_case()
+    h, w = meta[0]["img_shape"][:2]
+    H, W = img.shape[-2:]
+    pred = torch.zeros(1, gt.shape[1], 1, H, W)
+    pred[:, :, 0, :h, :w] = torch.from_numpy(G["metric_pred_disp"])
+    sm = metrics.SequenceMetrics(meta[0], torch.device(DEV))
+    pd, gd, fd = pred.to(DEV), gt.to(DEV), flow.to(DEV)
+    for f in range(pred.shape[1]):
+        sm.update_disparity_device(pd[:, f].contiguous(), gd[:, f].contiguous(), (h, w))
+        if f > 0:
+            sm.update_temporal_device(pd[:, f].contiguous(), gd[:, f].contiguous(), pd[:, f - 1].contiguous(),
+                                      gd[:, f - 1].contiguous(), fd[:, f - 1].contiguous(), (h, w))
+    row = sm.row().cpu()
+    ref = G["metric_values"]
+    for i, k in enumerate(metrics.COLUMNS[:7]):
+        assert abs(row[i].item() - float(ref[i])) < 2e-5 * max(1.0, abs(float(ref[i]))), (k, row[i].item(), ref[i])

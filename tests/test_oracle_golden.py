@@ -72,3 +72,33 @@ def test_raft_blocks():
         close(om.sample_bilinear(depth[:, None], coords), "depth_sampler")
         img, disp = cases.warp_inputs()
         close(ost.warp_x(img, disp), "disp_warp")
+
+
+def test_metrics_restatement_matches_reference_calc_metric():
+    """codd_amd.metrics (torch restatement, also the checker of the HIP metric kernels) against the
+    reference's own inference(evaluate=True) -- model/codd.py:435-521, utils/metric.py, utils/misc.py."""
+    from codd_amd import metrics
+    img, r_img, gt, flow, meta = cases.metric_case()
+    h, w = meta[0]["img_shape"][:2]
+    pred = torch.from_numpy(G["metric_pred_disp"])
+    sm = metrics.SequenceMetrics(meta[0], torch.device("cpu"))
+    for f in range(pred.shape[1]):
+        sm.update(pred[:, f:f + 1], gt[:, f, :, :h, :w], flow[:, f, :, :h, :w])
+    row = sm.row()
+    names = [str(n) for n in G["metric_names"]]
+    assert tuple(names) == metrics.COLUMNS
+    ref = G["metric_values"]
+    for i, k in enumerate(names[:7]):
+        assert abs(row[i].item() - float(ref[i])) < 2e-5 * max(1.0, abs(float(ref[i]))), (k, row[i].item(), ref[i])
+    assert float(ref[2]) > 0 and float(ref[6]) > 0  # the temporal columns were really exercised
+
+
+def test_ablation_plugins_match_reference():
+    from oracle import ablation
+    c = cases.ablation_case()
+    assert torch.equal(ablation.kalman_fuse(c["pred"], c["warp"]), torch.from_numpy(G["ablation_kalman"]))
+    assert torch.equal(ablation.gt_fuse(c["pred"], c["warp"], c["gt"]), torch.from_numpy(G["ablation_gtfusion"]))
+    mem = ablation.gt_motion(c["img_prev"], c["feat_prev"], c["disp_prev"], c["gt_flow"], c["gt_disp_change"],
+                             c["gt_flow_occ"])
+    for t, k in zip(mem, ("img", "feat", "conf", "disp", "flow")):
+        assert torch.equal(t.reshape(G[f"ablation_gtmotion_{k}"].shape), torch.from_numpy(G[f"ablation_gtmotion_{k}"])), k
