@@ -213,7 +213,8 @@ class RAFT3D(nn.Module):
         pend = getattr(self, "_pending", None)
         if not pend or key not in pend:
             return None
-        torch.cuda.current_stream(dev).wait_stream(self._side[0] if key == "fmap" else self._side[1])
+        if not getattr(self, "_nowait", False):  # pipelined runner: the tensors are already complete
+            torch.cuda.current_stream(dev).wait_stream(self._side[0] if key == "fmap" else self._side[1])
         return pend.pop(key)
 
     def forward(self, image_curr, depth_prev, depth_curr, intrinsics, state, outputs, iters=12, train_mode=False):

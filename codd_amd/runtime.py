@@ -113,3 +113,165 @@ class FrameRunner:
         self.graph.replay()
         self.state = {"memory": True}  # state now lives in the static buffers
         return st["out"]
+
+
+class PipelinedRunner:
+    """Frame pipeline of depth two: while the motion + fusion stages of frame t run, the image-only work
+    of frame t+1 -- the whole stereo network, RAFT3D's feature encoder and the context network (reference
+    hitnet.py:75-100, raft3d.py:151-160: none of them reads the recurrent state) -- runs beside them on
+    side streams of the SAME graph.  The GRU loop's 72x120 launches leave CUs idle (576 workgroups on 256
+    CUs); the next frame's 16-channel full-resolution layers fill them.  Results are identical to
+    FrameRunner's (same kernels, same per-stream order); the price is one frame of latency:
+
+        push(l0, r0) -> None;  push(l1, r1) -> disparity of frame 0;  ...;  flush() -> last frame.
+
+    Stage A (frame t+1) writes fresh tensors; stage B (frame t) reads the persistent copies ``a_cur`` of
+    stage A's previous results; the tail of the graph writes the recurrent state back and rotates A."""
+
+    A_KEYS = ("pred_disp", "left_feat", "right_feat", "left_img", "fmap", "netinp")
+
+    def __init__(self, estimator, img_metas, use_graph=True):
+        if estimator.motion is None or estimator.fusion is None:
+            raise ValueError("the frame pipeline needs the motion and fusion stages (use FrameRunner)")
+        self.est, self.metas, self.use_graph = estimator, img_metas, use_graph
+        self.reset()
+        self.graph = None
+        self._static = None
+
+    def reset(self):
+        self.state = {}
+        self.a_cur = None  # stage-A results of the frame waiting for its stage B
+        self.pushed = 0
+        if getattr(self, "_static", None) is not None:
+            self._static["primed"] = False
+
+    # ---- stages -------------------------------------------------------------------------------
+    def _stage_a(self, left, right, side):
+        """image-only work on ``side`` (+ RAFT3D's own two side streams); returns the new A dict."""
+        dev = left.device
+        raft = self.est.motion.raft3d
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self.est.motion.prefetch(left)
+            pend = raft._pending
+            raft._pending = None
+            if pend is None:
+                raise RuntimeError("PipelinedRunner needs the side streams (ops.Fork.serial must be False)")
+            out = self.est.stereo.stereo_matching(left, right, self.metas, {})
+        return dict(pred_disp=out["pred_disp"], left_feat=out["left_feat"], right_feat=out["right_feat"],
+                    left_img=left, fmap=pend["fmap"], netinp=pend["netinp"])
+
+    def _join_a(self, side, dev):
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_stream(side)
+        for s in self.est.motion.raft3d._side:
+            cur.wait_stream(s)
+
+    def _stage_b(self, a, state):
+        """motion + fusion of the frame whose stage-A results are ``a`` (reference model/codd.py:103-121)."""
+        raft = self.est.motion.raft3d
+        outputs = dict(pred_disp=a["pred_disp"], left_feat=a["left_feat"], right_feat=a["right_feat"],
+                       left_img=a["left_img"])
+        raft._pending, raft._nowait = dict(fmap=a["fmap"], netinp=a["netinp"]), True
+        try:
+            self.est.motion(state, outputs, img_metas=self.metas, train_mode=False)
+            self.est.fusion.memory_query(outputs, state, img_metas=self.metas)
+            self.est.fusion.memory_update(outputs, state, img_metas=self.metas)
+        finally:
+            raft._pending, raft._nowait = None, False
+        return outputs["pred_disp"]
+
+    @staticmethod
+    def _state_tensors(state):
+        mem = state["memory"]
+        return [mem[0], mem[1], mem[2], state["raft_feat"], state["raft_netinp"]]
+
+    def _side_stream(self, dev):
+        if getattr(self, "_side", None) is None or self._side.device != dev:
+            self._side = torch.cuda.Stream(device=dev)
+        return self._side
+
+    # ---- eager frames (the first two pushes, or use_graph = False) -------------------------------
+    def _eager_step(self, left, right):
+        dev = left.device
+        side = self._side_stream(dev)
+        new = self._stage_a(left, right, side)
+        pred = self._stage_b(self.a_cur, self.state) if self.a_cur is not None else None
+        self._join_a(side, dev)
+        new["left_img"] = left.clone()  # the caller may reuse its image buffer
+        self.a_cur = new
+        return pred
+
+    # ---- graph ------------------------------------------------------------------------------------
+    def _capture(self, left, right):
+        dev = left.device
+        st = dict(l=torch.empty_like(left), r=torch.empty_like(right), primed=True)
+        st["state"] = [t.clone().contiguous() for t in self._state_tensors(self.state)]
+        st["a"] = {k: self.a_cur[k].clone().contiguous() for k in self.A_KEYS}
+        st["l"].copy_(left)
+        st["r"].copy_(right)
+        stream, side = torch.cuda.Stream(device=dev), self._side_stream(dev)
+        stream.wait_stream(torch.cuda.current_stream(dev))
+        g = torch.cuda.CUDAGraph()
+
+        def body():
+            s, a = st["state"], st["a"]
+            state = dict(memory=[s[0], s[1], s[2]], raft_feat=s[3], raft_netinp=s[4])
+            new = self._stage_a(st["l"], st["r"], side)
+            pred = self._stage_b(a, state)
+            self._join_a(side, dev)
+            # tail (kernel nodes only, see FrameRunner._capture): recurrent state, then rotate stage A
+            for dst, src in zip(s, self._state_tensors(state)):
+                ops.add_relu(src.contiguous(), None, relu=False, out=dst)
+            for k in self.A_KEYS:
+                ops.add_relu(new[k].contiguous(), None, relu=False, out=a[k])
+            return pred
+
+        saved = [t.clone() for t in st["state"]] + [st["a"][k].clone() for k in self.A_KEYS]
+
+        def restore():
+            for dst, src in zip(st["state"] + [st["a"][k] for k in self.A_KEYS], saved):
+                dst.copy_(src)
+
+        with torch.cuda.stream(stream):
+            body()  # warm-up (weight packing, allocator)
+            restore()
+            torch.cuda.synchronize(dev)
+            with torch.cuda.graph(g, stream=stream):
+                st["out"] = body()
+        torch.cuda.current_stream(dev).wait_stream(stream)
+        restore()
+        self.graph, self._static = g, st
+
+    def push(self, left, right):
+        """Feed frame k; returns the fused disparity [B,1,H,W] of frame k-1 (None for k = 0); the tensor is
+        valid until the next call."""
+        self.pushed += 1
+        if self.pushed <= 2 or not self.use_graph:
+            return self._eager_step(left, right)
+        if self.graph is None:
+            self._capture(left, right)
+        elif not self._static["primed"]:
+            for dst, src in zip(self._static["state"], self._state_tensors(self.state)):
+                dst.copy_(src)
+            for k in self.A_KEYS:
+                self._static["a"][k].copy_(self.a_cur[k])
+            self._static["primed"] = True
+        st = self._static
+        st["l"].copy_(left, non_blocking=True)
+        st["r"].copy_(right, non_blocking=True)
+        self.graph.replay()
+        return st["out"]
+
+    def flush(self):
+        """Disparity of the last pushed frame (runs its motion + fusion stages; ends the sequence)."""
+        if self.pushed == 0:
+            return None
+        if self.pushed <= 2 or not self.use_graph:
+            a, state = self.a_cur, self.state
+        else:
+            s, a = self._static["state"], self._static["a"]
+            state = dict(memory=[s[0], s[1], s[2]], raft_feat=s[3], raft_netinp=s[4])
+        pred = self._stage_b(a, state)
+        self.reset()
+        return pred

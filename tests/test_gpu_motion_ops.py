@@ -427,3 +427,31 @@ def test_metric_kernels_match_reference_calc_metric():
     ref = G["metric_values"]
     for i, k in enumerate(metrics.COLUMNS[:7]):
         assert abs(row[i].item() - float(ref[i])) < 2e-5 * max(1.0, abs(float(ref[i]))), (k, row[i].item(), ref[i])
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_pipelined_runner_equals_frame_runner(use_graph):
+    """Overlapping frame t+1's image-only work with frame t's motion + fusion must not change a bit."""
+    from codd_amd import configs, synth
+    from codd_amd.registry import build_estimator
+    from codd_amd.runtime import FrameRunner, PipelinedRunner
+    H, W, MF = 128, 256, 6
+    est = build_estimator(configs.codd(iters=2)).to(DEV).eval()
+    synth.load_synthetic_weights(est, gain=1.4)
+    left, right, _ = synth.stereo_sequence(H, W, MF, 32.0)
+    left, right = left.to(DEV), right.to(DEV)
+    metas = synth.default_metas(H, W)[0]
+    ref_runner = FrameRunner(est, metas, use_graph=use_graph)
+    ref = [ref_runner.step(left[:, f].contiguous(), right[:, f].contiguous()).clone() for f in range(MF)]
+    pr = PipelinedRunner(est, metas, use_graph=use_graph)
+    got = []
+    for f in range(MF):
+        o = pr.push(left[:, f].contiguous(), right[:, f].contiguous())
+        if f == 0:
+            assert o is None
+        else:
+            got.append(o.clone())
+    got.append(pr.flush().clone())
+    torch.cuda.synchronize()
+    for f in range(MF):
+        assert torch.equal(got[f], ref[f]), (f, (got[f] - ref[f]).abs().max().item())
