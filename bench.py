@@ -258,8 +258,14 @@ def main():
                     rr.step(*frame(i)[:2])
             cr = conv_roofline(rr, (l, r), device)
             ach = cr["gflop"] / cr["time_ms"]  # GFLOP/ms = TFLOP/s
+            traffic, tsrc = None, None
+            tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_final_conv_traffic.json")
+            if os.path.exists(tp):  # HBM-side bytes per conv launch from the committed rocprofv3 PMC passes
+                tj = json.load(open(tp))
+                traffic, tsrc = round(tj["traffic_bytes_per_launch"]), "profiles/r01_final_conv_traffic.json: " + tj["correction"]
             roof = dict(bound="mfma", achieved=round(ach, 3), peak=FP32_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), traffic=None, kernel="conv_mfma_kernel<*>",
+                        frac=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), traffic=traffic, traffic_unit="bytes/launch (PMC, "
+                        "not collected in this run)", traffic_source=tsrc, kernel="conv_mfma_kernel<*>",
                         launches_per_frame=cr["launches"], gflop_per_frame=round(cr["gflop"], 2),
                         conv_ms_per_frame=round(cr["time_ms"], 3))
         except Exception as e:  # pragma: no cover
