@@ -22,9 +22,20 @@ def _rs(name):
     return np.random.RandomState(zlib.crc32(name.encode()) & 0x7FFFFFFF)
 
 
+# Layers that emit RESIDUALS of the recurrent estimates (HITNet's hypothesis deltas, RAFT3D's target
+# residual): trained networks keep them small.  With unit-scale random weights the deltas are +-100 px, the
+# ReLU after every "d + delta" (reference propagation.py:171,232-237) zeroes ~99.7 % of the disparities
+# and a parity test would compare zeros with zeros; scaled down, the disparity stays around the cost-volume
+# initialisation and every stage sees live data.
+_RESIDUAL_LAYERS = (".lastconv.", ".update_block.delta.2.")
+_RESIDUAL_SCALE = 0.02
+
+
 def fill_tensor(name, shape, gain=1.0):
     """Deterministic value for state-dict entry ``name`` of ``shape`` (fp32 torch tensor)."""
     rs = _rs(name)
+    if any(t in name for t in _RESIDUAL_LAYERS):
+        gain = gain * _RESIDUAL_SCALE
     shape = tuple(int(s) for s in shape)
     leaf = name.rsplit(".", 1)[-1]
     if leaf == "num_batches_tracked":

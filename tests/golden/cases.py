@@ -101,3 +101,9 @@ def ablation_case(H=32, W=48, hg=30, wg=44):
     occ = (R(1, 1, hg, wg) > 1.0)
     return dict(pred=pred, warp=warp, gt=gt, img_prev=img_prev, feat_prev=feat_prev, disp_prev=disp_prev,
                 gt_flow=gt_flow, gt_disp_change=gt_dc, gt_flow_occ=occ, left_feat=R(1, 24, H // 4, W // 4))
+
+
+def cfg1_sequence():
+    """BASELINE.json configs[0]: 2-frame 512x256 synthetic stereo pair sequence."""
+    img, r_img, _ = synth.stereo_sequence(256, 512, 2, dmax=40.0)
+    return img, r_img

@@ -68,6 +68,11 @@ def main():
             _, hyps = est.stereo.tile_init(fea_l, fea_r)
             for i, h in enumerate(hyps):
                 out[f"stereo_{name}_init_d{i}"] = h[:, 0:1]
+        # ---- BASELINE.json configs[0]: stereo-only, 2-frame 512x256 sequence through the reference's own
+        #      ConsistentOnlineDynamicDepth.inference (every 2nd pixel is stored: 128 KiB) -------------
+        img, r_img = cases.cfg1_sequence()
+        meta = [dict(img_shape=(256, 512, 3), disp_range=(1, 210), intrinsics=[1050.0, 1050.0, 256.0, 128.0])]
+        out["cfg1_pred_disp"] = est.inference(img, r_img, meta, evaluate=False)[:, :, ::2, ::2]
         # ---- fusion ----------------------------------------------------------------------------
         fus = load(MODELS.build(dict(type="Fusion", in_channels=24, fusion_channel=32,
                                      corr_cfg=dict(type="px2patch", patch_size=3))), sd, "fusion.")

@@ -34,3 +34,28 @@ def test_hitnet_matches_oracle(H, W):
     flipped = ((d - dr).abs() > 0.5).float().mean().item()
     print(f"EPE delta {epe:.3e}, >0.5px {flipped:.3e}, max {(d - dr).abs().max().item():.3e}")
     assert epe < 1e-3, epe
+
+
+def test_cfg1_stereo_only_sequence_matches_reference_output():
+    """BASELINE.json configs[0] on the GPU: 2-frame 512x256 stereo-only sequence, HIP path vs the
+    REFERENCE's own output (tests/golden cfg1_pred_disp, every 2nd pixel): EPE <= 1e-3 px."""
+    import os
+    import sys
+    import numpy as np
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gdir)
+    import cases
+    from codd_amd import configs
+    from codd_amd.registry import build_estimator
+    G = np.load(os.path.join(gdir, "reference_outputs.npz"))
+    est = build_estimator(configs.stereo_only())
+    sd = cases.state_dict()
+    est.load_state_dict({k: v for k, v in sd.items() if k.startswith("stereo.")}, strict=True)
+    est = est.to("cuda").eval()
+    img, r_img = cases.cfg1_sequence()
+    meta = [[dict(img_shape=(256, 512, 3), disp_range=(1, 210), intrinsics=[1050.0, 1050.0, 256.0, 128.0])]]
+    pred = est(img=[img.cuda()], r_img=[r_img.cuda()], img_metas=meta, return_loss=False, evaluate=False)[0]
+    ref = torch.from_numpy(G["cfg1_pred_disp"])
+    epe = (pred.cpu()[:, :, ::2, ::2] - ref).abs().mean().item()
+    assert epe < 1e-3, epe
+    assert (ref > 0).float().mean() > 0.9

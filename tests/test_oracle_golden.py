@@ -102,3 +102,21 @@ def test_ablation_plugins_match_reference():
                              c["gt_flow_occ"])
     for t, k in zip(mem, ("img", "feat", "conf", "disp", "flow")):
         assert torch.equal(t.reshape(G[f"ablation_gtmotion_{k}"].shape), torch.from_numpy(G[f"ablation_gtmotion_{k}"])), k
+
+
+def test_cfg1_stereo_only_sequence_matches_reference():
+    """BASELINE.json configs[0]: 2-frame 512x256 stereo-only sequence through the reference's own
+    ConsistentOnlineDynamicDepth.inference vs the oracle's frame loop (every 2nd pixel is stored)."""
+    from oracle import codd as oc
+    sd = cases.state_dict()
+    img, r_img = cases.cfg1_sequence()
+    state, preds = {}, []
+    with torch.no_grad():
+        for f in range(2):
+            preds.append(oc.frame(sd, img[:, f], r_img[:, f], state, (1050.0, 1050.0, 256.0, 128.0),
+                                  with_motion=False, with_fusion=False))
+    pred = torch.cat([p["pred_disp"] for p in preds], 1)[:, :, ::2, ::2]
+    ref = torch.from_numpy(G["cfg1_pred_disp"])
+    epe = (pred - ref).abs().mean().item()
+    assert epe < 1e-3, epe  # north-star bound: <= 1e-3 px EPE vs the reference PyTorch path
+    assert (ref > 0).float().mean() > 0.9  # the comparison is over live disparities, not zeros
