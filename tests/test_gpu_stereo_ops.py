@@ -170,3 +170,26 @@ def test_hyp_upsample_select():
     out = torch.empty(2, 16, 9, 15, device=dev())
     ops.hyp_select(upd.to(dev()), cur.to(dev()), prev.to(dev()), out)
     assert (out.cpu() - ref).abs().max().item() < 1e-6
+
+
+def test_c_abi_error_codes_are_loud():
+    """Invalid arguments come back as negative CODD_E* codes (never a silent fallback), surfaced as
+    CoddHipError by the Python host (reference behaviour: Python exceptions)."""
+    import ctypes as C
+    from codd_amd import _abi, ops
+    lib = _abi.load()
+    x = rnd(1, 32, 16, 32).to("cuda")
+    pc = ops.PackedConv(rnd(32, 32, 3, 3, seed=1).to("cuda"), None)
+    p = _abi.ConvParams()
+    C.memset(C.byref(p), 0, C.sizeof(p))
+    assert lib.codd_conv2d(C.byref(p), None) == -1  # CODD_EINVAL: no input / output / weights
+    old = ops._FORCE_NW
+    ops._FORCE_NW = 7  # not an instantiated workgroup height
+    try:
+        with pytest.raises(_abi.CoddHipError, match="-2"):  # CODD_EUNSUPPORTED
+            ops.conv2d(x, pc, pad=1)
+    finally:
+        ops._FORCE_NW = old
+    assert lib.codd_tile_costvol_argmin(None, None, 1, 16, 4, 8, 32, 4, None, 1, 0, None, 1, 0, 4, None) == -1
+    with pytest.raises(_abi.CoddHipError):
+        ops.conv2d(x.cpu(), pc, pad=1)  # host tensor: the product path has no CPU fallback
