@@ -59,3 +59,20 @@ def test_cfg1_stereo_only_sequence_matches_reference_output():
     epe = (pred.cpu()[:, :, ::2, ::2] - ref).abs().mean().item()
     assert epe < 1e-3, epe
     assert (ref > 0).float().mean() > 0.9
+
+
+def test_stereo_only_graph_replay_equals_eager():
+    from codd_amd import configs, synth
+    from codd_amd.registry import build_estimator
+    from codd_amd.runtime import FrameRunner
+    est = build_estimator(configs.stereo_only()).to("cuda").eval()
+    synth.load_synthetic_weights(est, gain=1.4)
+    img, r_img, _ = synth.stereo_sequence(128, 256, 3, 24.0)
+    img, r_img = img.cuda(), r_img.cuda()
+    metas = synth.default_metas(128, 256)[0]
+    eager, graph = FrameRunner(est, metas, use_graph=False), FrameRunner(est, metas, use_graph=True)
+    for f in range(3):
+        a = eager.step(img[:, f].contiguous(), r_img[:, f].contiguous()).clone()
+        b = graph.step(img[:, f].contiguous(), r_img[:, f].contiguous()).clone()
+        assert torch.equal(a, b), f
+    assert graph.graph is not None
