@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--prewarm", type=int, default=30,
+    ap.add_argument("--prewarm", type=int, default=150,
                     help="untimed steady-state frames run before the W warm-up steps so that the GPU clocks and "
                          "the captured graph are in steady state (reported in config.prewarm_frames)")
     ap.add_argument("--iters", type=int, default=16)
@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--stereo-only", action="store_true")
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="use the heuristic conv launch configurations instead of timing the alternatives once per "
+                         "layer shape during the (untimed) first frames")
     ap.add_argument("--frame-pipeline", type=int, default=0, choices=[0, 1],
                     help="1: codd_amd.runtime.PipelinedRunner -- frame t+1's image-only work (stereo network, "
                          "RAFT3D encoders) overlaps frame t's motion + fusion inside one graph (same results, one "
@@ -188,6 +191,8 @@ def main():
     from codd_amd import metrics, synth
     from codd_amd.runtime import FrameRunner, PipelinedRunner
 
+    from codd_amd import ops as _ops_tune
+    _ops_tune.enable_autotune(not args.no_autotune)
     est = build_model(args, device)
     if args.serial_streams:
         from codd_amd import ops as _ops
@@ -246,6 +251,10 @@ def main():
         dt = tt.item()
 
     log(f"timed region done: {dt:.3f} s")
+    if os.environ.get("CODD_BENCH_VERBOSE"):
+        for r in sorted(_ops_tune.AUTOTUNE_LOG, key=lambda r: -((r[2] or 0) - r[4])):
+            if r[1] != r[3]:
+                log("autotune %-34s heuristic %s %.1f us -> %s %.1f us" % (r[0], r[1], r[2] or -1, r[3], r[4]))
     roof = None
     cpu = None
     if rank == 0:
@@ -288,6 +297,9 @@ def main():
                                    "steady-state frames (idx>=1), synthetic stereo sequence, random-init weights",
                        "hip_graph": bool(runner.graph is not None), "frames_per_gpu": args.steps,
                        "prewarm_frames": args.prewarm, "side_streams": not args.serial_streams,
+                       "conv_autotune": ("off" if args.no_autotune else "%d layer shapes timed in the first frames, %d "
+                                         "moved off the heuristic" % (len(_ops_tune.AUTOTUNE_LOG), sum(
+                                             1 for r in _ops_tune.AUTOTUNE_LOG if r[1] != r[3]))),
                        "frame_pipeline": ("depth 2: stereo/encoders of frame t+1 overlap motion+fusion of frame t "
                                           "(identical outputs, +1 frame latency)" if pipelined else "off"),
                        "fps_per_gpu": round(fps / world, 3)},

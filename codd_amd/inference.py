@@ -97,6 +97,7 @@ def main(argv=None):
         print("no checkpoint given: synthetic weights (outputs are meaningless, timing is not)")
         synth.load_synthetic_weights(model, gain=1.4)
     model = model.to(device).eval()
+    ops.enable_autotune(True)  # time the conv launch configurations once per layer shape (first frames)
     videos = list_videos(args.img_dir, args.r_img_dir, args.img_suffix)
     mine = apis.shard_loader(videos) if distributed else videos
 

@@ -76,6 +76,7 @@ class PackedConv:
             self.mb = _FORCE_MB
         self._w = w
         self._packs = {}
+        self.tuned = {}  # launch shape -> (npb, nw, ck)
 
     def packed(self, ck):
         if ck not in self._packs:
@@ -188,7 +189,16 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
         out = torch.empty(B, pc.cout, Hout * up, Wout * up, device=xs.buf.device, dtype=torch.float32)
     os_ = _as_slice(out)
     assert os_.shape == (B, pc.cout, Hout * up, Wout * up), (os_.shape, (B, pc.cout, Hout * up, Wout * up))
-    npb, nw, ck = _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl)
+    key = (Hout, Wout, B, sy, sx, dy, dx, pl, C1 > 0)
+    cfg = pc.tuned.get(key)
+    if cfg is None:
+        cfg = _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl)
+        tune = _AUTOTUNE and not torch.cuda.is_current_stream_capturing()
+        if not _AUTOTUNE or tune:
+            pc.tuned[key] = cfg  # (while capturing with autotune on: heuristic for this launch, tune later)
+    else:
+        tune = False
+    npb, nw, ck = cfg
     p = ConvParams()
     p.in0 = _view(xs)
     p.in1 = _view(x2)
@@ -202,8 +212,64 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
     p.act = ACT[act]
     p.store_mode = 1 if pc.deconv else 0
     p.mb, p.npb, p.nw, p.ck = pc.mb, npb, nw, ck
+    if tune:
+        npb, nw, ck = pc.tuned[key] = _autotune(lib, p, pc, cfg)
+        p.wpacked = pc.packed(ck).data_ptr()
+        p.npb, p.nw, p.ck = npb, nw, ck
     _abi.check(_launch_conv(lib, p, _stream()), "codd_conv2d")
     return out
+
+
+_AUTOTUNE = bool(int(_os.environ.get("CODD_AUTOTUNE", "0")))
+AUTOTUNE_LOG = []  # (layer description, heuristic cfg, us, chosen cfg, us) of every tuned launch shape
+
+
+def enable_autotune(flag=True):
+    """Measure-don't-guess launch configuration: the first (eager, un-captured) launch of every
+    (layer, shape) times the heuristic (npb, nw, ck) against every other configuration the kernel is
+    instantiated for and keeps the fastest for the rest of the process (bench.py turns this on; the tests
+    run the deterministic heuristics).  Different chunk depths change the fp32 summation order, nothing else."""
+    global _AUTOTUNE
+    _AUTOTUNE = bool(flag)
+
+
+def _autotune(lib, p, pc, default):
+    cin_pad = -(-pc.cin // 4) * 4
+    cks = sorted({c for c in (8, 12, 16, 24, 32) if c <= cin_pad} | {min(cin_pad, 32)})
+    cands = [default]
+    for npb in (1, 2, 4):
+        for nw in ((4, 9) if (npb == 1 and pc.mb >= 2) else (4,)):
+            for ck in cks:
+                if (npb, nw, ck) not in cands:
+                    cands.append((npb, nw, ck))
+    stream = _stream()
+    torch.cuda.synchronize()  # nothing else on the device while the candidates are timed
+    best, best_t, t_default = default, float("inf"), None
+    for (npb, nw, ck) in [default] + cands:  # the heuristic is timed twice (first = warm-up of clocks / caches)
+        try:
+            p.wpacked = pc.packed(ck).data_ptr()
+        except Exception:
+            continue
+        p.npb, p.nw, p.ck = npb, nw, ck
+        if _launch_conv(lib, p, stream) != 0:  # not instantiated / LDS or staging limits: skip
+            continue
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(3):
+            _launch_conv(lib, p, stream)
+        e.record()
+        e.synchronize()
+        t = s.elapsed_time(e) / 3.0
+        if (npb, nw, ck) == default:
+            if t_default is None:
+                t_default = t
+                continue  # warm-up pass
+            t_default = t
+        if t < best_t * 0.97 or best_t == float("inf"):  # 3 % hysteresis: earlier (heuristic-first) candidates win ties
+            best, best_t = (npb, nw, ck), t
+    AUTOTUNE_LOG.append(("%dx%d k%dx%d %d->%d out %dx%d" % (p.sy, p.sx, pc.kh, pc.kw, pc.cin, pc.cout, p.Hout, p.Wout),
+                         default, None if t_default is None else t_default * 1e3, best, best_t * 1e3))
+    return best
 
 
 # ----------------------------------------------------------------------------------------- stereo

@@ -193,3 +193,23 @@ def test_c_abi_error_codes_are_loud():
     assert lib.codd_tile_costvol_argmin(None, None, 1, 16, 4, 8, 32, 4, None, 1, 0, None, 1, 0, 4, None) == -1
     with pytest.raises(_abi.CoddHipError):
         ops.conv2d(x.cpu(), pc, pad=1)  # host tensor: the product path has no CPU fallback
+
+
+def test_autotuned_launch_configuration_keeps_results():
+    """ops.enable_autotune: the first launch of a layer shape times the alternative (npb, nw, ck)
+    configurations; whichever wins, the output only differs by fp32 summation order."""
+    from codd_amd import ops
+    x = rnd(1, 64, 72, 120).to("cuda")
+    w = (rnd(128, 64, 3, 3, seed=1) / 24.0).to("cuda")
+    ref = ops.conv2d(x, ops.PackedConv(w, None), pad=1, act="relu")
+    n0 = len(ops.AUTOTUNE_LOG)
+    ops.enable_autotune(True)
+    try:
+        pc = ops.PackedConv(w, None)
+        y1 = ops.conv2d(x, pc, pad=1, act="relu")
+        y2 = ops.conv2d(x, pc, pad=1, act="relu")  # cached configuration
+    finally:
+        ops.enable_autotune(False)
+    assert len(ops.AUTOTUNE_LOG) == n0 + 1 and len(pc.tuned) == 1
+    assert torch.equal(y1, y2)
+    assert (y1 - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
