@@ -191,13 +191,17 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
     assert os_.shape == (B, pc.cout, Hout * up, Wout * up), (os_.shape, (B, pc.cout, Hout * up, Wout * up))
     key = (Hout, Wout, B, sy, sx, dy, dx, pl, C1 > 0)
     cfg = pc.tuned.get(key)
+    tune = False
     if cfg is None:
-        cfg = _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl)
-        tune = _AUTOTUNE and not torch.cuda.is_current_stream_capturing()
-        if not _AUTOTUNE or tune:
-            pc.tuned[key] = cfg  # (while capturing with autotune on: heuristic for this launch, tune later)
-    else:
-        tune = False
+        sig = "%d,%d,%d,%d,%d,%d|" % (pc.cout_eff, pc.cin, pc.kh, pc.kw, pc.mb, int(pc.deconv)) + ",".join(
+            str(int(v)) for v in key)
+        if _AUTOTUNE and sig in TUNE_DB:  # same layer signature already timed (this process or a loaded file)
+            cfg = pc.tuned[key] = tuple(TUNE_DB[sig])
+        else:
+            cfg = _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl)
+            tune = _AUTOTUNE and not torch.cuda.is_current_stream_capturing()
+            if not _AUTOTUNE or tune:
+                pc.tuned[key] = cfg  # (while capturing with autotune on: heuristic for this launch, tune later)
     npb, nw, ck = cfg
     p = ConvParams()
     p.in0 = _view(xs)
@@ -213,7 +217,7 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
     p.store_mode = 1 if pc.deconv else 0
     p.mb, p.npb, p.nw, p.ck = pc.mb, npb, nw, ck
     if tune:
-        npb, nw, ck = pc.tuned[key] = _autotune(lib, p, pc, cfg)
+        npb, nw, ck = pc.tuned[key] = TUNE_DB[sig] = _autotune(lib, p, pc, cfg)
         p.wpacked = pc.packed(ck).data_ptr()
         p.npb, p.nw, p.ck = npb, nw, ck
     _abi.check(_launch_conv(lib, p, _stream()), "codd_conv2d")
@@ -222,6 +226,20 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
 
 _AUTOTUNE = bool(int(_os.environ.get("CODD_AUTOTUNE", "0")))
 AUTOTUNE_LOG = []  # (layer description, heuristic cfg, us, chosen cfg, us) of every tuned launch shape
+
+
+TUNE_DB = {}  # layer signature "cout,cin,kh,kw,mb,deconv|launch shape" -> (npb, nw, ck)
+
+
+def save_tune_db(path):
+    import json
+    with open(path, "w") as f:
+        json.dump({k: list(v) for k, v in TUNE_DB.items()}, f, indent=0, sort_keys=True)
+
+
+def load_tune_db(path):
+    import json
+    TUNE_DB.update({k: tuple(v) for k, v in json.load(open(path)).items()})
 
 
 def enable_autotune(flag=True):

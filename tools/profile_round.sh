@@ -4,13 +4,15 @@
 # the committed summaries under profiles/.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_final; mkdir -p $OUT
+rm -f $OUT/tune_db.json
+python $R/bench.py --no-cpu-baseline --tune-db $OUT/tune_db.json > $OUT/bench_plain.log 2>&1   # un-profiled: tunes, writes the db
 for mode in serial default; do
   flag=""; [ $mode = serial ] && flag="--serial-streams"
   rm -rf /tmp/st_$mode
-  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$mode -o s -- python $R/bench.py --no-cpu-baseline $flag > $OUT/bench_$mode.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$mode -o s -- python $R/bench.py --no-cpu-baseline --tune-db $OUT/tune_db.json $flag > $OUT/bench_$mode.log 2>&1
   cp /tmp/st_$mode/s_kernel_stats.csv $OUT/${mode}_kernel_stats.csv
 done
-CMD="python $R/bench.py --no-cpu-baseline --serial-streams --steps 4 --prewarm 2 --warmup 1 --no-graph"
+CMD="python $R/bench.py --no-cpu-baseline --tune-db $OUT/tune_db.json --serial-streams --steps 4 --prewarm 2 --warmup 1 --no-graph"
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do
   tag=$(echo $set | cut -d' ' -f1)
   rm -rf /tmp/pm_$tag
@@ -28,4 +30,4 @@ with open(dst, "w") as f:
         w.writerow([kn, cn, s, n])
 PY
 done
-tail -1 $OUT/bench_serial.log; tail -1 $OUT/bench_default.log; ls -la $OUT
+tail -1 $OUT/bench_plain.log | cut -c1-200; ls -la $OUT
