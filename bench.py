@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--stereo-only", action="store_true")
+    ap.add_argument("--tune-db", default=None,
+                    help="JSON file of tuned launch configurations: loaded if it exists (no tuning launches, e.g. under "
+                         "a profiler), written at the end otherwise")
     ap.add_argument("--no-autotune", action="store_true",
                     help="use the heuristic conv launch configurations instead of timing the alternatives once per "
                          "layer shape during the (untimed) first frames")
@@ -193,6 +196,8 @@ def main():
 
     from codd_amd import ops as _ops_tune
     _ops_tune.enable_autotune(not args.no_autotune)
+    if args.tune_db and os.path.exists(args.tune_db):
+        _ops_tune.load_tune_db(args.tune_db)
     est = build_model(args, device)
     if args.serial_streams:
         from codd_amd import ops as _ops
@@ -251,6 +256,8 @@ def main():
         dt = tt.item()
 
     log(f"timed region done: {dt:.3f} s")
+    if args.tune_db and rank == 0 and not os.path.exists(args.tune_db):
+        _ops_tune.save_tune_db(args.tune_db)
     if os.environ.get("CODD_BENCH_VERBOSE"):
         for r in sorted(_ops_tune.AUTOTUNE_LOG, key=lambda r: -((r[2] or 0) - r[4])):
             if r[1] != r[3]:
@@ -297,9 +304,10 @@ def main():
                                    "steady-state frames (idx>=1), synthetic stereo sequence, random-init weights",
                        "hip_graph": bool(runner.graph is not None), "frames_per_gpu": args.steps,
                        "prewarm_frames": args.prewarm, "side_streams": not args.serial_streams,
-                       "conv_autotune": ("off" if args.no_autotune else "%d layer shapes timed in the first frames, %d "
-                                         "moved off the heuristic" % (len(_ops_tune.AUTOTUNE_LOG), sum(
-                                             1 for r in _ops_tune.AUTOTUNE_LOG if r[1] != r[3]))),
+                       "conv_autotune": ("off" if args.no_autotune else "%d layer signatures tuned (%d timed in this run's "
+                                         "first frames, %d moved off the heuristic)" % (
+                                             len(_ops_tune.TUNE_DB), len(_ops_tune.AUTOTUNE_LOG),
+                                             sum(1 for r in _ops_tune.AUTOTUNE_LOG if r[1] != r[3]))),
                        "frame_pipeline": ("depth 2: stereo/encoders of frame t+1 overlap motion+fusion of frame t "
                                           "(identical outputs, +1 frame latency)" if pipelined else "off"),
                        "fps_per_gpu": round(fps / world, 3)},
