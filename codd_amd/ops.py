@@ -78,15 +78,22 @@ class PackedConv:
         self._packs = {}
         self.tuned = {}  # launch shape -> (npb, nw, ck)
 
-    def packed(self, ck):
-        if ck not in self._packs:
+    def packed(self, ck, mb=None):
+        mb = self.mb if mb is None else mb
+        if (mb, ck) not in self._packs:
             lib = _abi.load()
-            n = lib.codd_conv2d_packed_size(self.cout_eff, self.cin, self.kh, self.kw, self.mb, ck)
+            n = lib.codd_conv2d_packed_size(self.cout_eff, self.cin, self.kh, self.kw, mb, ck)
             wp = torch.empty(n, device=self._w.device, dtype=torch.float32)
             _abi.check(lib.codd_conv2d_pack_weights(self._w.data_ptr(), wp.data_ptr(), self.cout_eff, self.cin,
-                                                    self.kh, self.kw, self.mb, ck, _stream()), "pack_weights")
-            self._packs[ck] = wp
-        return self._packs[ck]
+                                                    self.kh, self.kw, mb, ck, _stream()), "pack_weights")
+            self._packs[(mb, ck)] = wp
+        return self._packs[(mb, ck)]
+
+    def drop_unused_packs(self):
+        """Free the packed-weight variants no tuned configuration refers to (after autotuning)."""
+        used = {(c[3] if len(c) > 3 else self.mb, c[2]) for c in self.tuned.values()}
+        for k in [k for k in self._packs if k not in used]:
+            del self._packs[k]
 
 
 def _launch_conv(lib, p, stream):
@@ -202,12 +209,13 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
             tune = _AUTOTUNE and not torch.cuda.is_current_stream_capturing()
             if not _AUTOTUNE or tune:
                 pc.tuned[key] = cfg  # (while capturing with autotune on: heuristic for this launch, tune later)
-    npb, nw, ck = cfg
+    npb, nw, ck = cfg[:3]
+    mb = cfg[3] if len(cfg) > 3 else pc.mb
     p = ConvParams()
     p.in0 = _view(xs)
     p.in1 = _view(x2)
     p.C0, p.C1, p.B, p.Hin, p.Win = C0, C1, B, Hin, Win
-    p.wpacked = pc.packed(ck).data_ptr()
+    p.wpacked = pc.packed(ck, mb).data_ptr()
     p.bias = None if pc.bias is None else pc.bias.data_ptr()
     p.res1, p.res2, p.post = _view(res1), _view(res2), _view(post)
     p.out, p.out_ctot, p.out_coff = os_.buf.data_ptr(), os_.buf.shape[1], os_.coff
@@ -215,11 +223,11 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
     p.kh, p.kw, p.sy, p.sx, p.pad_t, p.pad_l, p.dil_y, p.dil_x = pc.kh, pc.kw, sy, sx, pt, pl, dy, dx
     p.act = ACT[act]
     p.store_mode = 1 if pc.deconv else 0
-    p.mb, p.npb, p.nw, p.ck = pc.mb, npb, nw, ck
+    p.mb, p.npb, p.nw, p.ck = mb, npb, nw, ck
     if tune:
-        npb, nw, ck = pc.tuned[key] = TUNE_DB[sig] = _autotune(lib, p, pc, cfg)
-        p.wpacked = pc.packed(ck).data_ptr()
-        p.npb, p.nw, p.ck = npb, nw, ck
+        npb, nw, ck, mb = pc.tuned[key] = TUNE_DB[sig] = _autotune(lib, p, pc, (npb, nw, ck, mb))
+        p.wpacked = pc.packed(ck, mb).data_ptr()
+        p.mb, p.npb, p.nw, p.ck = mb, npb, nw, ck
     _abi.check(_launch_conv(lib, p, _stream()), "codd_conv2d")
     return out
 
@@ -254,21 +262,23 @@ def enable_autotune(flag=True):
 def _autotune(lib, p, pc, default):
     cin_pad = -(-pc.cin // 4) * 4
     cks = sorted({c for c in (8, 12, 16, 24, 32) if c <= cin_pad} | {min(cin_pad, 32)})
+    mbs = [m for m in (1, 2, 4) if m == pc.mb or (16 * m <= max(16, -(-pc.cout_eff // 16) * 16) and pc.cout_eff > 16)]
     cands = [default]
-    for npb in (1, 2, 4):
-        for nw in ((4, 9) if (npb == 1 and pc.mb >= 2) else (4,)):
-            for ck in cks:
-                if (npb, nw, ck) not in cands:
-                    cands.append((npb, nw, ck))
+    for mb in mbs:
+        for npb in (1, 2, 4):
+            for nw in ((4, 9) if (npb == 1 and mb >= 2) else (4,)):
+                for ck in cks:
+                    if (npb, nw, ck, mb) not in cands:
+                        cands.append((npb, nw, ck, mb))
     stream = _stream()
     torch.cuda.synchronize()  # nothing else on the device while the candidates are timed
     best, best_t, t_default = default, float("inf"), None
-    for (npb, nw, ck) in [default] + cands:  # the heuristic is timed twice (first = warm-up of clocks / caches)
+    for (npb, nw, ck, mb) in [default] + cands:  # the heuristic is timed twice (first = warm-up of clocks / caches)
         try:
-            p.wpacked = pc.packed(ck).data_ptr()
+            p.wpacked = pc.packed(ck, mb).data_ptr()
         except Exception:
             continue
-        p.npb, p.nw, p.ck = npb, nw, ck
+        p.mb, p.npb, p.nw, p.ck = mb, npb, nw, ck
         if _launch_conv(lib, p, stream) != 0:  # not instantiated / LDS or staging limits: skip
             continue
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -278,13 +288,16 @@ def _autotune(lib, p, pc, default):
         e.record()
         e.synchronize()
         t = s.elapsed_time(e) / 3.0
-        if (npb, nw, ck) == default:
+        if (npb, nw, ck, mb) == default:
             if t_default is None:
                 t_default = t
                 continue  # warm-up pass
             t_default = t
         if t < best_t * 0.97 or best_t == float("inf"):  # 3 % hysteresis: earlier (heuristic-first) candidates win ties
-            best, best_t = (npb, nw, ck), t
+            best, best_t = (npb, nw, ck, mb), t
+    used = {(c[3] if len(c) > 3 else pc.mb, c[2]) for c in pc.tuned.values()} | {(best[3], best[2])}
+    for k in [k for k in pc._packs if k not in used]:
+        del pc._packs[k]  # packed-weight variants of the losing candidates
     AUTOTUNE_LOG.append(("%dx%d k%dx%d %d->%d out %dx%d" % (p.sy, p.sx, pc.kh, pc.kw, pc.cin, pc.cout, p.Hout, p.Wout),
                          default, None if t_default is None else t_default * 1e3, best, best_t * 1e3))
     return best
