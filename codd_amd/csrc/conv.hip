@@ -93,14 +93,15 @@ static int launch_conv_regs(const ConvK& k, size_t lds, int grid, hipStream_t s)
   return CODD_EUNSUPPORTED;
 }
 
-// Workgroups of 9 waves (9 tile rows of 16 pixels): for maps where a 4-row tiling leaves the last round of
-// workgroups nearly empty (72 rows x 8 column tiles x 4 channel groups = 576 blocks = 2.25 per CU with 4
-// waves, exactly 256 with 9: the weights of a chunk are then fetched once per 9 rows instead of per 4).
-template <int MB>
-static int launch_conv_nw9(const ConvK& k, size_t lds, int grid, hipStream_t s) {
-  const int wr = cdiv(k.wchunk >> 2, 9 * 64), ir = cdiv(k.nunits, 9 * 64);
-  if (wr <= 8 && ir <= 4) return launch_conv<9, 1, MB, 8, 4>(k, lds, grid, s);
-  if (wr <= 16 && ir <= 4) return launch_conv<9, 1, MB, 16, 4>(k, lds, grid, s);
+// Workgroups of NW != 4 waves (NW tile rows of 16 pixels).  9: for maps where a 4-row tiling leaves the last
+// round of workgroups nearly empty (72 rows x 8 column tiles x 4 channel groups = 576 blocks = 2.25 per CU with 4
+// waves, exactly 256 with 9: the weights of a chunk are then fetched once per 9 rows instead of per 4).  2 and
+// 8: more / fewer, smaller / larger workgroups for the autotuner (tiny maps, 144- and 288-row maps).
+template <int NW, int MB>
+static int launch_conv_nwx(const ConvK& k, size_t lds, int grid, hipStream_t s) {
+  const int wr = cdiv(k.wchunk >> 2, NW * 64), ir = cdiv(k.nunits, NW * 64);
+  if (wr <= 8 && ir <= 4) return launch_conv<NW, 1, MB, 8, 4>(k, lds, grid, s);
+  if (wr <= 16 && ir <= 4) return launch_conv<NW, 1, MB, 16, 4>(k, lds, grid, s);
   return CODD_EUNSUPPORTED;
 }
 
@@ -121,7 +122,7 @@ extern "C" int codd_conv2d(const codd_conv_params* pp, void* stream) {
   k.ntaps = p.kh * p.kw;
   const int xb = p.npb >= 2 ? 2 : 1, rpw = p.npb / xb;
   const int nw = p.nw ? p.nw : 4;
-  if (nw != 4 && (nw != 9 || p.npb != 1 || p.mb == 1)) return CODD_EUNSUPPORTED;
+  if (nw != 4 && (!(nw == 9 || nw == 2 || nw == 8) || p.npb != 1)) return CODD_EUNSUPPORTED;
   k.th = nw * rpw;
   k.tw = 16 * xb;
   k.thi = (k.th - 1) * p.sy + (p.kh - 1) * p.dil_y + 1;
@@ -148,7 +149,9 @@ extern "C" int codd_conv2d(const codd_conv_params* pp, void* stream) {
   long long grid = (long long)k.tiles_x * k.tiles_y * k.ncog * p.B;
   if (grid <= 0 || grid > 0x7fffffffLL) return CODD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (nw == 9) return p.mb == 2 ? launch_conv_nw9<2>(k, lds, (int)grid, s) : launch_conv_nw9<4>(k, lds, (int)grid, s);
+#define CASEW(W, M) if (nw == W && p.mb == M) return launch_conv_nwx<W, M>(k, lds, (int)grid, s)
+  CASEW(9, 1); CASEW(9, 2); CASEW(9, 4); CASEW(2, 1); CASEW(2, 2); CASEW(2, 4); CASEW(8, 1); CASEW(8, 2); CASEW(8, 4);
+#undef CASEW
 #define CASE(N, M) if (p.npb == N && p.mb == M) return launch_conv_regs<N, M>(k, lds, (int)grid, s)
   CASE(1, 1); CASE(1, 2); CASE(1, 4);
   CASE(2, 1); CASE(2, 2); CASE(2, 4);

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(const ConvK k) {
 
 // ---- instantiation lists (X(NW, NPB, MB, WREG, IREG)) -----------------------------------------------
 #define CONV_REGS_NW4(X, NPB, MB) X(4, NPB, MB, 4, 4) X(4, NPB, MB, 4, 8) X(4, NPB, MB, 12, 4) X(4, NPB, MB, 12, 8) X(4, NPB, MB, 16, 8)
-#define CONV_REGS_NW9(X, MB) X(9, 1, MB, 8, 4) X(9, 1, MB, 16, 4)
+#define CONV_REGS_NWX(X, NW, MB) X(NW, 1, MB, 8, 4) X(NW, 1, MB, 16, 4)
 #define CONV_GROUP_0(X) CONV_REGS_NW4(X, 1, 1)
 #define CONV_GROUP_1(X) CONV_REGS_NW4(X, 1, 2)
 #define CONV_GROUP_2(X) CONV_REGS_NW4(X, 1, 4)
@@ -216,7 +216,9 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(const ConvK k) {
 #define CONV_GROUP_4(X) CONV_REGS_NW4(X, 2, 4) CONV_REGS_NW4(X, 4, 1)
 #define CONV_GROUP_5(X) CONV_REGS_NW4(X, 4, 2)
 #define CONV_GROUP_6(X) CONV_REGS_NW4(X, 4, 4)
-#define CONV_GROUP_7(X) CONV_REGS_NW9(X, 2) CONV_REGS_NW9(X, 4)
-#define CONV_ALL_GROUPS(X) CONV_GROUP_0(X) CONV_GROUP_1(X) CONV_GROUP_2(X) CONV_GROUP_3(X) CONV_GROUP_4(X) CONV_GROUP_5(X) CONV_GROUP_6(X) CONV_GROUP_7(X)
+#define CONV_GROUP_7(X) CONV_REGS_NWX(X, 9, 1) CONV_REGS_NWX(X, 9, 2) CONV_REGS_NWX(X, 9, 4)
+#define CONV_GROUP_8(X) CONV_REGS_NWX(X, 2, 1) CONV_REGS_NWX(X, 2, 2) CONV_REGS_NWX(X, 2, 4)
+#define CONV_GROUP_9(X) CONV_REGS_NWX(X, 8, 1) CONV_REGS_NWX(X, 8, 2) CONV_REGS_NWX(X, 8, 4)
+#define CONV_ALL_GROUPS(X) CONV_GROUP_0(X) CONV_GROUP_1(X) CONV_GROUP_2(X) CONV_GROUP_3(X) CONV_GROUP_4(X) CONV_GROUP_5(X) CONV_GROUP_6(X) CONV_GROUP_7(X) CONV_GROUP_8(X) CONV_GROUP_9(X)
 #define CONV_DECLARE(NW, NPB, MB, WREG, IREG) extern template __global__ void conv_mfma_kernel<NW, NPB, MB, WREG, IREG>(const ConvK);
 #define CONV_DEFINE(NW, NPB, MB, WREG, IREG) template __global__ void conv_mfma_kernel<NW, NPB, MB, WREG, IREG>(const ConvK);

@@ -119,7 +119,7 @@ def _pick_nw(pc, npb, Hout, Wout, B, ncog):
     = 1 round x 9 rows with nw = 9 (measured 88 -> 82, 165 -> 153, 133 -> 125 us on the 128/256/196 -> 256
     3x3 layers; tools/time_conv_sweep.py).  Only for the plain 4x16 tile with >= 32 channels per group."""
     if _FORCE_NW:
-        return _FORCE_NW if (npb == 1 and pc.mb >= 2) else 4
+        return _FORCE_NW if npb == 1 else 4
     if npb != 1 or pc.mb < 2 or Hout * Wout > 16384:
         return 4
     tx = -(-Wout // 16)
@@ -266,7 +266,7 @@ def _autotune(lib, p, pc, default):
     cands = [default]
     for mb in mbs:
         for npb in (1, 2, 4):
-            for nw in ((4, 9) if (npb == 1 and mb >= 2) else (4,)):
+            for nw in ((4, 9, 2, 8) if npb == 1 else (4,)):
                 for ck in cks:
                     if (npb, nw, ck, mb) not in cands:
                         cands.append((npb, nw, ck, mb))

@@ -73,7 +73,7 @@ typedef struct {
   int store_mode;
   int mb;  /* 16-channel output blocks per workgroup (1, 2 or 4) */
   int npb; /* 16-pixel blocks per wave (1, 2 or 4) */
-  int nw;  /* waves (= 16-pixel tile rows) per workgroup: 0 or 4 (default), or 9 (npb 1, mb >= 2 only) */
+  int nw;  /* waves (= 16-pixel tile rows) per workgroup: 0 or 4 (default), or 2 / 8 / 9 (npb 1 only) */
   int ck;  /* input channels staged per LDS chunk (multiple of 4) */
 } codd_conv_params;
 
