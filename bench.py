@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--tune-db", default=None,
                     help="JSON file of tuned launch configurations: loaded if it exists (no tuning launches, e.g. under "
                          "a profiler), written at the end otherwise")
+    ap.add_argument("--retune", action="store_true", help="ignore the shipped codd_amd/tuned/mi355x.json and time every shape")
     ap.add_argument("--no-autotune", action="store_true",
                     help="use the heuristic conv launch configurations instead of timing the alternatives once per "
                          "layer shape during the (untimed) first frames")
@@ -196,8 +197,13 @@ def main():
 
     from codd_amd import ops as _ops_tune
     _ops_tune.enable_autotune(not args.no_autotune)
+    shipped = os.path.join(os.path.dirname(os.path.abspath(__file__)), "codd_amd", "tuned", "mi355x.json")
     if args.tune_db and os.path.exists(args.tune_db):
         _ops_tune.load_tune_db(args.tune_db)
+    elif not args.tune_db and not args.no_autotune and not args.retune and os.path.exists(shipped):
+        # launch configurations found by the autotuner on an MI355X for the layer shapes of this workload and
+        # committed with the library (like a find-db); shapes it does not know are still timed on the fly
+        _ops_tune.load_tune_db(shipped)
     est = build_model(args, device)
     if args.serial_streams:
         from codd_amd import ops as _ops
