@@ -34,23 +34,54 @@ __global__ __launch_bounds__(256) void instnorm_stats_kernel(const float* __rest
   }
 }
 
-__global__ void instnorm_apply_kernel(const float* __restrict__ x, const double* __restrict__ partial, int parts,
-                                      const float* __restrict__ res, int HW, int relu, float* __restrict__ y) {
+// One workgroup normalises 2048 consecutive elements of one plane (two float4 per thread); the plane's
+// statistics are combined once per workgroup (first wave, fp64 shuffle reduction) instead of once per element.
+__global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __restrict__ x,
+                                                             const double* __restrict__ partial, int parts,
+                                                             const float* __restrict__ res, int HW, int relu,
+                                                             float* __restrict__ y) {
+  __shared__ float st[2];
   const int bc = blockIdx.y;
   const float* p = x + (size_t)bc * HW;
-  double s = 0.0, q = 0.0;
-  for (int i = 0; i < parts; ++i) { s += partial[((size_t)bc * parts + i) * 2]; q += partial[((size_t)bc * parts + i) * 2 + 1]; }
-  const double md = s / HW;                       // mean of (x - K)
-  const double var = fmax(q / HW - md * md, 0.0);  // shift invariant
-  const float mean = (float)((double)p[0] + md);
-  const float rstd = (float)(1.0 / sqrt(var + 1e-5));
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= HW) return;
-  const size_t e = (size_t)bc * HW + i;
-  float v = (x[e] - mean) * rstd;
-  if (res) v += res[e];
-  if (relu) v = fmaxf(v, 0.f);
-  y[e] = v;
+  if (threadIdx.x < 64) {
+    double s = 0.0, q = 0.0;
+    if ((int)threadIdx.x < parts) {
+      s = partial[((size_t)bc * parts + threadIdx.x) * 2];
+      q = partial[((size_t)bc * parts + threadIdx.x) * 2 + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if (threadIdx.x == 0) {
+      const double md = s / HW;                       // mean of (x - K)
+      const double var = fmax(q / HW - md * md, 0.0);  // shift invariant
+      st[0] = (float)((double)p[0] + md);
+      st[1] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+  }
+  __syncthreads();
+  const float mean = st[0], rstd = st[1];
+  const size_t base = (size_t)bc * HW;
+  const bool vec = ((HW & 3) == 0) && (((uintptr_t)x & 15) == 0) && (((uintptr_t)y & 15) == 0) &&
+                   (!res || ((uintptr_t)res & 15) == 0);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = (blockIdx.x * 512 + u * 256 + threadIdx.x) * 4;
+    if (i >= HW) continue;
+    if (vec) {
+      float4 v = *(const float4*)(x + base + i);
+      v.x = (v.x - mean) * rstd; v.y = (v.y - mean) * rstd; v.z = (v.z - mean) * rstd; v.w = (v.w - mean) * rstd;
+      if (res) { const float4 r = *(const float4*)(res + base + i); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *(float4*)(y + base + i) = v;
+    } else {
+      for (int c = 0; c < 4 && i + c < HW; ++c) {
+        float v = (x[base + i + c] - mean) * rstd;
+        if (res) v += res[base + i + c];
+        if (relu) v = fmaxf(v, 0.f);
+        y[base + i + c] = v;
+      }
+    }
+  }
 }
 
 extern "C" int codd_instnorm(const float* x, int B, int C, int HW, float* stats, const float* res, int relu,
@@ -63,7 +94,7 @@ extern "C" int codd_instnorm(const float* x, int B, int C, int HW, float* stats,
   double* partial = (double*)stats;
   instnorm_stats_kernel<<<dim3(parts, B * C), 256, 0, s>>>(x, HW, parts, partial);
   CODD_LAUNCH_CHECK();
-  instnorm_apply_kernel<<<dim3(cdiv(HW, 256), B * C), 256, 0, s>>>(x, partial, parts, res, HW, relu, y);
+  instnorm_apply_kernel<<<dim3(cdiv(HW, 2048), B * C), 256, 0, s>>>(x, partial, parts, res, HW, relu, y);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }
