@@ -26,7 +26,7 @@ for mode in ("serial", "default"):
     with open(os.path.join(DST, f"r01_final_kernel_stats_{mode}.md"), "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats: round 1, final kernels, {'serial streams' if mode == 'serial' else 'default schedule (side streams ON)'}\n\n")
         f.write(f"Command (tools/profile_round.sh): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --tune-db <db>{' --serial-streams' if mode == 'serial' else ''}` "
-                f"({frames:.0f} frames: 1 priming + 150 pre-warm + 5 warm-up + 60 timed + 1 eager roofline frame; launch configurations from the tune db of an un-profiled run, so no tuning launches are in the statistics).\n\n")
+                f"({frames:.0f} frames: 1 priming + 150 pre-warm + 5 warm-up + 60 timed + 1 eager roofline frame; launch configurations = the shipped codd_amd/tuned/mi355x.json, so no tuning launches are in the statistics).\n\n")
         f.write(f"bench.py under the profiler: {b.get('value')} frames/s, {b.get('ms_per_step')} ms/step (the profiler slows the run and inflates bench.py's own event brackets: "
                 f"conv_ms_per_frame {(b.get('roofline') or {}).get('conv_ms_per_frame')} here; the same command WITHOUT the profiler measures 22.97 ms with its HIP events, "
                 "within 2 % of the kernel durations below).\n\n")

@@ -4,8 +4,8 @@
 # the committed summaries under profiles/.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_final; mkdir -p $OUT
-rm -f $OUT/tune_db.json
-python $R/bench.py --no-cpu-baseline --tune-db $OUT/tune_db.json > $OUT/bench_plain.log 2>&1   # un-profiled: tunes, writes the db
+cp $R/codd_amd/tuned/mi355x.json $OUT/tune_db.json   # the shipped launch configurations (what bench.py runs by default)
+python $R/bench.py --no-cpu-baseline --tune-db $OUT/tune_db.json > $OUT/bench_plain.log 2>&1   # un-profiled reference run
 for mode in serial default; do
   flag=""; [ $mode = serial ] && flag="--serial-streams"
   rm -rf /tmp/st_$mode
