@@ -167,8 +167,16 @@ extern "C" int codd_conv2d(const codd_conv_params* pp, void* stream) {
 // ------------------------------------------------------------------------------------------------
 extern "C" int codd_avgpool2(const float* in, int BC, int h, int w, float* out, void* stream);
 
-#define CORR_MB 4
-#define CORR_CK 32
+static int corr_mb() {  // 16-channel blocks per workgroup of the all-pairs GEMM (dev override: CODD_CORR_MB)
+  static const int v = getenv("CODD_CORR_MB") ? atoi(getenv("CODD_CORR_MB")) : 4;
+  return v;
+}
+#define CORR_MB corr_mb()
+static int corr_ck() {  // chunk depth of the all-pairs GEMM (dev override: CODD_CORR_CK)
+  static const int v = getenv("CODD_CORR_CK") ? atoi(getenv("CODD_CORR_CK")) : 32;
+  return v;
+}
+#define CORR_CK corr_ck()
 extern "C" long long codd_allpairs_corr_scratch(int B, int D, int h, int w) {
   long long packed = codd_conv2d_packed_size(h * w, D, 1, 1, CORR_MB, CORR_CK);
   long long pooled = 0;
@@ -211,7 +219,13 @@ extern "C" int codd_allpairs_corr(const float* f1, const float* f2, int B, int D
       p.Cout = N; p.Hout = hh; p.Wout = ww;
       p.kh = p.kw = 1; p.sy = p.sx = 1; p.dil_y = p.dil_x = 1;
       p.act = CODD_ACT_NONE; p.mb = CORR_MB; p.ck = CORR_CK;
-      p.npb = (hh * ww >= 4096) ? 4 : 1;
+      p.npb = 1;  // measured: 4x16-pixel tiles 559 us vs 890 us with 8x32 tiles for the whole pyramid
+      {  // dev overrides for experiments: CODD_CORR_NPB / CODD_CORR_NW (level 0 only)
+        static const int env_npb = getenv("CODD_CORR_NPB") ? atoi(getenv("CODD_CORR_NPB")) : 0;
+        static const int env_nw = getenv("CODD_CORR_NW") ? atoi(getenv("CODD_CORR_NW")) : 0;
+        if (i == 0 && env_npb) p.npb = env_npb;
+        if (i == 0 && env_nw) p.nw = env_nw;
+      }
       int rc = codd_conv2d(&p, stream);
       if (rc) return rc;
     }
