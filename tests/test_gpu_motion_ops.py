@@ -355,7 +355,7 @@ def test_cli_folder_of_frames_writes_disparities(tmp_path):
             Image.fromarray(u8).save(tmp_path / side / "clip7" / ("%04d.png" % f))
     out_dir = tmp_path / "out"
     inference.main(["--img-dir", str(tmp_path / "l"), "--r-img-dir", str(tmp_path / "r"), "--iters", "2", "--show",
-                    "--show-dir", str(out_dir)])
+                    "--show-dir", str(out_dir), "--no-autotune"])
     got = np.load(out_dir / "clip7.disp.pred.npz")["disp"]
     assert got.shape == (MF, h, w) or got.shape == (1, MF, h, w)
     est = build_estimator(configs.codd(iters=2)).to(DEV).eval()

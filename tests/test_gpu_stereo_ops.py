@@ -213,3 +213,36 @@ def test_autotuned_launch_configuration_keeps_results():
     assert len(ops.AUTOTUNE_LOG) == n0 + 1 and len(pc.tuned) == 1
     assert torch.equal(y1, y2)
     assert (y1 - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("shape", [(20, 40, 3, 1, 1, 1, 37, 70), (64, 96, 3, 1, 4, 4, 24, 40), (33, 16, 1, 1, 0, 1, 19, 50),
+                                   (16, 130, 4, 4, 0, 1, 64, 128), (9, 128, 7, 1, 3, 1, 24, 40), (96, 64, 3, 2, 1, 1, 40, 56)])
+def test_every_launch_configuration_the_autotuner_may_pick(shape):
+    """All (npb, nw, ck, mb) candidates of ops._autotune -- every kernel instantiation, including the 2-, 8-
+    and 9-wave workgroups -- against torch's fp32 convolution on ragged shapes."""
+    from codd_amd import _abi, ops
+    cin, cout, k, s, p, d, H, W = shape
+    x, w, b = rnd(1, cin, H, W), rnd(cout, cin, k, k, seed=1) / (cin * k * k) ** 0.5, rnd(cout, seed=2) * 0.1
+    ref = F.conv2d(x, w, b, stride=s, padding=p, dilation=d)
+    xd = x.to("cuda")
+    pc = ops.PackedConv(w.to("cuda"), b.to("cuda"))
+    key = (ref.shape[2], ref.shape[3], 1, s, s, d, d, p, False)
+    cin_pad = -(-cin // 4) * 4
+    cks = sorted({c for c in (8, 12, 16, 24, 32) if c <= cin_pad} | {min(cin_pad, 32)})
+    tried = 0
+    for mb in (1, 2, 4):
+        if 16 * mb > max(16, -(-cout // 16) * 16):
+            continue
+        for npb in (1, 2, 4):
+            for nw in ((4, 9, 2, 8) if npb == 1 else (4,)):
+                for ck in cks:
+                    pc.tuned[key] = (npb, nw, ck, mb)
+                    try:
+                        y = ops.conv2d(xd, pc, stride=s, pad=p, dil=d)
+                    except _abi.CoddHipError as e:
+                        assert "-2" in str(e), e  # CODD_EUNSUPPORTED (staging / LDS limits) is the only allowed refusal
+                        continue
+                    tried += 1
+                    err = (y.cpu() - ref).abs().max().item()
+                    assert err < 2e-5 * max(1.0, ref.abs().max().item()), ((npb, nw, ck, mb), err)
+    assert tried >= 3
