@@ -1,6 +1,7 @@
 // Motion / RAFT3D non-convolution kernels (fp32, HBM / LDS / VALU bound; the only MFMA use is the
 // all-pairs correlation, which is routed through the conv family as a 1x1 convolution).
 #include "common.h"
+#include <stdlib.h>
 #include "se3.h"
 
 #define MIN_DEPTH 0.05f  // reference projective_ops.py:7
@@ -455,7 +456,8 @@ __global__ __launch_bounds__(64) void se3_gn_solve_kernel(float* __restrict__ T,
 }
 
 static inline int gn_rowgroups(int ntiles, int NC) {
-  int R = 3072 / (ntiles > 0 ? ntiles : 1);  // ~3 waves per SIMD on 256 CUs
+  static const int tasks = getenv("CODD_GN_TASKS") ? atoi(getenv("CODD_GN_TASKS")) : 4096;  // dev override; 4096: 190 us, 3072: 216 us, 2048: 243 us
+  int R = tasks / (ntiles > 0 ? ntiles : 1);  // ~4 waves per SIMD on 256 CUs
   if (R < 1) R = 1;
   if (R > NC) R = NC;
   return R;
