@@ -65,6 +65,7 @@ SIGNATURES = {
     "codd_fusion_cues_lr": (_i, [_p] * 6 + [_i] * 5 + [_p, _p, _i, _i, _p]),
     "codd_fusion_cues_fr": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "codd_disp_metrics": (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p]),
+    "codd_raft_geometry_lookup": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p]),
     "codd_fusion_select": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p]),
     "codd_gt_motion": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "codd_tepe_metrics": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p]),

@@ -1,6 +1,7 @@
 // Motion / RAFT3D non-convolution kernels (fp32, HBM / LDS / VALU bound; the only MFMA use is the
 // all-pairs correlation, which is routed through the conv family as a 1x1 convolution).
 #include "common.h"
+#include <string.h>
 #include <stdlib.h>
 #include "se3.h"
 
@@ -129,10 +130,22 @@ extern "C" int codd_avgpool2(const float* in, int BC, int h, int w, float* out, 
 // window of one pixel (lane = ty*8 + tx), forms the 7x7 bilinear outputs with lane shuffles, and the
 // [49][16] result tile is written out through LDS as 64-byte runs.
 // ------------------------------------------------------------------------------------------------
+struct LookupGeom {  // coords == NULL: the projected coordinates are computed here (fused geometry)
+  const float *T, *d1, *d2;
+  float fx, fy, cx, cy;
+  float *xyz, *minfo;
+};
+__device__ __forceinline__ V3 inv_project(float depth, int x, int y, float fx, float fy, float cx, float cy);
+__device__ __forceinline__ V3 project(V3 X, float fx, float fy, float cx, float cy);
+__device__ __forceinline__ void raft_geometry_pixel(const float* __restrict__ T, const float* __restrict__ d1,
+                                                    const float* __restrict__ d2, int b, int pix, int h, int w,
+                                                    float fx, float fy, float cx, float cy, float* __restrict__ xyz,
+                                                    float* __restrict__ minfo);
+
 __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restrict__ l0, const float* __restrict__ l1,
                                                           const float* __restrict__ l2, const float* __restrict__ l3,
                                                           const float* __restrict__ coords, int cstride, int h, int w,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, const LookupGeom gm) {
   __shared__ float tile[49][17];
   const int lvl = blockIdx.y, b = blockIdx.z;
   const int N = h * w;
@@ -145,8 +158,18 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
   for (int q = 0; q < 4; ++q) {
     const int pi = wave * 4 + q, n = n0 + pi;
     if (n >= N) break;
-    const float* cp = coords + ((size_t)b * N + n) * cstride;
-    const float x0 = cp[0] * inv, y0 = cp[1] * inv;
+    float px, py;
+    if (coords) {
+      const float* cp = coords + ((size_t)b * N + n) * cstride;
+      px = cp[0]; py = cp[1];
+    } else {  // every lane recomputes the projection of its wave's pixel (reference raft3d.py:225-227)
+      const int yy = n / w, xx = n - yy * w;
+      const SE3T Ti = se3_load(gm.T + ((size_t)b * N + n) * 7);
+      const V3 pp = project(se3_act(Ti, inv_project(gm.d1[(size_t)b * N + n], xx, yy, gm.fx, gm.fy, gm.cx, gm.cy)), gm.fx,
+                            gm.fy, gm.cx, gm.cy);
+      px = pp.x; py = pp.y;
+    }
+    const float x0 = px * inv, y0 = py * inv;
     float fx = floorf(x0), fy = floorf(y0);
     const float dx = x0 - fx, dy = y0 - fy;
     // keep the int conversion defined for wild coordinates; everything is out of range then
@@ -162,6 +185,9 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
       tile[tx * 7 + ty][pi] = r;  // channel = i*7 + j, i = x offset, j = y offset
     }
   }
+  // fused geometry: the level-0 workgroups also publish xyz and the motion-info channels of their 16 pixels
+  if (!coords && lvl == 0 && tid < 16 && n0 + tid < N)
+    raft_geometry_pixel(gm.T, gm.d1, gm.d2, b, n0 + tid, h, w, gm.fx, gm.fy, gm.cx, gm.cy, gm.xyz, gm.minfo);
   __syncthreads();
   for (int e = tid; e < 49 * 16; e += 256) {
     const int ch = e >> 4, pi = e & 15, n = n0 + pi;
@@ -173,7 +199,21 @@ extern "C" int codd_corr_lookup(const float* lvl0, const float* lvl1, const floa
                                 const float* coords, int cstride, int B, int h, int w, float* out, void* stream) {
   if (!lvl0 || !lvl1 || !lvl2 || !lvl3 || !coords || !out || cstride < 2) return CODD_EINVAL;
   dim3 grid(cdiv(h * w, 16), 4, B);
-  corr_lookup_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(lvl0, lvl1, lvl2, lvl3, coords, cstride, h, w, out);
+  LookupGeom gm;
+  memset(&gm, 0, sizeof(gm));
+  corr_lookup_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(lvl0, lvl1, lvl2, lvl3, coords, cstride, h, w, out, gm);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+extern "C" int codd_raft_geometry_lookup(const float* T, const float* depth1, const float* depth2, const float* lvl0,
+                                         const float* lvl1, const float* lvl2, const float* lvl3, int B, int h, int w,
+                                         float fx, float fy, float cx, float cy, float* xyz, float* minfo, float* out,
+                                         void* stream) {
+  if (!T || !depth1 || !depth2 || !lvl0 || !lvl1 || !lvl2 || !lvl3 || !xyz || !minfo || !out) return CODD_EINVAL;
+  LookupGeom gm = {T, depth1, depth2, fx, fy, cx, cy, xyz, minfo};
+  dim3 grid(cdiv(h * w, 16), 4, B);
+  corr_lookup_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(lvl0, lvl1, lvl2, lvl3, nullptr, 0, h, w, out, gm);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }
@@ -189,13 +229,12 @@ __device__ __forceinline__ V3 project(V3 X, float fx, float fy, float cx, float 
   return V3{fx * (X.x / Z) + cx, fy * (X.y / Z) + cy, 1.f / Z};
 }
 
-__global__ void raft_geometry_kernel(const float* __restrict__ T, const float* __restrict__ d1,
-                                     const float* __restrict__ d2, int B, int h, int w, float fx, float fy, float cx,
-                                     float cy, float* __restrict__ xyz, float* __restrict__ minfo) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  const int N = h * w;
-  if (n >= B * N) return;
-  const int b = n / N, pix = n - b * N, y = pix / w, x = pix - y * w;
+// full per-pixel geometry of pixel n (batch b): writes xyz[n] and the 9 motion-info channels
+__device__ __forceinline__ void raft_geometry_pixel(const float* __restrict__ T, const float* __restrict__ d1,
+                                                    const float* __restrict__ d2, int b, int pix, int h, int w,
+                                                    float fx, float fy, float cx, float cy, float* __restrict__ xyz,
+                                                    float* __restrict__ minfo) {
+  const int N = h * w, n = b * N + pix, y = pix / w, x = pix - y * w;
   const SE3T Ti = se3_load(T + (size_t)n * 7);
   const V3 X1 = se3_act(Ti, inv_project(d1[n], x, y, fx, fy, cx, cy));
   const V3 p = project(X1, fx, fy, cx, cy);
@@ -224,6 +263,15 @@ __global__ void raft_geometry_kernel(const float* __restrict__ T, const float* _
   float* mp = minfo + (size_t)b * 9 * N + pix;
 #pragma unroll
   for (int c = 0; c < 9; ++c) mp[(size_t)c * N] = fminf(fmaxf(vals[c], -50.f), 50.f);
+}
+
+__global__ void raft_geometry_kernel(const float* __restrict__ T, const float* __restrict__ d1,
+                                     const float* __restrict__ d2, int B, int h, int w, float fx, float fy, float cx,
+                                     float cy, float* __restrict__ xyz, float* __restrict__ minfo) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int N = h * w;
+  if (n >= B * N) return;
+  raft_geometry_pixel(T, d1, d2, n / N, n % N, h, w, fx, fy, cx, cy, xyz, minfo);
 }
 
 extern "C" int codd_raft_geometry(const float* T, const float* depth1, const float* depth2, int B, int h, int w,

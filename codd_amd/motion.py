@@ -239,8 +239,7 @@ class RAFT3D(nn.Module):
         d2 = depth_curr[:, 3::8, 3::8].contiguous()
         mask = weight = zr = None
         for it in range(iters):
-            xyz, minfo = ops.raft_geometry(T, d1, d2, K8)
-            corr = ops.corr_lookup(pyr, xyz, h, w)
+            xyz, minfo, corr = ops.raft_geometry_lookup(T, d1, d2, K8, pyr)  # projection + pyramid lookup, one launch
             net, mask, ae, delta, weight, zr = self.update_block.run(net, inp, corr, minfo, need_mask=it == iters - 1,
                                                                      zr=zr, prefetch_next=it < iters - 1)
             ops.se3_gn_step(T, ae, xyz, delta, weight, d1, K8, radius=32)

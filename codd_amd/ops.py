@@ -405,6 +405,18 @@ def raft_geometry(T, d1, d2, K8):
     return xyz, minfo
 
 
+def raft_geometry_lookup(T, d1, d2, K8, pyr):
+    """raft_geometry + corr_lookup in one launch -> (xyz [B,h,w,3], minfo [B,9,h,w], corr [B,196,h,w])."""
+    lib = _abi.load()
+    B, h, w, _ = T.shape
+    xyz, minfo, out = _f32(B, h, w, 3, like=T), _f32(B, 9, h, w, like=T), _f32(B, 196, h, w, like=T)
+    _abi.check(lib.codd_raft_geometry_lookup(T.data_ptr(), d1.data_ptr(), d2.data_ptr(), pyr[0].data_ptr(),
+                                             pyr[1].data_ptr(), pyr[2].data_ptr(), pyr[3].data_ptr(), B, h, w, *K8,
+                                             xyz.data_ptr(), minfo.data_ptr(), out.data_ptr(), _stream()),
+               "raft_geometry_lookup")
+    return xyz, minfo, out
+
+
 def se3_gn_step(T, ae, xyz, delta, weight, d1, K8, radius=32, lm=1e-4, ep=10.0):
     """In-place Gauss-Newton update of the SE3 field T [B,h,w,7]."""
     lib = _abi.load()

@@ -276,6 +276,13 @@ int codd_gt_motion(const float* img_prev, const float* disp_prev, const float* f
                    int B, int H, int W, int hg, int wg, float* img_warp, float* feat_warp, float* conf,
                    float* disp_warp, float* flow3, void* stream);
 
+/* codd_raft_geometry + codd_corr_lookup in one launch (the lookup workgroups project their own pixels; the
+ * level-0 workgroups also write xyz [B,h,w,3] and minfo [B,9,h,w]).  Same results as the two separate calls. */
+int codd_raft_geometry_lookup(const float* T, const float* depth1, const float* depth2, const float* lvl0,
+                              const float* lvl1, const float* lvl2, const float* lvl3, int B, int h, int w,
+                              float fx, float fy, float cx, float cy, float* xyz, float* minfo, float* out,
+                              void* stream);
+
 int codd_abi_version(void);
 
 #ifdef __cplusplus

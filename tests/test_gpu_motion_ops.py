@@ -455,3 +455,22 @@ def test_pipelined_runner_equals_frame_runner(use_graph):
     torch.cuda.synchronize()
     for f in range(MF):
         assert torch.equal(got[f], ref[f]), (f, (got[f] - ref[f]).abs().max().item())
+
+
+def test_fused_geometry_lookup_equals_separate_kernels():
+    from codd_amd import ops
+    h, w = 24, 40
+    T = ops.se3_identity(1, h, w, DEV)
+    T[..., :3] = rnd(1, h, w, 3, seed=3).to(DEV) * 0.05
+    q = rnd(1, h, w, 4, seed=4).to(DEV) * 0.05
+    q[..., 3] = 1.0
+    T[..., 3:] = q / q.norm(dim=-1, keepdim=True)
+    d1 = (rnd(1, h, w, seed=5).abs() * 5 + 2).to(DEV)
+    d2 = (rnd(1, h, w, seed=6).abs() * 5 + 2).to(DEV)
+    pyr = ops.allpairs_corr(rnd(1, 128, h, w, seed=7).to(DEV), rnd(1, 128, h, w, seed=8).to(DEV))
+    K8 = [30.0, 32.0, 20.0, 12.0]
+    xyz, minfo = ops.raft_geometry(T, d1, d2, K8)
+    corr = ops.corr_lookup(pyr, xyz, h, w)
+    xyz2, minfo2, corr2 = ops.raft_geometry_lookup(T, d1, d2, K8, pyr)
+    assert torch.equal(xyz, xyz2) and torch.equal(minfo, minfo2)
+    assert (corr - corr2).abs().max().item() < 1e-5 * max(1.0, corr.abs().max().item())
