@@ -228,7 +228,18 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
         npb, nw, ck, mb = pc.tuned[key] = TUNE_DB[sig] = _autotune(lib, p, pc, (npb, nw, ck, mb))
         p.wpacked = pc.packed(ck, mb).data_ptr()
         p.mb, p.npb, p.nw, p.ck = mb, npb, nw, ck
-    _abi.check(_launch_conv(lib, p, _stream()), "codd_conv2d")
+    rc = _launch_conv(lib, p, _stream())
+    if rc == -2 and not tune:
+        # a tuned / loaded configuration this build does not support (e.g. a tune db from another version):
+        # fall back to the heuristic for this launch shape, loudly
+        import warnings
+        warnings.warn("codd_amd: launch configuration %s rejected for conv %dx%d %d->%d, using the heuristic" % (
+            (npb, nw, ck, mb), pc.kh, pc.kw, pc.cin, pc.cout))
+        npb, nw, ck = pc.tuned[key] = _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl)
+        p.wpacked = pc.packed(ck, pc.mb).data_ptr()
+        p.mb, p.npb, p.nw, p.ck = pc.mb, npb, nw, ck
+        rc = _launch_conv(lib, p, _stream())
+    _abi.check(rc, "codd_conv2d")
     return out
 
 

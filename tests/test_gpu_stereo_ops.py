@@ -220,7 +220,8 @@ def test_autotuned_launch_configuration_keeps_results():
 def test_every_launch_configuration_the_autotuner_may_pick(shape):
     """All (npb, nw, ck, mb) candidates of ops._autotune -- every kernel instantiation, including the 2-, 8-
     and 9-wave workgroups -- against torch's fp32 convolution on ragged shapes."""
-    from codd_amd import _abi, ops
+    import warnings
+    from codd_amd import ops
     cin, cout, k, s, p, d, H, W = shape
     x, w, b = rnd(1, cin, H, W), rnd(cout, cin, k, k, seed=1) / (cin * k * k) ** 0.5, rnd(cout, seed=2) * 0.1
     ref = F.conv2d(x, w, b, stride=s, padding=p, dilation=d)
@@ -237,11 +238,11 @@ def test_every_launch_configuration_the_autotuner_may_pick(shape):
             for nw in ((4, 9, 2, 8) if npb == 1 else (4,)):
                 for ck in cks:
                     pc.tuned[key] = (npb, nw, ck, mb)
-                    try:
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
                         y = ops.conv2d(xd, pc, stride=s, pad=p, dil=d)
-                    except _abi.CoddHipError as e:
-                        assert "-2" in str(e), e  # CODD_EUNSUPPORTED (staging / LDS limits) is the only allowed refusal
-                        continue
+                    if tuple(pc.tuned[key]) != (npb, nw, ck, mb):
+                        continue  # CODD_EUNSUPPORTED (staging / LDS limits): ops fell back to the heuristic
                     tried += 1
                     err = (y.cpu() - ref).abs().max().item()
                     assert err < 2e-5 * max(1.0, ref.abs().max().item()), ((npb, nw, ck, mb), err)
