@@ -24,7 +24,7 @@ class ConvParams(C.Structure):
         ("Cout", C.c_int), ("Hout", C.c_int), ("Wout", C.c_int),
         ("kh", C.c_int), ("kw", C.c_int), ("sy", C.c_int), ("sx", C.c_int),
         ("pad_t", C.c_int), ("pad_l", C.c_int), ("dil_y", C.c_int), ("dil_x", C.c_int),
-        ("act", C.c_int), ("store_mode", C.c_int), ("mb", C.c_int), ("npb", C.c_int), ("nw", C.c_int), ("ck", C.c_int),
+        ("act", C.c_int), ("store_mode", C.c_int), ("mb", C.c_int), ("npb", C.c_int), ("nw", C.c_int), ("ck", C.c_int), ("layout", C.c_int),
     ]
 
 
@@ -66,6 +66,8 @@ SIGNATURES = {
     "codd_fusion_cues_fr": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "codd_disp_metrics": (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p]),
     "codd_raft_geometry_lookup": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p]),
+    "codd_conv2d_packed_size_quad": (C.c_longlong, [_i, _i, _i, _i, _i, _i]),
+    "codd_conv2d_pack_weights_quad": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "codd_fusion_select": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p]),
     "codd_gt_motion": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "codd_tepe_metrics": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p]),

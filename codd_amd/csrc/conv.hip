@@ -12,11 +12,12 @@
 // channels and the matching weight chunk are staged in LDS per chunk; channel stride of the
 // LDS image is padded to 16 (mod 32) floats so that the two ci-groups of a 32-lane half hit
 // disjoint banks.
-#include "conv_kernel.h"
+#include "conv_quad_kernel.h"
 #include <stdio.h>
 #include <stdlib.h>
 
 CONV_ALL_GROUPS(CONV_DECLARE)
+CONVQ_ALL(CONVQ_DECLARE)
 
 
 __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int ntaps,
@@ -34,6 +35,37 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict_
   float v = 0.f;
   if (col < 16 * mb && co < Cout && ci < Cin) v = w[(size_t)co * co_stride + (size_t)ci * ci_stride + tap] * scale;
   wp[e] = v;
+}
+
+// quad layout: [cog][chunk][tap][cq = c/4][co (16*mb)][4]
+__global__ void conv_pack_quad_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int ntaps,
+                                      int mb, int ck, int nchunks, long long total) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int q = (int)(e & 3);
+  long long t = e >> 2;
+  const int col = (int)(t % (16 * mb)); t /= 16 * mb;
+  const int cq = (int)(t % (ck >> 2)); t /= ck >> 2;
+  const int tap = (int)(t % ntaps); t /= ntaps;
+  const int chunk = (int)(t % nchunks);
+  const int cog = (int)(t / nchunks);
+  const int co = cog * 16 * mb + col, ci = chunk * ck + 4 * cq + q;
+  wp[e] = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * ntaps + tap] : 0.f;
+}
+
+extern "C" long long codd_conv2d_packed_size_quad(int Cout, int Cin, int kh, int kw, int mb, int ck) {
+  if (mb < 1 || !(ck == 16 || ck == 32)) return -1;
+  return (long long)cdiv(Cout, 16 * mb) * cdiv(Cin, ck) * (kh * kw) * ck * 16 * mb;
+}
+
+extern "C" int codd_conv2d_pack_weights_quad(const float* w, float* wpacked, int Cout, int Cin, int kh, int kw, int mb,
+                                             int ck, void* stream) {
+  const long long total = codd_conv2d_packed_size_quad(Cout, Cin, kh, kw, mb, ck);
+  if (total <= 0 || !w || !wpacked) return CODD_EINVAL;
+  conv_pack_quad_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(w, wpacked, Cout, Cin, kh * kw, mb, ck,
+                                                                           cdiv(Cin, ck), total);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
 }
 
 static inline int wrow_of(int mb) { return 16 * mb + ((mb & 1) ? 0 : 16); }
@@ -105,6 +137,30 @@ static int launch_conv_nwx(const ConvK& k, size_t lds, int grid, hipStream_t s) 
   return CODD_EUNSUPPORTED;
 }
 
+template <int NW, int NPB, int MB, int WREG, int QREG>
+static int launch_quad(const ConvK& k, size_t lds, int grid, hipStream_t s) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_quad_kernel<NW, NPB, MB, WREG, QREG>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  conv_quad_kernel<NW, NPB, MB, WREG, QREG><<<grid, NW * 64, lds, s>>>(k);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+// quad-layout dispatch: wr / qr = float4 of weights / quad units of input per thread and chunk
+static int launch_quad_any(const ConvK& k, int nw, size_t lds, int grid, hipStream_t s) {
+  const codd_conv_params& p = k.p;
+  const int nt = nw * 64, wr = cdiv(k.wchunk >> 2, nt), qr = cdiv((p.ck >> 2) * k.upc, nt);
+#define Q(W, N, M, R, QQ) if (nw == W && p.npb == N && p.mb == M && wr <= R && qr <= QQ) return launch_quad<W, N, M, R, QQ>(k, lds, grid, s);
+  Q(4, 1, 2, 8, 1) Q(4, 1, 2, 16, 2) Q(4, 1, 4, 12, 1) Q(4, 1, 4, 16, 2)
+  Q(4, 2, 2, 8, 2) Q(4, 2, 2, 16, 2) Q(4, 2, 4, 12, 2) Q(4, 2, 4, 16, 2)
+  Q(9, 1, 2, 8, 1) Q(9, 1, 4, 8, 1) Q(9, 1, 4, 16, 1)
+#undef Q
+  return CODD_EUNSUPPORTED;
+}
+
 /* staging limits the host heuristics must respect: <= 16 float4 of weights and <= 8 float4 of input
  * per thread and chunk (codd_conv2d returns CODD_EUNSUPPORTED otherwise) */
 extern "C" int codd_conv2d(const codd_conv_params* pp, void* stream) {
@@ -145,10 +201,18 @@ extern "C" int codd_conv2d(const codd_conv_params* pp, void* stream) {
   k.vec_ok = (p.Win % 4 == 0) && ((uintptr_t)p.in0.ptr % 16 == 0) && (hwb % 16 == 0) &&
              (p.C1 == 0 || (uintptr_t)p.in1.ptr % 16 == 0);
   size_t lds = ((size_t)k.wchunk + (size_t)p.ck * k.chs) * sizeof(float);
+  if (p.layout == 1) {  // quad layout: unpadded weights, input tile [cq][y][x][4]
+    if (!(p.ck == 16 || p.ck == 32) || p.sx != 1 || !k.vec_ok || (p.npb != 1 && p.npb != 2)) return CODD_EUNSUPPORTED;
+    k.wchunk = k.ntaps * p.ck * 16 * p.mb;
+    lds = ((size_t)k.wchunk + (size_t)p.ck * k.thi * k.twp) * sizeof(float);
+  } else if (p.layout != 0) {
+    return CODD_EINVAL;
+  }
   if (lds > 160 * 1024) return CODD_EUNSUPPORTED;
   long long grid = (long long)k.tiles_x * k.tiles_y * k.ncog * p.B;
   if (grid <= 0 || grid > 0x7fffffffLL) return CODD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  if (p.layout == 1) return launch_quad_any(k, nw, lds, (int)grid, s);
 #define CASEW(W, M) if (nw == W && p.mb == M) return launch_conv_nwx<W, M>(k, lds, (int)grid, s)
   CASEW(9, 1); CASEW(9, 2); CASEW(9, 4); CASEW(2, 1); CASEW(2, 2); CASEW(2, 4); CASEW(8, 1); CASEW(8, 2); CASEW(8, 4);
 #undef CASEW

@@ -78,20 +78,27 @@ class PackedConv:
         self._packs = {}
         self.tuned = {}  # launch shape -> (npb, nw, ck)
 
-    def packed(self, ck, mb=None):
+    def packed(self, ck, mb=None, layout=0):
         mb = self.mb if mb is None else mb
-        if (mb, ck) not in self._packs:
+        if (mb, ck, layout) not in self._packs:
             lib = _abi.load()
-            n = lib.codd_conv2d_packed_size(self.cout_eff, self.cin, self.kh, self.kw, mb, ck)
+            size, pack = ((lib.codd_conv2d_packed_size_quad, lib.codd_conv2d_pack_weights_quad) if layout == 1 else
+                          (lib.codd_conv2d_packed_size, lib.codd_conv2d_pack_weights))
+            n = size(self.cout_eff, self.cin, self.kh, self.kw, mb, ck)
+            if n <= 0:
+                raise _abi.CoddHipError("no packed layout %d for ck=%d mb=%d" % (layout, ck, mb))
             wp = torch.empty(n, device=self._w.device, dtype=torch.float32)
-            _abi.check(lib.codd_conv2d_pack_weights(self._w.data_ptr(), wp.data_ptr(), self.cout_eff, self.cin,
-                                                    self.kh, self.kw, mb, ck, _stream()), "pack_weights")
-            self._packs[(mb, ck)] = wp
-        return self._packs[(mb, ck)]
+            _abi.check(pack(self._w.data_ptr(), wp.data_ptr(), self.cout_eff, self.cin, self.kh, self.kw, mb, ck,
+                            _stream()), "pack_weights")
+            self._packs[(mb, ck, layout)] = wp
+        return self._packs[(mb, ck, layout)]
+
+    def _pack_key(self, c):
+        return (c[3] if len(c) > 3 else self.mb, c[2], c[4] if len(c) > 4 else 0)
 
     def drop_unused_packs(self):
         """Free the packed-weight variants no tuned configuration refers to (after autotuning)."""
-        used = {(c[3] if len(c) > 3 else self.mb, c[2]) for c in self.tuned.values()}
+        used = {self._pack_key(c) for c in self.tuned.values()}
         for k in [k for k in self._packs if k not in used]:
             del self._packs[k]
 
@@ -211,11 +218,12 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
                 pc.tuned[key] = cfg  # (while capturing with autotune on: heuristic for this launch, tune later)
     npb, nw, ck = cfg[:3]
     mb = cfg[3] if len(cfg) > 3 else pc.mb
+    layout = cfg[4] if len(cfg) > 4 else 0
     p = ConvParams()
     p.in0 = _view(xs)
     p.in1 = _view(x2)
     p.C0, p.C1, p.B, p.Hin, p.Win = C0, C1, B, Hin, Win
-    p.wpacked = pc.packed(ck, mb).data_ptr()
+    p.wpacked = pc.packed(ck, mb, layout).data_ptr()
     p.bias = None if pc.bias is None else pc.bias.data_ptr()
     p.res1, p.res2, p.post = _view(res1), _view(res2), _view(post)
     p.out, p.out_ctot, p.out_coff = os_.buf.data_ptr(), os_.buf.shape[1], os_.coff
@@ -223,21 +231,21 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
     p.kh, p.kw, p.sy, p.sx, p.pad_t, p.pad_l, p.dil_y, p.dil_x = pc.kh, pc.kw, sy, sx, pt, pl, dy, dx
     p.act = ACT[act]
     p.store_mode = 1 if pc.deconv else 0
-    p.mb, p.npb, p.nw, p.ck = mb, npb, nw, ck
+    p.mb, p.npb, p.nw, p.ck, p.layout = mb, npb, nw, ck, layout
     if tune:
-        npb, nw, ck, mb = pc.tuned[key] = TUNE_DB[sig] = _autotune(lib, p, pc, (npb, nw, ck, mb))
-        p.wpacked = pc.packed(ck, mb).data_ptr()
-        p.mb, p.npb, p.nw, p.ck = mb, npb, nw, ck
+        npb, nw, ck, mb, layout = pc.tuned[key] = TUNE_DB[sig] = _autotune(lib, p, pc, (npb, nw, ck, mb, layout))
+        p.wpacked = pc.packed(ck, mb, layout).data_ptr()
+        p.mb, p.npb, p.nw, p.ck, p.layout = mb, npb, nw, ck, layout
     rc = _launch_conv(lib, p, _stream())
     if rc == -2 and not tune:
         # a tuned / loaded configuration this build does not support (e.g. a tune db from another version):
         # fall back to the heuristic for this launch shape, loudly
         import warnings
         warnings.warn("codd_amd: launch configuration %s rejected for conv %dx%d %d->%d, using the heuristic" % (
-            (npb, nw, ck, mb), pc.kh, pc.kw, pc.cin, pc.cout))
+            (npb, nw, ck, mb, layout), pc.kh, pc.kw, pc.cin, pc.cout))
         npb, nw, ck = pc.tuned[key] = _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl)
-        p.wpacked = pc.packed(ck, pc.mb).data_ptr()
-        p.mb, p.npb, p.nw, p.ck = pc.mb, npb, nw, ck
+        p.wpacked = pc.packed(ck, pc.mb, 0).data_ptr()
+        p.mb, p.npb, p.nw, p.ck, p.layout = pc.mb, npb, nw, ck, 0
         rc = _launch_conv(lib, p, _stream())
     _abi.check(rc, "codd_conv2d")
     return out
@@ -282,17 +290,23 @@ def _autotune(lib, p, pc, default):
         for npb in (1, 2, 4):
             for nw in ((4, 9, 2, 8) if npb == 1 else (4,)):
                 for ck in cks:
-                    if (npb, nw, ck, mb) not in cands:
-                        cands.append((npb, nw, ck, mb))
+                    if (npb, nw, ck, mb, 0) not in cands:
+                        cands.append((npb, nw, ck, mb, 0))
+    if p.sx == 1 and cin_pad >= 16:  # quad layout (ds_read_b128 operands): ck 16 / 32, 4- and 9-wave workgroups
+        for mb in [m for m in mbs if m >= 2]:
+            for npb, nw in ((1, 4), (2, 4), (1, 9)):
+                for ck in (16, 32):
+                    if ck <= max(16, cin_pad):
+                        cands.append((npb, nw, ck, mb, 1))
     stream = _stream()
     torch.cuda.synchronize()  # nothing else on the device while the candidates are timed
     best, best_t, t_default = default, float("inf"), None
-    for (npb, nw, ck, mb) in [default] + cands:  # the heuristic is timed twice (first = warm-up of clocks / caches)
+    for (npb, nw, ck, mb, layout) in [default] + cands:  # the heuristic is timed twice (first = warm-up of clocks / caches)
         try:
-            p.wpacked = pc.packed(ck, mb).data_ptr()
+            p.wpacked = pc.packed(ck, mb, layout).data_ptr()
         except Exception:
             continue
-        p.mb, p.npb, p.nw, p.ck = mb, npb, nw, ck
+        p.mb, p.npb, p.nw, p.ck, p.layout = mb, npb, nw, ck, layout
         if _launch_conv(lib, p, stream) != 0:  # not instantiated / LDS or staging limits: skip
             continue
         t = float("inf")
@@ -304,14 +318,14 @@ def _autotune(lib, p, pc, default):
             e.record()
             e.synchronize()
             t = min(t, s.elapsed_time(e) / 3.0)
-        if (npb, nw, ck, mb) == default:
+        if (npb, nw, ck, mb, layout) == default:
             if t_default is None:
                 t_default = t
                 continue  # warm-up pass
             t_default = t
         if t < best_t * 0.97 or best_t == float("inf"):  # 3 % hysteresis: earlier (heuristic-first) candidates win ties
-            best, best_t = (npb, nw, ck, mb), t
-    used = {(c[3] if len(c) > 3 else pc.mb, c[2]) for c in pc.tuned.values()} | {(best[3], best[2])}
+            best, best_t = (npb, nw, ck, mb, layout), t
+    used = {pc._pack_key(c) for c in pc.tuned.values()} | {pc._pack_key(best)}
     for k in [k for k in pc._packs if k not in used]:
         del pc._packs[k]  # packed-weight variants of the losing candidates
     AUTOTUNE_LOG.append(("%dx%d k%dx%d %d->%d out %dx%d" % (p.sy, p.sx, pc.kh, pc.kw, pc.cin, pc.cout, p.Hout, p.Wout),

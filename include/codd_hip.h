@@ -75,9 +75,16 @@ typedef struct {
   int npb; /* 16-pixel blocks per wave (1, 2 or 4) */
   int nw;  /* waves (= 16-pixel tile rows) per workgroup: 0 or 4 (default), or 2 / 8 / 9 (npb 1 only) */
   int ck;  /* input channels staged per LDS chunk (multiple of 4) */
+  int layout; /* 0: weights packed by codd_conv2d_pack_weights; 1: quad layout (codd_conv2d_pack_weights_quad;
+                 ck 16 or 32, unit x-stride, 16-byte aligned rows, npb 1 or 2) */
 } codd_conv_params;
 
 int codd_conv2d(const codd_conv_params* p, void* stream);
+
+/* quad layout (layout = 1): four input channels innermost, [cog][chunk][tap][c/4][co][4] */
+long long codd_conv2d_packed_size_quad(int Cout, int Cin, int kh, int kw, int mb, int ck);
+int codd_conv2d_pack_weights_quad(const float* w, float* wpacked, int Cout, int Cin, int kh, int kw, int mb,
+                                  int ck, void* stream);
 
 /* number of floats of the packed weight buffer for (Cout, Cin, kh, kw, mb, ck) */
 long long codd_conv2d_packed_size(int Cout, int Cin, int kh, int kw, int mb, int ck);

@@ -216,7 +216,8 @@ def test_autotuned_launch_configuration_keeps_results():
 
 
 @pytest.mark.parametrize("shape", [(20, 40, 3, 1, 1, 1, 37, 70), (64, 96, 3, 1, 4, 4, 24, 40), (33, 16, 1, 1, 0, 1, 19, 50),
-                                   (16, 130, 4, 4, 0, 1, 64, 128), (9, 128, 7, 1, 3, 1, 24, 40), (96, 64, 3, 2, 1, 1, 40, 56)])
+                                   (16, 130, 4, 4, 0, 1, 64, 128), (9, 128, 7, 1, 3, 1, 24, 40), (96, 64, 3, 2, 1, 1, 40, 56),
+                                   (48, 80, 3, 1, 1, 1, 37, 72), (100, 256, 1, 1, 0, 1, 21, 44), (36, 36, 3, 1, 1, 1, 72, 120)])
 def test_every_launch_configuration_the_autotuner_may_pick(shape):
     """All (npb, nw, ck, mb) candidates of ops._autotune -- every kernel instantiation, including the 2-, 8-
     and 9-wave workgroups -- against torch's fp32 convolution on ragged shapes."""
@@ -246,4 +247,22 @@ def test_every_launch_configuration_the_autotuner_may_pick(shape):
                     tried += 1
                     err = (y.cpu() - ref).abs().max().item()
                     assert err < 2e-5 * max(1.0, ref.abs().max().item()), ((npb, nw, ck, mb), err)
+    # quad layout (ds_read_b128 operands): ck 16 / 32, unit stride
+    tq = 0
+    if s == 1 and cin_pad >= 16:
+        for mb in (2, 4):
+            if 16 * mb > max(16, -(-cout // 16) * 16):
+                continue
+            for npb, nw in ((1, 4), (2, 4), (1, 9)):
+                for ck in (16, 32):
+                    pc.tuned[key] = (npb, nw, ck, mb, 1)
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        y = ops.conv2d(xd, pc, stride=s, pad=p, dil=d)
+                    if tuple(pc.tuned[key]) != (npb, nw, ck, mb, 1):
+                        continue
+                    tq += 1
+                    err = (y.cpu() - ref).abs().max().item()
+                    assert err < 2e-5 * max(1.0, ref.abs().max().item()), ((npb, nw, ck, mb, 1), err)
+        assert tq >= 2 or W % 4 != 0, tq  # rows that are not 16-byte aligned are refused (CODD_EUNSUPPORTED)
     assert tried >= 3

@@ -3,6 +3,6 @@
 mkdir -p gpurun_out/tune_search
 for i in $(seq 1 ${1:-6}); do
   rm -f gpurun_out/tune_search/db_$i.json
-  python bench.py --no-cpu-baseline --tune-db gpurun_out/tune_search/db_$i.json 2>/dev/null | tail -1 | python3 -c "
+  python bench.py --no-cpu-baseline --retune --tune-db gpurun_out/tune_search/db_$i.json 2>/dev/null | tail -1 | python3 -c "
 import sys,json; d=json.loads(sys.stdin.read()); print($i, d['value'], d['roofline']['frac'])" | tee -a gpurun_out/tune_search/results.txt
 done
