@@ -154,9 +154,10 @@ static int launch_quad_any(const ConvK& k, int nw, size_t lds, int grid, hipStre
   const codd_conv_params& p = k.p;
   const int nt = nw * 64, wr = cdiv(k.wchunk >> 2, nt), qr = cdiv((p.ck >> 2) * k.upc, nt);
 #define Q(W, N, M, R, QQ) if (nw == W && p.npb == N && p.mb == M && wr <= R && qr <= QQ) return launch_quad<W, N, M, R, QQ>(k, lds, grid, s);
-  Q(4, 1, 2, 8, 1) Q(4, 1, 2, 16, 2) Q(4, 1, 4, 12, 1) Q(4, 1, 4, 16, 2)
-  Q(4, 2, 2, 8, 2) Q(4, 2, 2, 16, 2) Q(4, 2, 4, 12, 2) Q(4, 2, 4, 16, 2)
-  Q(9, 1, 2, 8, 1) Q(9, 1, 4, 8, 1) Q(9, 1, 4, 16, 1)
+  Q(4, 1, 1, 8, 2) Q(4, 1, 2, 8, 1) Q(4, 1, 2, 16, 2) Q(4, 1, 4, 12, 1) Q(4, 1, 4, 16, 2)
+  Q(4, 2, 1, 8, 2) Q(4, 2, 2, 8, 2) Q(4, 2, 2, 16, 2) Q(4, 2, 4, 12, 2) Q(4, 2, 4, 16, 2)
+  Q(4, 4, 1, 8, 4) Q(4, 4, 2, 8, 4)
+  Q(9, 1, 1, 8, 1) Q(9, 1, 2, 8, 1) Q(9, 1, 4, 8, 1) Q(9, 1, 4, 16, 1)
 #undef Q
   return CODD_EUNSUPPORTED;
 }
@@ -202,7 +203,7 @@ extern "C" int codd_conv2d(const codd_conv_params* pp, void* stream) {
              (p.C1 == 0 || (uintptr_t)p.in1.ptr % 16 == 0);
   size_t lds = ((size_t)k.wchunk + (size_t)p.ck * k.chs) * sizeof(float);
   if (p.layout == 1) {  // quad layout: unpadded weights, input tile [cq][y][x][4]
-    if (!(p.ck == 16 || p.ck == 32) || p.sx != 1 || !k.vec_ok || (p.npb != 1 && p.npb != 2)) return CODD_EUNSUPPORTED;
+    if (!(p.ck == 16 || p.ck == 32) || p.sx > 2 || !k.vec_ok) return CODD_EUNSUPPORTED;
     k.wchunk = k.ntaps * p.ck * 16 * p.mb;
     lds = ((size_t)k.wchunk + (size_t)p.ck * k.thi * k.twp) * sizeof(float);
   } else if (p.layout != 0) {

@@ -9,7 +9,8 @@
 //   input    LDS image  [cq][y][x][4]                    (transposed while staging: a thread loads the same
 //                                                          float4 of pixels from 4 channels and writes 4 pixels)
 // 16 consecutive lanes read 16 consecutive 16-byte slots (256 B = every bank once): no padding needed.
-// Restrictions (checked on the host): ck = 16 or 32, unit x-stride, 16-byte aligned rows (vec_ok).
+// Restrictions (checked on the host): ck = 16 or 32, 16-byte aligned rows (vec_ok).  With an x-stride of 2 the
+// 16 lanes of an operand read are 32 bytes apart (2-way bank conflict, accepted).
 #include "conv_kernel.h"
 
 template <int NW, int NPB, int MB, int WREG, int QREG>
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(NW * 64) void conv_quad_kernel(const ConvK k) {
 #pragma unroll
   for (int a = 0; a < NPB; ++a) {
     const int prow = wave * RPW + a / XB, pcol = (a % XB) * 16 + j;
-    pbase[a] = prow * p.sy * k.twp + pcol + k.xoff;  // unit x-stride only
+    pbase[a] = prow * p.sy * k.twp + pcol * p.sx + k.xoff;
   }
   const int wq = 16 * MB;           // float4 per (tap, channel quad) of the weights
   const int iq = k.thi * k.twp;     // float4 per channel quad of the input tile
@@ -179,9 +180,10 @@ __global__ __launch_bounds__(NW * 64) void conv_quad_kernel(const ConvK k) {
   }
 }
 
-// instantiations (X(NW, NPB, MB, WREG, QREG)): 4-wave workgroups with 4x16 / 4x32 tiles, 9-wave with 4x16
-#define CONVQ_GROUP_A(X) X(4, 1, 2, 8, 1) X(4, 1, 2, 16, 2) X(4, 1, 4, 12, 1) X(4, 1, 4, 16, 2)
-#define CONVQ_GROUP_B(X) X(4, 2, 2, 8, 2) X(4, 2, 2, 16, 2) X(4, 2, 4, 12, 2) X(4, 2, 4, 16, 2) X(9, 1, 2, 8, 1) X(9, 1, 4, 8, 1) X(9, 1, 4, 16, 1)
-#define CONVQ_ALL(X) CONVQ_GROUP_A(X) CONVQ_GROUP_B(X)
+// instantiations (X(NW, NPB, MB, WREG, QREG)): 4-wave workgroups with 4x16 / 4x32 / 8x32 tiles, 9-wave with 4x16
+#define CONVQ_GROUP_A(X) X(4, 1, 2, 8, 1) X(4, 1, 2, 16, 2) X(4, 1, 4, 12, 1) X(4, 1, 4, 16, 2) X(4, 1, 1, 8, 2)
+#define CONVQ_GROUP_B(X) X(4, 2, 2, 8, 2) X(4, 2, 2, 16, 2) X(4, 2, 4, 12, 2) X(4, 2, 4, 16, 2) X(4, 2, 1, 8, 2)
+#define CONVQ_GROUP_C(X) X(9, 1, 2, 8, 1) X(9, 1, 4, 8, 1) X(9, 1, 4, 16, 1) X(9, 1, 1, 8, 1) X(4, 4, 1, 8, 4) X(4, 4, 2, 8, 4)
+#define CONVQ_ALL(X) CONVQ_GROUP_A(X) CONVQ_GROUP_B(X) CONVQ_GROUP_C(X)
 #define CONVQ_DECLARE(NW, NPB, MB, WREG, QREG) extern template __global__ void conv_quad_kernel<NW, NPB, MB, WREG, QREG>(const ConvK);
 #define CONVQ_DEFINE(NW, NPB, MB, WREG, QREG) template __global__ void conv_quad_kernel<NW, NPB, MB, WREG, QREG>(const ConvK);

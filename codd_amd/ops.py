@@ -292,9 +292,9 @@ def _autotune(lib, p, pc, default):
                 for ck in cks:
                     if (npb, nw, ck, mb, 0) not in cands:
                         cands.append((npb, nw, ck, mb, 0))
-    if p.sx == 1 and cin_pad >= 16:  # quad layout (ds_read_b128 operands): ck 16 / 32, 4- and 9-wave workgroups
-        for mb in [m for m in mbs if m >= 2]:
-            for npb, nw in ((1, 4), (2, 4), (1, 9)):
+    if p.sx <= 2 and cin_pad >= 16:  # quad layout (ds_read_b128 operands): ck 16 / 32
+        for mb in mbs:
+            for npb, nw in ((1, 4), (2, 4), (4, 4), (1, 9)):
                 for ck in (16, 32):
                     if ck <= max(16, cin_pad):
                         cands.append((npb, nw, ck, mb, 1))

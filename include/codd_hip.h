@@ -76,7 +76,7 @@ typedef struct {
   int nw;  /* waves (= 16-pixel tile rows) per workgroup: 0 or 4 (default), or 2 / 8 / 9 (npb 1 only) */
   int ck;  /* input channels staged per LDS chunk (multiple of 4) */
   int layout; /* 0: weights packed by codd_conv2d_pack_weights; 1: quad layout (codd_conv2d_pack_weights_quad;
-                 ck 16 or 32, unit x-stride, 16-byte aligned rows, npb 1 or 2) */
+                 ck 16 or 32, x-stride <= 2, 16-byte aligned rows) */
 } codd_conv_params;
 
 int codd_conv2d(const codd_conv_params* p, void* stream);

@@ -249,11 +249,11 @@ def test_every_launch_configuration_the_autotuner_may_pick(shape):
                     assert err < 2e-5 * max(1.0, ref.abs().max().item()), ((npb, nw, ck, mb), err)
     # quad layout (ds_read_b128 operands): ck 16 / 32, unit stride
     tq = 0
-    if s == 1 and cin_pad >= 16:
-        for mb in (2, 4):
+    if s <= 2 and cin_pad >= 16:
+        for mb in (1, 2, 4):
             if 16 * mb > max(16, -(-cout // 16) * 16):
                 continue
-            for npb, nw in ((1, 4), (2, 4), (1, 9)):
+            for npb, nw in ((1, 4), (2, 4), (4, 4), (1, 9)):
                 for ck in (16, 32):
                     pc.tuned[key] = (npb, nw, ck, mb, 1)
                     with warnings.catch_warnings():
