@@ -212,7 +212,7 @@ def test_autotuned_launch_configuration_keeps_results():
         ops.enable_autotune(False)
     assert len(ops.AUTOTUNE_LOG) == n0 + 1 and len(pc.tuned) == 1
     assert torch.equal(y1, y2)
-    assert (y1 - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+    assert (y1 - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("shape", [(20, 40, 3, 1, 1, 1, 37, 70), (64, 96, 3, 1, 4, 4, 24, 40), (33, 16, 1, 1, 0, 1, 19, 50),
