@@ -287,7 +287,7 @@ def main():
                 traffic, tsrc = round(tj["traffic_bytes_per_launch"]), "profiles/r01_final_conv_traffic.json: " + tj["correction"]
             roof = dict(bound="mfma", achieved=round(ach, 3), peak=FP32_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), traffic=traffic, traffic_unit="bytes/launch (PMC, "
-                        "not collected in this run)", traffic_source=tsrc, kernel="conv_mfma_kernel<*>",
+                        "not collected in this run)", traffic_source=tsrc, kernel="conv_mfma_kernel<*> + conv_quad_kernel<*>",
                         launches_per_frame=cr["launches"], gflop_per_frame=round(cr["gflop"], 2),
                         conv_ms_per_frame=round(cr["time_ms"], 3))
         except Exception as e:  # pragma: no cover

@@ -19,7 +19,7 @@ for mode in ("serial", "default"):
     rows = list(csv.DictReader(open(os.path.join(SRC, f"{mode}_kernel_stats.csv"))))
     shutil.copy(os.path.join(SRC, f"{mode}_kernel_stats.csv"), os.path.join(DST, f"r01_final_kernel_stats_{mode}.csv"))
     tot = sum(int(r["TotalDurationNs"]) for r in rows)
-    conv = [r for r in rows if "conv_mfma_kernel" in r["Name"]]
+    conv = [r for r in rows if "conv_mfma_kernel" in r["Name"] or "conv_quad_kernel" in r["Name"]]
     cn, ct = sum(int(r["Calls"]) for r in conv), sum(int(r["TotalDurationNs"]) for r in conv)
     b = bench_line(mode)
     stats[mode] = dict(rows=rows, tot=tot, conv_calls=cn, conv_ns=ct)
@@ -32,7 +32,7 @@ for mode in ("serial", "default"):
                 "within 2 % of the kernel durations below).\n\n")
         f.write(f"Total kernel time {tot/1e6:.1f} ms over {frames:.0f} frames = {tot/frames/1e6:.2f} ms/frame (sum of kernel durations"
                 f"{'; with side streams kernels overlap, so this exceeds the wall time' if mode == 'default' else ''}).\n\n")
-        f.write(f"conv_mfma_kernel<*> family: {cn} launches = {cn/frames:.0f}/frame, {ct/frames/1e6:.2f} ms/frame, avg {ct/cn/1e3:.1f} us/launch"
+        f.write(f"conv_mfma_kernel<*> + conv_quad_kernel<*> family: {cn} launches = {cn/frames:.0f}/frame, {ct/frames/1e6:.2f} ms/frame, avg {ct/cn/1e3:.1f} us/launch"
                 f"{' (includes the 4 all-pairs 1x1 launches issued inside the C library; bench.py times 505 launches/frame through the Python hook)' if mode == 'serial' else ''}.\n\n")
         f.write("| kernel | calls | ms/frame | avg us | % |\n|---|---|---|---|---|\n")
         for r in rows[:36]:
@@ -49,13 +49,13 @@ def load_pmc(tag):
 fetch, write, mf = load_pmc("FETCH_SIZE"), load_pmc("WRITE_SIZE"), load_pmc("SQ_VALU_MFMA_BUSY_CYCLES")
 serial_avg = {r["Name"]: float(r["AverageNs"]) / 1e3 for r in stats["serial"]["rows"]}
 kernels = sorted({k for k, _ in fetch})
-conv_f = sum(v[0] for (k, c), v in fetch.items() if "conv_mfma" in k)
-conv_w = sum(v[0] for (k, c), v in write.items() if "conv_mfma" in k)
-conv_n = sum(v[1] for (k, c), v in fetch.items() if "conv_mfma" in k)
+conv_f = sum(v[0] for (k, c), v in fetch.items() if "conv_mfma" in k or "conv_quad" in k)
+conv_w = sum(v[0] for (k, c), v in write.items() if "conv_mfma" in k or "conv_quad" in k)
+conv_n = sum(v[1] for (k, c), v in fetch.items() if "conv_mfma" in k or "conv_quad" in k)
 # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts
 # wide coalesced reads at half their size -> traffic upper estimate = 2 * FETCH + WRITE
 traffic_per_launch = (2 * conv_f + conv_w) * 1024.0 / conv_n
-json.dump(dict(kernel="conv_mfma_kernel<*>", launches=conv_n, fetch_kib_per_launch=conv_f / conv_n,
+json.dump(dict(kernel="conv_mfma_kernel<*> + conv_quad_kernel<*>", launches=conv_n, fetch_kib_per_launch=conv_f / conv_n,
                write_kib_per_launch=conv_w / conv_n, traffic_bytes_per_launch=traffic_per_launch,
                correction="traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950: FETCH_SIZE counts wide reads at half size)",
                source="tools/profile_round.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) on "
@@ -69,13 +69,13 @@ with open(os.path.join(DST, "r01_final_pmc_counters.md"), "w") as f:
             "(HBM section) FETCH_SIZE on gfx950 counts wide coalesced reads at half their size, so `traffic = (2*FETCH + WRITE) KiB` "
             "(an upper estimate for narrow gathers).  Durations are the un-counted serial-stream averages of "
             "`r01_final_kernel_stats_serial.csv`.\n\n")
-    f.write(f"## Convolution family\n\nAll `conv_mfma_kernel<*>` launches: FETCH {conv_f/conv_n:.0f} KiB + WRITE {conv_w/conv_n:.0f} KiB per launch "
+    f.write(f"## Convolution family\n\nAll `conv_mfma_kernel<*>` / `conv_quad_kernel<*>` launches: FETCH {conv_f/conv_n:.0f} KiB + WRITE {conv_w/conv_n:.0f} KiB per launch "
             f"-> traffic {(traffic_per_launch)/1e6:.2f} MB per launch ({conv_n} launches in the pass); the frame's conv launches move "
             f"{traffic_per_launch*512/1e9:.2f} GB per frame against 1 044 GFLOP: arithmetic intensity ~{1043.84e9/(traffic_per_launch*512):.0f} FLOP/B, "
             "far on the compute side of the fp32-MFMA ridge (157.3 TFLOP/s / 8 TB/s = 20 FLOP/B).\n\n")
-    f.write("| instantiation <NW,NPB,MB,WREG,IREG> | launches in pass | MFMA busy cycles/launch | MFMA pipe utilisation | FETCH KiB/launch | WRITE KiB/launch |\n|---|---|---|---|---|---|\n")
+    f.write("| instantiation <NW,NPB,MB,WREG,IREG|QREG> | launches in pass | MFMA busy cycles/launch | MFMA pipe utilisation | FETCH KiB/launch | WRITE KiB/launch |\n|---|---|---|---|---|---|\n")
     for k in kernels:
-        if "conv_mfma" not in k:
+        if "conv_mfma" not in k and "conv_quad" not in k:
             continue
         busy, n = mf.get((k, "SQ_VALU_MFMA_BUSY_CYCLES"), (0, 1))
         act, _ = mf.get((k, "GRBM_GUI_ACTIVE"), (0, 1))
@@ -85,7 +85,7 @@ with open(os.path.join(DST, "r01_final_pmc_counters.md"), "w") as f:
     f.write("\n`util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCD x 1024 SIMD)`.\n\n## Other kernels (HBM / latency bound)\n\n")
     f.write("| kernel | launches in pass | avg us (serial) | FETCH KiB/launch | WRITE KiB/launch | traffic MB/launch (2F+W) | GB/s at the serial duration |\n|---|---|---|---|---|---|---|\n")
     for k in kernels:
-        if "conv_mfma" in k or "rocclr" in k:
+        if "conv_mfma" in k or "conv_quad" in k or "rocclr" in k:
             continue
         fs, n = fetch[(k, "FETCH_SIZE")]
         ws, _ = write.get((k, "WRITE_SIZE"), (0, 1))
