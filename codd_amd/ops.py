@@ -299,6 +299,12 @@ def _autotune(lib, p, pc, default):
                     if ck <= max(16, cin_pad):
                         cands.append((npb, nw, ck, mb, 1))
     stream = _stream()
+    # the timed launches write into a scratch copy of the output buffer: the real one may alias an operand
+    # (in-place accumulation "out = conv(x) + out"), which repeated launches would accumulate over and over
+    real_out = p.out
+    scratch_out = torch.empty(p.B * p.out_ctot * (4 if p.store_mode else 1) * p.Hout * p.Wout, device=pc._w.device,
+                              dtype=torch.float32)
+    p.out = scratch_out.data_ptr()
     torch.cuda.synchronize()  # nothing else on the device while the candidates are timed
     best, best_t, t_default = default, float("inf"), None
     for (npb, nw, ck, mb, layout) in [default] + cands:  # the heuristic is timed twice (first = warm-up of clocks / caches)
@@ -328,6 +334,7 @@ def _autotune(lib, p, pc, default):
     used = {pc._pack_key(c) for c in pc.tuned.values()} | {pc._pack_key(best)}
     for k in [k for k in pc._packs if k not in used]:
         del pc._packs[k]  # packed-weight variants of the losing candidates
+    p.out = real_out
     AUTOTUNE_LOG.append(("%dx%d k%dx%d %d->%d out %dx%d" % (p.sy, p.sx, pc.kh, pc.kw, pc.cin, pc.cout, p.Hout, p.Wout),
                          default, None if t_default is None else t_default * 1e3, best, best_t * 1e3))
     return best

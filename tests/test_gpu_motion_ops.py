@@ -474,3 +474,33 @@ def test_fused_geometry_lookup_equals_separate_kernels():
     xyz2, minfo2, corr2 = ops.raft_geometry_lookup(T, d1, d2, K8, pyr)
     assert torch.equal(xyz, xyz2) and torch.equal(minfo, minfo2)
     assert (corr - corr2).abs().max().item() < 1e-5 * max(1.0, corr.abs().max().item())
+
+
+def test_full_codd_parity_with_autotuned_launch_configurations():
+    """The configurations the tuner picks (quad-layout kernel, 2/8/9-wave workgroups, ...) in the whole pipeline:
+    HIP vs oracle on a 3-frame sequence, same bound as the un-tuned parity tests."""
+    from codd_amd import configs, ops, synth
+    from codd_amd.registry import build_estimator
+    from oracle import codd as oc
+    H, W, MF, iters = 128, 256, 3, 2
+    est = build_estimator(configs.codd(iters=iters)).eval()
+    synth.load_synthetic_weights(est, 1.4)
+    sd = {k: v.clone() for k, v in est.state_dict().items()}
+    est = est.to(DEV)
+    img, r_img, _ = synth.stereo_sequence(H, W, MF, 32.0)
+    intr = (160.0, 160.0, 128.0, 64.0)
+    metas = synth.default_metas(H, W, intrinsics=intr)[0]
+    so, sg = {}, {}
+    ops.enable_autotune(True)
+    try:
+        with torch.no_grad():
+            for f in range(MF):
+                oo = oc.frame(sd, img[:, f], r_img[:, f], so, intr, iters=iters)
+                og = est.consistent_online_depth_estimation(img[:, f].to(DEV).contiguous(), r_img[:, f].to(DEV).contiguous(),
+                                                            metas, sg)
+                d = (og["pred_disp"].cpu() - oo["pred_disp"]).abs()
+                assert d.median().item() < 1e-4 and (d > 1e-2).float().mean().item() < 5e-3, (f, d.mean().item())
+                assert d[d <= 1e-2].mean().item() < 1e-3
+    finally:
+        ops.enable_autotune(False)
+    assert len(ops.TUNE_DB) > 50

@@ -266,3 +266,21 @@ def test_every_launch_configuration_the_autotuner_may_pick(shape):
                     assert err < 2e-5 * max(1.0, ref.abs().max().item()), ((npb, nw, ck, mb, 1), err)
         assert tq >= 2 or W % 4 != 0, tq  # rows that are not 16-byte aligned are refused (CODD_EUNSUPPORTED)
     assert tried >= 3
+
+
+def test_autotune_leaves_in_place_accumulation_alone():
+    """out = conv(x) + out (HRNet's fuse layers write into their own residual operand): the tuner's timing
+    launches must not accumulate into the real output."""
+    from codd_amd import ops
+    x = rnd(1, 32, 36, 60).to("cuda")
+    w = (rnd(32, 32, 3, 3, seed=1) / 17.0).to("cuda")
+    acc0 = rnd(1, 32, 36, 60, seed=5).to("cuda")
+    ref = F.conv2d(x.cpu(), w.cpu(), padding=1) + acc0.cpu()
+    ops.enable_autotune(True)
+    try:
+        pc = ops.PackedConv(w, None)
+        acc = acc0.clone()
+        ops.conv2d(x, pc, pad=1, res1=acc, out=acc)
+    finally:
+        ops.enable_autotune(False)
+    assert (acc.cpu() - ref).abs().max().item() < 1e-4
