@@ -284,3 +284,34 @@ def test_autotune_leaves_in_place_accumulation_alone():
     finally:
         ops.enable_autotune(False)
     assert (acc.cpu() - ref).abs().max().item() < 1e-4
+
+
+def test_tunable_configurations_with_views_and_two_inputs():
+    """Quad-layout and classic kernels with a channel-slice view as first input (24 of 40 channels, offset 6), a
+    second input (18 channels: the quad of channels 24..27 straddles both), residual + post operands and a slice
+    of a wider buffer as output."""
+    import warnings
+    from codd_amd import ops
+    from codd_amd.ops import Slice
+    H, W = 36, 64
+    big, x2 = rnd(1, 40, H, W), rnd(1, 18, H, W, seed=3)
+    w, b = rnd(48, 42, 3, 3, seed=1) / 19.0, rnd(48, seed=2) * 0.1
+    res, post = rnd(1, 48, H, W, seed=4), rnd(1, 48, H, W, seed=5)
+    ref = F.relu(F.conv2d(torch.cat([big[:, 6:30], x2], 1), w, b, padding=1) + res) + post
+    bd, x2d, resd, postd = big.to("cuda"), x2.to("cuda"), res.to("cuda"), post.to("cuda")
+    pc = ops.PackedConv(w.to("cuda"), b.to("cuda"))
+    key = (H, W, 1, 1, 1, 1, 1, 1, True)
+    n = 0
+    for cfg in [(1, 4, 12, 2, 0), (2, 4, 8, 1, 0), (1, 9, 16, 2, 0), (1, 2, 8, 2, 0), (1, 8, 16, 1, 0),
+                (1, 4, 16, 2, 1), (2, 4, 16, 2, 1), (1, 9, 16, 2, 1), (1, 4, 32, 1, 1), (4, 4, 16, 1, 1)]:
+        pc.tuned[key] = cfg
+        outbuf = torch.zeros(1, 64, H, W, device="cuda")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ops.conv2d(Slice(bd, 6, 24), pc, x2=x2d, pad=1, act="relu", res1=resd, post=postd, out=Slice(outbuf, 8, 48))
+        if tuple(pc.tuned[key]) != cfg:
+            continue
+        n += 1
+        assert (outbuf[:, 8:56].cpu() - ref).abs().max().item() < 5e-5, cfg
+        assert outbuf[:, :8].abs().max().item() == 0 and outbuf[:, 56:].abs().max().item() == 0, cfg
+    assert n >= 6, n
