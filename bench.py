@@ -196,14 +196,12 @@ def main():
     from codd_amd.runtime import FrameRunner, PipelinedRunner
 
     from codd_amd import ops as _ops_tune
-    _ops_tune.enable_autotune(not args.no_autotune)
-    shipped = os.path.join(os.path.dirname(os.path.abspath(__file__)), "codd_amd", "tuned", "mi355x.json")
+    # shipped = codd_amd/tuned/mi355x.json: launch configurations found by the autotuner on an MI355X for the layer
+    # shapes of this workload and committed with the library (like a find-db); shapes it does not know are still
+    # timed on the fly.  --retune ignores it, --tune-db replaces it.
+    _ops_tune.enable_autotune(not args.no_autotune, shipped=not args.retune and not args.tune_db)
     if args.tune_db and os.path.exists(args.tune_db):
         _ops_tune.load_tune_db(args.tune_db)
-    elif not args.tune_db and not args.no_autotune and not args.retune and os.path.exists(shipped):
-        # launch configurations found by the autotuner on an MI355X for the layer shapes of this workload and
-        # committed with the library (like a find-db); shapes it does not know are still timed on the fly
-        _ops_tune.load_tune_db(shipped)
     est = build_model(args, device)
     if args.serial_streams:
         from codd_amd import ops as _ops

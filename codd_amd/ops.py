@@ -272,13 +272,20 @@ def load_tune_db(path=None):
     TUNE_DB.update({k: tuple(v) for k, v in json.load(open(path)).items()})
 
 
-def enable_autotune(flag=True):
+def enable_autotune(flag=True, shipped=True):
     """Measure-don't-guess launch configuration: the first (eager, un-captured) launch of every
-    (layer, shape) times the heuristic (npb, nw, ck) against every other configuration the kernel is
-    instantiated for and keeps the fastest for the rest of the process (bench.py turns this on; the tests
-    run the deterministic heuristics).  Different chunk depths change the fp32 summation order, nothing else."""
+    (layer, shape) times the heuristic (npb, nw, ck, mb, layout) against every other configuration the kernels
+    are instantiated for and keeps the fastest for the rest of the process (bench.py and the CLI turn this on;
+    the tests run the deterministic heuristics).  ``shipped``: start from codd_amd/tuned/mi355x.json (the
+    configurations found on an MI355X for the 960x576 workload), so that known layer signatures are not timed
+    again.  Different chunk depths / layouts change the fp32 summation order, nothing else."""
     global _AUTOTUNE
     _AUTOTUNE = bool(flag)
+    if _AUTOTUNE and shipped and not TUNE_DB:
+        try:
+            load_tune_db()
+        except (OSError, ValueError):
+            pass
 
 
 def _autotune(lib, p, pc, default):

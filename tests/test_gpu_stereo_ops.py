@@ -203,7 +203,7 @@ def test_autotuned_launch_configuration_keeps_results():
     w = (rnd(128, 64, 3, 3, seed=1) / 24.0).to("cuda")
     ref = ops.conv2d(x, ops.PackedConv(w, None), pad=1, act="relu")
     n0 = len(ops.AUTOTUNE_LOG)
-    ops.enable_autotune(True)
+    ops.enable_autotune(True, shipped=False)
     try:
         pc = ops.PackedConv(w, None)
         y1 = ops.conv2d(x, pc, pad=1, act="relu")
@@ -276,7 +276,7 @@ def test_autotune_leaves_in_place_accumulation_alone():
     w = (rnd(32, 32, 3, 3, seed=1) / 17.0).to("cuda")
     acc0 = rnd(1, 32, 36, 60, seed=5).to("cuda")
     ref = F.conv2d(x.cpu(), w.cpu(), padding=1) + acc0.cpu()
-    ops.enable_autotune(True)
+    ops.enable_autotune(True, shipped=False)
     try:
         pc = ops.PackedConv(w, None)
         acc = acc0.clone()
