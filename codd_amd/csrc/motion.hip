@@ -641,7 +641,7 @@ extern "C" int codd_disp_to_depth(const float* disp, long long n, float bf, floa
 // Forward splat (Motion.transform_and_project, reference motion.py:82-130).
 //   pass 1 (per source point): project, append the point id to the candidate list of every covered
 //           pixel (atomic slot counter; the slot ORDER is irrelevant, see pass 2);
-//   pass 2 (per output pixel): re-project the candidates, keep the 8 nearest by (z, id) --
+//   pass 2 (per output pixel): read the candidates' projections back, keep the 8 nearest by (z, id) --
 //           deterministic regardless of the append order -- and composite front to back.
 // Pixel centres sit at +0.5 (pytorch3d NDC convention); R = radius * min(H,W) / (2H) pixels.
 // ------------------------------------------------------------------------------------------------
@@ -650,6 +650,7 @@ struct SplatP {
   const float* featA; int CA; const float* featB; int CB; int with_flow;
   int H, W; float fx, fy, cx, cy, R; float bf;
   float* out; float* zout; int* cnt; int* list; int cap;
+  float4* uvz;  // per source point: projected (u, v, z) written by pass 1, read back by pass 2
 };
 
 __device__ __forceinline__ bool splat_point(const SplatP& p, int b, int n, float* u, float* v, float* z,
@@ -674,8 +675,10 @@ __global__ void splat_scatter_kernel(const SplatP p) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = blockIdx.y;
   if (n >= p.H * p.W) return;
-  float u, v, z;
-  if (!splat_point(p, b, n, &u, &v, &z, nullptr)) return;
+  float u = 0.f, v = 0.f, z = 0.f;
+  const bool ok = splat_point(p, b, n, &u, &v, &z, nullptr);
+  p.uvz[(size_t)b * p.H * p.W + n] = make_float4(u, v, z, ok ? 1.f : 0.f);
+  if (!ok) return;
   const int span = (int)(p.R + 1.5f);
   const int bx = (int)floorf(u - 0.5f), by = (int)floorf(v - 0.5f);
   const float R2 = p.R * p.R;
@@ -703,49 +706,65 @@ __global__ void splat_gather_kernel(const SplatP p) {
   const int py = pix / p.W, px = pix - py * p.W;
   const size_t gp = (size_t)b * HW + pix;
   const int cnt = min(p.cnt[gp], p.cap);
+  // sorted (z, id) top-8 kept in REGISTERS: every array index below is a compile-time constant after unrolling
+  // (a run-time index would push the arrays to scratch memory); empty slots hold (+inf, INT_MAX)
   float kz[8], ka[8];
   int kid[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { kz[q] = INFINITY; ka[q] = 0.f; kid[q] = 0x7fffffff; }
   int nk = 0;
   const float R2 = p.R * p.R;
   for (int s = 0; s < cnt; ++s) {
     const int n = p.list[gp * p.cap + s];
-    float u, v, z;
-    splat_point(p, b, n, &u, &v, &z, nullptr);
-    const float du = u - ((float)px + 0.5f), dv = v - ((float)py + 0.5f);
-    const float al = 1.f - (du * du + dv * dv) / R2;
-    // insertion into the sorted (z, id) top-8
-    int pos = nk;
-    while (pos > 0 && (z < kz[pos - 1] || (z == kz[pos - 1] && n < kid[pos - 1]))) --pos;
-    if (pos >= 8) continue;
-    const int last = nk < 8 ? nk : 7;
-    for (int q = last; q > pos; --q) { kz[q] = kz[q - 1]; ka[q] = ka[q - 1]; kid[q] = kid[q - 1]; }
-    kz[pos] = z; ka[pos] = al; kid[pos] = n;
-    if (nk < 8) ++nk;
+    // 16 bytes written by pass 1 instead of re-loading T (28 B) + depth and redoing the SE3 action per candidate
+    const float4 q4 = p.uvz[(size_t)b * HW + n];
+    const float du = q4.x - ((float)px + 0.5f), dv = q4.y - ((float)py + 0.5f);
+    float cz = q4.z, ca = 1.f - (du * du + dv * dv) / R2;
+    int cn = n;
+    // insertion by carrying the displaced element down the list
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (cz < kz[q] || (cz == kz[q] && cn < kid[q])) {
+        const float tz = kz[q], ta = ka[q]; const int tn = kid[q];
+        kz[q] = cz; ka[q] = ca; kid[q] = cn;
+        cz = tz; ca = ta; cn = tn;
+      }
+    }
   }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) nk += kid[q] != 0x7fffffff ? 1 : 0;  // occupied slots (they are a prefix of the list)
   const int C = p.CA + (p.with_flow ? 3 : 0) + p.CB;
   float wk[8];
   float tr = 1.f;
-  for (int k = 0; k < nk; ++k) { wk[k] = tr * ka[k]; tr *= (1.f - ka[k]); }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { wk[k] = k < nk ? tr * ka[k] : 0.f; tr *= (1.f - ka[k]); if (k >= nk) kid[k] = 0; }
   float* op = p.out + (size_t)b * C * HW + pix;
   for (int c = 0; c < p.CA; ++c) {
+    const float* fp = p.featA + ((size_t)b * p.CA + c) * HW;
     float acc = 0.f;
-    for (int k = 0; k < nk; ++k) acc += wk[k] * p.featA[((size_t)b * p.CA + c) * HW + kid[k]];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (k < nk) acc += wk[k] * fp[kid[k]];
     op[(size_t)c * HW] = acc;
   }
   int co = p.CA;
   if (p.with_flow) {
     float f0 = 0.f, f1 = 0.f, f2 = 0.f;
-    for (int k = 0; k < nk; ++k) {
-      float u, v, z; V3 fl;
-      splat_point(p, b, kid[k], &u, &v, &z, &fl);
-      f0 += wk[k] * fl.x; f1 += wk[k] * fl.y; f2 += wk[k] * fl.z;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < nk) {
+        float u, v, z; V3 fl;
+        splat_point(p, b, kid[k], &u, &v, &z, &fl);
+        f0 += wk[k] * fl.x; f1 += wk[k] * fl.y; f2 += wk[k] * fl.z;
+      }
     }
     op[(size_t)co * HW] = f0; op[(size_t)(co + 1) * HW] = f1; op[(size_t)(co + 2) * HW] = f2;
     co += 3;
   }
   for (int c = 0; c < p.CB; ++c) {
+    const float* fp = p.featB + ((size_t)b * p.CB + c) * HW;
     float acc = 0.f;
-    for (int k = 0; k < nk; ++k) acc += wk[k] * p.featB[((size_t)b * p.CB + c) * HW + kid[k]];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (k < nk) acc += wk[k] * fp[kid[k]];
     op[(size_t)(co + c) * HW] = acc;
   }
   if (p.zout) {
@@ -765,7 +784,7 @@ extern "C" int codd_splat(const float* T, const float* depth, int HT, int WT, in
                           const float* featA, int CA, const float* featB, int CB, int with_flow, int B, int H, int W,
                           float fx, float fy, float cx, float cy, float radius, float bf, float* out, float* zout,
                           int* scratch, int cap, void* stream) {
-  if (!T || !depth || !out || !scratch || cap < 8 || CA < 0 || CB < 0 || (CA > 0 && !featA) || (CB > 0 && !featB))
+  if (!T || !depth || !out || !scratch || ((uintptr_t)scratch & 15) || cap < 8 || CA < 0 || CB < 0 || (CA > 0 && !featA) || (CB > 0 && !featB))
     return CODD_EINVAL;
   if (oy + ds * (H - 1) >= HT || ox + ds * (W - 1) >= WT) return CODD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
@@ -776,6 +795,7 @@ extern "C" int codd_splat(const float* T, const float* depth, int HT, int WT, in
   p.R = radius * (float)(H < W ? H : W) / (2.f * (float)H);
   p.bf = bf; p.out = out; p.zout = zout;
   p.cnt = scratch; p.list = scratch + (size_t)B * H * W; p.cap = cap;
+  p.uvz = (float4*)(scratch + ((((size_t)B * H * W * (1 + cap)) + 3) & ~(size_t)3));  // 16-byte aligned
   // zero the per-pixel candidate counters with a kernel (a plain kernel node under graph capture;
   // hipMemsetAsync becomes a memset node whose ordering against neighbouring kernel nodes is not
   // relied upon)

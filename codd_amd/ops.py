@@ -498,7 +498,7 @@ def splat(T, depth, featA, featB, with_flow, H, W, oy, ox, ds, K, radius, bf=0.0
     Cc = CA + (3 if with_flow else 0) + CB
     out = _f32(B, Cc, H, W, like=T)
     z = _f32(B, 1, H, W, like=T)
-    scratch = torch.empty(B * H * W * (1 + cap), device=T.device, dtype=torch.int32)
+    scratch = torch.empty(-(-(B * H * W * (1 + cap)) // 4) * 4 + 4 * B * H * W, device=T.device, dtype=torch.int32)
     _abi.check(lib.codd_splat(T.data_ptr(), depth.data_ptr(), HT, WT, oy, ox, ds,
                               None if featA is None else featA.data_ptr(), CA,
                               None if featB is None else featB.data_ptr(), CB, int(with_flow), B, H, W, *K,

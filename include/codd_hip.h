@@ -190,7 +190,8 @@ int codd_disp_to_depth(const float* disp, long long n, float bf, float* depth, v
  *   feat channels = concat(featA [CA], flow(3, computed when with_flow), featB [CB]);
  *   out [B,C,H,W], zout [B,1,H,W] (nearest z, 0 when empty) or disparity when bf > 0:
  *   disp = bf/(z+1e-5), > W -> 0 (motion.py:190-193).
- * scratch: B*H*W*(1+cap) ints; cap = candidate-list capacity per pixel (>= 8). */
+ * scratch: 16-byte aligned, round_up(B*H*W*(1+cap), 4) + 4*B*H*W ints (counters, candidate lists, one
+ * float4 (u, v, z, valid) per source point); cap = candidate-list capacity per pixel (>= 8). */
 int codd_splat(const float* T, const float* depth, int HT, int WT, int oy, int ox, int ds,
                const float* featA, int CA, const float* featB, int CB, int with_flow,
                int B, int H, int W, float fx, float fy, float cx, float cy, float radius,
