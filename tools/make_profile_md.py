@@ -85,7 +85,7 @@ with open(os.path.join(DST, "r01_final_pmc_counters.md"), "w") as f:
     f.write("\n`util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCD x 1024 SIMD)`.\n\n## Other kernels (HBM / latency bound)\n\n")
     f.write("| kernel | launches in pass | avg us (serial) | FETCH KiB/launch | WRITE KiB/launch | traffic MB/launch (2F+W) | GB/s at the serial duration |\n|---|---|---|---|---|---|---|\n")
     for k in kernels:
-        if "conv_mfma" in k or "conv_quad" in k or "rocclr" in k:
+        if "conv_mfma" in k or "conv_quad" in k or "rocclr" in k or "at::native" in k:  # torch kernels: eager set-up only
             continue
         fs, n = fetch[(k, "FETCH_SIZE")]
         ws, _ = write.get((k, "WRITE_SIZE"), (0, 1))
