@@ -67,6 +67,17 @@ class Fusion(nn.Module):
         fc = self.fusion_channel
         # [mo (fc-2) | pc | pw] : second half of residual_conv's input (reference fuse(), :343-346)
         tail = torch.empty(B, fc, H // 4, W // 4, device=pred_curr.device, dtype=torch.float32)
+        # the full-resolution forget-head chain (reference fusion.py:123-132) only needs the warped state: it runs
+        # on a side stream beside the quarter-resolution cue / weight-head chain
+        if getattr(self, "_fk", None) is None or self._fk.dev != pred_curr.device:
+            self._fk = ops.Fork(pred_curr.device, 1)
+
+        def forget_chain():
+            cues_fr = ops.fusion_cues_fr(pred_curr, pred_warp, flow_warp, conf_warp)
+            t = cv(self.forget_head[1], cv(self.forget_head[0], cues_fr))
+            return cv(self.forget_head[2], t, act="sigmoid")
+
+        wr = self._fk.run(0, forget_chain)
         corr_feat = ops.fusion_cues_lr(pred_curr, pred_warp, feat_curr, feat_warp, fea_l, fea_r, Slice(tail, fc - 2, 2))
         corr = cv(self.conv_corr[2], cv(self.conv_corr[0], corr_feat, act="relu"), act="relu")
         disp = cv(self.conv_disp[0], Slice(tail, fc - 2, 2), act="relu")
@@ -74,9 +85,7 @@ class Fusion(nn.Module):
         cv(self.motion_conv[0], corr, x2=disp, act="relu", out=Slice(tail, 0, fc - 2))
         net = cv(self.residual_conv[0], feat_curr, x2=tail, act="relu", post=corr)
         wf_lr = cv(self.weight_head[1], cv(self.weight_head[0], net), act="sigmoid")
-        cues_fr = ops.fusion_cues_fr(pred_curr, pred_warp, flow_warp, conf_warp)
-        t = cv(self.forget_head[1], cv(self.forget_head[0], cues_fr))
-        wr = cv(self.forget_head[2], t, act="sigmoid")
+        self._fk.join()
         fused, wf, wr = ops.fusion_blend(pred_curr, pred_warp, wf_lr, wr, self.ds_scale)
         outputs["pred_disp"] = fused
         outputs["fusion_weights"] = wf
