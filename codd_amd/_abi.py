@@ -25,6 +25,7 @@ class ConvParams(C.Structure):
         ("kh", C.c_int), ("kw", C.c_int), ("sy", C.c_int), ("sx", C.c_int),
         ("pad_t", C.c_int), ("pad_l", C.c_int), ("dil_y", C.c_int), ("dil_x", C.c_int),
         ("act", C.c_int), ("store_mode", C.c_int), ("mb", C.c_int), ("npb", C.c_int), ("nw", C.c_int), ("ck", C.c_int), ("layout", C.c_int),
+        ("terms", C.c_int), ("pgw", C.c_int), ("cgw", C.c_int),
     ]
 
 
@@ -68,6 +69,8 @@ SIGNATURES = {
     "codd_raft_geometry_lookup": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p]),
     "codd_conv2d_packed_size_quad": (C.c_longlong, [_i, _i, _i, _i, _i, _i]),
     "codd_conv2d_pack_weights_quad": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "codd_conv2d_packed_bytes_bf16": (_ll, [_i] * 7),
+    "codd_conv2d_pack_weights_bf16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _f, _p]),
     "codd_fusion_select": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p]),
     "codd_gt_motion": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "codd_tepe_metrics": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p]),
@@ -75,6 +78,7 @@ SIGNATURES = {
     "codd_fusion_blend": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
 }
 
+ABI_VERSION = 2  # CODD_ABI_VERSION of include/codd_hip.h
 _lib = None
 MISSING = []
 
@@ -93,12 +97,20 @@ def load():
     if _lib is not None:
         return _lib
     path = lib_path()
-    if not os.path.exists(path) or _build.needs_build():
+    # One process at a time decides / rebuilds (torchrun starts every rank at once on a fresh checkout); a rebuild
+    # that is needed but fails is an error -- a stale library is never loaded silently against newer sources.
+    import fcntl
+    with open(os.path.join(os.path.dirname(path), ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            _build.build(verbose=False)
-        except Exception as e:  # pragma: no cover
-            if not os.path.exists(path):
-                raise CoddHipError(f"libcodd_hip.so missing and cannot be built: {e}") from e
+            if not os.path.exists(path) or _build.needs_build():
+                try:
+                    _build.build(verbose=False)
+                except Exception as e:  # pragma: no cover
+                    raise CoddHipError(f"libcodd_hip.so is missing or older than its sources and the rebuild "
+                                       f"failed: {e}") from e
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         try:
@@ -109,7 +121,7 @@ def load():
             continue
         fn.restype = res
         fn.argtypes = args
-    if lib.codd_abi_version() != 1:
+    if lib.codd_abi_version() != ABI_VERSION:
         raise CoddHipError("ABI version mismatch")
     _lib = lib
     return lib

@@ -58,10 +58,12 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1, 16))) as ex:
         list(ex.map(run, jobs))  # translation units are independent: compile them in parallel
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    tmp = LIB + ".tmp.%d" % os.getpid()  # link under a private name, then rename: no reader ever sees a partial file
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)
     return LIB
 
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CODD_ABI_VERSION 1
+#define CODD_ABI_VERSION 2
 
 #define CODD_OK 0
 #define CODD_EINVAL (-1)
@@ -42,7 +42,12 @@ typedef struct {
 } codd_view;
 
 /* ---------------------------------------------------------------------------------------------
- * Convolution family (MFMA implicit GEMM, v_mfma_f32_16x16x4_f32: exact fp32).
+ * Convolution family (MFMA implicit GEMM).  Three kernel families behind one entry point, selected by `layout`:
+ *   0 / 1  v_mfma_f32_16x16x4_f32 (exact fp32 k-ordered fma chain);
+ *   2      v_mfma_f32_16x16x32_bf16 on split-bf16 operands: terms = 3 evaluates every product as
+ *          a_hi b_hi + a_hi b_lo + a_lo b_hi (fp32 accumulate, ~16 mantissa bits per product: the fp32-grade
+ *          default), terms = 1 is plain bf16 operands / fp32 accumulate (reference auto_fp16 hook,
+ *          model/codd.py:37,128; BASELINE.json configs[4]).
  * Replaces every nn.Conv2d / nn.ConvTranspose2d call of the hot path: HITUNet (backbone.py:8-88),
  * TileInitialization convs (initialization.py:60-156,186-190), TileUpdate* / PostTileUpdate /
  * FinalTileUpdate (propagation.py:89-333), BasicEncoder (blocks/extractor.py:119-199),
@@ -76,7 +81,11 @@ typedef struct {
   int nw;  /* waves (= 16-pixel tile rows) per workgroup: 0 or 4 (default), or 2 / 8 / 9 (npb 1 only) */
   int ck;  /* input channels staged per LDS chunk (multiple of 4) */
   int layout; /* 0: weights packed by codd_conv2d_pack_weights; 1: quad layout (codd_conv2d_pack_weights_quad;
-                 ck 16 or 32, x-stride <= 2, 16-byte aligned rows) */
+                 ck 16 or 32, x-stride <= 2, 16-byte aligned rows); 2: split-bf16 kernel (weights packed by
+                 codd_conv2d_pack_weights_bf16 for (mb, ck, terms); here nw = tile rows, npb = 16-pixel units per
+                 tile row (1 | 2), ck a multiple of 8) */
+  int terms;  /* layout 2: 1 = bf16 operands, 3 = split-bf16 (hi/lo) operands */
+  int pgw, cgw; /* layout 2: wave grid of a workgroup (pixel-unit groups x channel-block groups), mb % cgw == 0 */
 } codd_conv_params;
 
 int codd_conv2d(const codd_conv_params* p, void* stream);
@@ -85,6 +94,12 @@ int codd_conv2d(const codd_conv_params* p, void* stream);
 long long codd_conv2d_packed_size_quad(int Cout, int Cin, int kh, int kw, int mb, int ck);
 int codd_conv2d_pack_weights_quad(const float* w, float* wpacked, int Cout, int Cin, int kh, int kw, int mb,
                                   int ck, void* stream);
+
+/* split-bf16 layout (layout = 2): [cog][chunk][plane hi|lo][k-step][g][co][8 bf16]; element (co, ci, tap) is read
+ * from w[co*co_stride + ci*ci_stride + tap] and scaled (as codd_conv2d_pack_weights_ex). */
+long long codd_conv2d_packed_bytes_bf16(int Cout, int Cin, int kh, int kw, int mb, int ck, int terms);
+int codd_conv2d_pack_weights_bf16(const float* w, void* wpacked, int Cout, int Cin, int kh, int kw, int mb, int ck,
+                                  int terms, long long co_stride, long long ci_stride, float scale, void* stream);
 
 /* number of floats of the packed weight buffer for (Cout, Cin, kh, kw, mb, ck) */
 long long codd_conv2d_packed_size(int Cout, int Cin, int kh, int kw, int mb, int ck);
