@@ -37,6 +37,7 @@ _i, _f, _p, _ll = C.c_int, C.c_float, C.c_void_p, C.c_longlong
 SIGNATURES = {
     "codd_abi_version": (_i, []),
     "codd_conv2d": (_i, [C.POINTER(ConvParams), _p]),
+    "codd_conv2d_check": (_i, [C.POINTER(ConvParams)]),
     "codd_conv2d_packed_size": (_ll, [_i] * 6),
     "codd_conv2d_pack_weights": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "codd_tile_costvol_argmin": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _i, _p]),

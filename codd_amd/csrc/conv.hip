@@ -105,7 +105,7 @@ static int launch_conv(const ConvK& k, size_t lds, int grid, hipStream_t s) {
   static const bool debug = getenv("CODD_CONV_DEBUG") != nullptr;  // dev aid: resident workgroups per CU
   if (debug) {
     int nb = -1;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)conv_mfma_kernel<NW, NPB, MB, WREG, IREG>, NW * 64, lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)conv_mfma_kernel<NW, NPB, MB, WREG, IREG>, NW * 64, lds);
     fprintf(stderr, "conv<%d,%d,%d,%d,%d> grid %d lds %zu ck %d: %d workgroups/CU\n", NW, NPB, MB, WREG, IREG, grid, lds,
             k.p.ck, nb);
   }
@@ -164,7 +164,12 @@ static int launch_quad_any(const ConvK& k, int nw, size_t lds, int grid, hipStre
 
 /* staging limits the host heuristics must respect: <= 16 float4 of weights and <= 8 float4 of input
  * per thread and chunk (codd_conv2d returns CODD_EUNSUPPORTED otherwise) */
-int codd_conv2d_bf16(const codd_conv_params* pp, void* stream);  // conv_bf16.hip
+int codd_conv2d_bf16(const codd_conv_params* pp, void* stream, int dry_run);  // conv_bf16.hip
+
+extern "C" int codd_conv2d_check(const codd_conv_params* pp) {
+  if (!pp || pp->layout != 2) return CODD_EINVAL;
+  return codd_conv2d_bf16(pp, nullptr, 1);
+}
 
 extern "C" int codd_conv2d(const codd_conv_params* pp, void* stream) {
   if (!pp) return CODD_EINVAL;
@@ -174,7 +179,7 @@ extern "C" int codd_conv2d(const codd_conv_params* pp, void* stream) {
         q.Cout < 1 || q.kh < 1 || q.kw < 1 || q.pad_l < 0 || q.pad_t < 0)
       return CODD_EINVAL;
     if (q.store_mode && (q.kh != 1 || q.kw != 1 || q.res1.ptr || q.res2.ptr || q.post.ptr)) return CODD_EUNSUPPORTED;
-    return codd_conv2d_bf16(pp, stream);
+    return codd_conv2d_bf16(pp, stream, 0);
   }
   ConvK k;
   k.p = *pp;

@@ -4,27 +4,35 @@
 // Numerics.  TERMS = 3 ("split-bf16", the fp32-grade path): every fp32 operand x is split into two bf16 numbers
 //   hi = bf16_rne(x), lo = bf16_rne(x - hi)          (|x - hi - lo| <= 2^-18 |x|),
 // and a product a*b is evaluated as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi -- three bf16 MFMAs whose products are exact
-// in the fp32 accumulator; the dropped terms (a_lo*b_lo and the two split residuals) are <= 3 * 2^-18 |a b|, i.e.
-// about 16 mantissa bits per product against fp32's 24 (TF32, the reference's own CUDA conv arithmetic under
-// torch >= 1.12 defaults, keeps 10).  TERMS = 1 is the plain bf16-operand / fp32-accumulate path of
-// BASELINE.json configs[4].
+// in the fp32 accumulator; the dropped terms (a_lo*b_lo and the two split residuals) are <= 3 * 2^-18 |a b|
+// (measured on MI355X: max error 1e-6 of sum |w||x| against 3e-7 for the exact-fp32 kernels; TF32, the reference's
+// own CUDA conv arithmetic under torch >= 1.12 defaults, keeps 10 mantissa bits).  TERMS = 1 is the plain
+// bf16-operand / fp32-accumulate path of BASELINE.json configs[4].
 //
 // GEMM view (same roles as conv_kernel.h):  D[co, pixel] = sum_k W[co, k] X[k, pixel],  k = (tap, ci).
 //   A operand (16 x 32) = weights : lane (j = l&15, g = l>>4) holds W[co = j][entry g][8 channels]
 //   B operand (32 x 16) = im2col  : lane (j, g) holds X[entry g][8 channels][pixel j]
 //   D (16 x 16)                   : lane holds D[co = 4g + r][pixel = j], r = 0..3
-// A k-step consumes four ENTRIES; an entry is (tap, channel octet) in the order e = tap * noct + oct.  The LDS byte
+// A k-step consumes four ENTRIES; an entry is (tap, channel octet) in the order e = tap * noct + oct.  The LDS slot
 // offset of every entry is kept in a small table (built once per workgroup), so any (kh, kw, dilation, stride, ck)
 // runs through the same loop; entries beyond ntaps * noct point at entry 0 and carry zero weights.
 //
-// LDS images (16-byte slots = 8 bf16, one ds_read_b128 per operand fragment; hi and lo planes back to back):
-//   weights [plane][k-step][g][co (16 * mb)][8]        = the packed global layout, copied 16 bytes at a time
-//   input   [plane][octet][y][x][8]                    fp32 NCHW -> (hi, lo) converted while staging; the octet
-//                                                       stride is a multiple of 256 B so that the four 16-lane
-//                                                       groups of a ds_read_b128 never meet on a bank
-// Workgroup = PGW x CGW waves: wave (pg, cg) owns pixel units [pg*A, pg*A + A) (a unit = 16 consecutive pixels of
-// one tile row; the tile has th rows x xb units) and the B 16-channel blocks [cg*B, cg*B + B) of the workgroup's
-// 16*mb output channels (mb = B * CGW): A*B accumulator tiles per wave, (A + B) fragment reads per plane and k-step.
+// Workgroup = PGW x CGW CONSUMER waves + 4 PRODUCER waves (wave specialisation).  With the matrix pipe 5x faster
+// than on the fp32 path the kernel lives or dies by its staging, so staging gets its own waves:
+//   producers  global -> registers (issued two chunks ahead) -> bf16 split -> LDS buffer (c+1) & 1
+//   consumers  LDS buffer c & 1 -> operand fragments (read one k-step ahead) -> MFMA
+// one __syncthreads per chunk; a producer shares its SIMD with one consumer, so its VALU / LDS-write work runs in
+// the shadow of the consumer's MFMAs (separate pipes).
+// LDS images (16-byte slots = 8 bf16, one ds_read_b128 per operand fragment; hi and lo planes back to back; x2):
+//   weights [plane][k-step][g][co (16 * mb)][8]  = the packed global layout, copied 16 bytes at a time
+//   input   [plane][octet][y][x][8]              fp32 NCHW -> (hi, lo) while staging: a producer lane owns ONE pixel
+//                                                 and 8 channels (8 coalesced dword loads, 2 conflict-free 16-byte
+//                                                 LDS writes), so rows need no alignment; the octet stride is a
+//                                                 multiple of 256 B so the 16-lane groups of a ds_read_b128 never
+//                                                 meet on a bank
+// Consumer wave (pg, cg) owns pixel units [pg*A, pg*A + A) (a unit = 16 consecutive pixels of one tile row; the tile
+// has th rows x xb units) and the B 16-channel blocks [cg*B, cg*B + B) of the workgroup's 16*mb output channels
+// (mb = B * CGW): A*B accumulator tiles per wave, (A + B) fragment reads per plane and k-step.
 #include "conv_kernel.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -33,133 +41,286 @@ struct ConvB {
   codd_conv_params p;
   int cin, nchunks, ntaps, noct;  // noct = ck / 8 channel octets per chunk
   int nk;                         // k-steps per chunk = ceil(ntaps * noct / 4)
-  int th, tw, thi, twp, twp4, xoff;
+  int th, tw, thi, twi;           // tile: th x tw output pixels, thi x twi input pixels (halo)
   int pu, xb;                     // pixel units per tile (th * xb), units per tile row
-  int upo;                        // staging units (float4 columns) per octet = thi * twp4
-  int nunits;                     // noct * upo
+  int npix;                       // thi * twi
+  int nunits;                     // staging units per chunk = noct * npix (one pixel x 8 channels each)
   int os16;                       // 16-byte slots per octet plane of the input image (multiple of 16)
   int iplane16;                   // slots per precision plane of the input image = noct * os16
+  int ibuf16;                     // slots of one input buffer = planes * iplane16
   int wplane16;                   // slots per precision plane of the weight image = nk * 4 * nco
   int nco;                        // output channels per workgroup = 16 * mb
   int wslots;                     // slots of one (channel group, chunk) weight image = planes * wplane16
   int tiles_x, tiles_y, ncog, cout_eff;
-  int vec_ok;
 };
 
-__device__ __forceinline__ void split8(const float* v, bf16x8& h, bf16x8& l) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const __bf16 hh = (__bf16)v[i];
-    h[i] = hh;
-    l[i] = (__bf16)(v[i] - (float)hh);
-  }
+constexpr int CONVB_NWP = 4;  // producer waves per workgroup
+// dev ablations (tools/ubench/convb_ablate.hip): drop the weight DMA / the input loads
+#ifdef CONVB_NO_DMA
+#define CONVB_DMA_N(n) 0
+#else
+#define CONVB_DMA_N(n) (n)
+#endif
+#ifdef CONVB_NO_INPUT
+#define CONVB_IN_N(n) 0
+#else
+#define CONVB_IN_N(n) (n)
+#endif
+
+/* launch geometry of the split-bf16 kernel for layout-2 parameters: fills k, the dynamic LDS size and the grid.
+ * Field use: nw = tile rows, npb = 16-pixel units per tile row (1 or 2), mb = 16-channel blocks per workgroup,
+ * ck = channels per chunk (multiple of 8), pgw x cgw = consumer wave grid, terms = 1 | 3. */
+static inline int convb_geometry(const codd_conv_params* pp, ConvB& k, size_t& lds, long long& grid) {
+  k.p = *pp;
+  const codd_conv_params& p = k.p;
+  if (p.ck < 8 || (p.ck & 7) || !(p.terms == 1 || p.terms == 3) || p.nw < 1 || p.npb < 1 || p.npb > 2 ||
+      p.pgw < 1 || p.cgw < 1 || p.mb < 1 || p.mb % p.cgw)
+    return CODD_EINVAL;
+  const int planes = p.terms == 3 ? 2 : 1;
+  k.cin = p.C0 + p.C1;
+  k.ntaps = p.kh * p.kw;
+  k.noct = p.ck >> 3;
+  k.nchunks = cdiv(k.cin, p.ck);
+  k.nk = cdiv((long long)k.ntaps * k.noct, 4);
+  k.th = p.nw; k.xb = p.npb; k.pu = k.th * k.xb; k.tw = 16 * k.xb;
+  k.thi = (k.th - 1) * p.sy + (p.kh - 1) * p.dil_y + 1;
+  k.twi = (k.tw - 1) * p.sx + (p.kw - 1) * p.dil_x + 1;
+  k.npix = k.thi * k.twi;
+  k.nunits = k.noct * k.npix;
+  k.os16 = ((k.npix + 15) / 16) * 16;
+  k.iplane16 = k.noct * k.os16;
+  k.ibuf16 = planes * k.iplane16;
+  k.nco = 16 * p.mb;
+  k.wplane16 = k.nk * 4 * k.nco;
+  k.wslots = planes * k.wplane16;
+  k.tiles_x = cdiv(p.Wout, k.tw);
+  k.tiles_y = cdiv(p.Hout, k.th);
+  k.cout_eff = p.store_mode ? 4 * p.Cout : p.Cout;
+  k.ncog = cdiv(k.cout_eff, k.nco);
+  lds = (3 * (size_t)k.wslots + 2 * (size_t)k.ibuf16) * 16 + ((size_t)k.nk + 1) * 16;  // 3 weight + 2 input buffers + table
+  if (lds > 160 * 1024) return CODD_EUNSUPPORTED;
+  grid = (long long)k.tiles_x * k.tiles_y * k.ncog * p.B;
+  if (grid <= 0 || grid > 0x7fffffffLL) return CODD_EINVAL;
+  return CODD_OK;
 }
 
-template <int PGW, int CGW, int A, int B, int TERMS, int WREG, int QREG>
-__global__ __launch_bounds__(PGW * CGW * 64) void conv_bf16_kernel(const ConvB k) {
-  constexpr int NT = PGW * CGW * 64;
-  constexpr int NPL = TERMS == 1 ? 1 : 2;  // precision planes
+// Activation of one accumulator tile.  The cheap ones are inlined; the transcendental ones (a handful of small head
+// layers use them) go through ONE out-of-line copy -- inlined into all A*B unrolled tile epilogues they made the
+// kernel 170-220 KB of code.
+__device__ __attribute__((noinline)) f32x4 convb_act_slow(f32x4 v, int act) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], act, 1);
+  return v;
+}
+__device__ __forceinline__ f32x4 convb_act(f32x4 v, int act, int co) {
+  if (act == CODD_ACT_NONE) return v;
+  if (act == CODD_ACT_RELU || (act == CODD_ACT_RELU_CH0 && co == 0)) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    return v;
+  }
+  if (act == CODD_ACT_RELU_CH0) return v;
+  if (act == CODD_ACT_LRELU02) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
+    return v;
+  }
+  return convb_act_slow(v, act);
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate)
+__device__ __forceinline__ void convb_wait_vmcnt(int n) {
+#define CONVB_W1(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+#define CONVB_W8(N) CONVB_W1(N) CONVB_W1(N + 1) CONVB_W1(N + 2) CONVB_W1(N + 3) CONVB_W1(N + 4) CONVB_W1(N + 5) CONVB_W1(N + 6) CONVB_W1(N + 7)
+  switch (n) {
+    CONVB_W8(0) CONVB_W8(8) CONVB_W8(16) CONVB_W8(24) CONVB_W8(32) CONVB_W8(40) CONVB_W8(48)
+    default: break;  // >= 56 outstanding allowed: nothing to wait for (callers keep their queues shorter)
+  }
+#undef CONVB_W8
+#undef CONVB_W1
+}
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to LDS bytes [lds_dst, lds_dst + 1024).
+// Inline asm on purpose: hipcc drains vmcnt(0) in front of every LDS access that follows a __builtin LDS-DMA, which
+// would serialise the weight stream with the producers' own ds_writes; issued from asm the DMA is invisible to its
+// bookkeeping and the producers count the queue themselves (convb_wait_vmcnt).  M0 is written and restored inside the
+// statement (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void convb_dma16(const uint4* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// Compile-time interleave of one k-step: the NM MFMAs of the current fragment set with the NR LDS reads of the next
+// one (q_i MFMAs, then one read), so that the reads are in flight under the matrix pipe instead of in front of it.
+template <int I, int NR, int NM>
+struct ConvbSched {
+  static __device__ __forceinline__ void run() {
+    constexpr int q = ((I + 1) * NM) / NR - (I * NM) / NR;
+    if constexpr (q > 0) __builtin_amdgcn_sched_group_barrier(0x008, q, 0);  // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                      // DS read
+    if constexpr (I + 1 < NR) ConvbSched<I + 1, NR, NM>::run();
+  }
+};
+
+template <int PGW, int CGW, int A, int B, int TERMS, int QREG>
+__global__ __launch_bounds__((PGW * CGW + CONVB_NWP) * 64) void conv_bf16_kernel(const ConvB k) {
+  constexpr int NWC = PGW * CGW;          // consumer waves
+  constexpr int NTP = CONVB_NWP * 64;     // producer threads
+  constexpr int NPL = TERMS == 1 ? 1 : 2; // precision planes
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
-  uint4* wl = smem4;                              // weight image
-  uint4* il = smem4 + k.wslots;                   // input image
-  int* etab = (int*)(il + NPL * k.iplane16);      // entry table: slot offset of (k-step, g) inside an input plane
+  uint4* wl = smem4;                       // 3 weight buffers (the DMA runs two chunks ahead)
+  uint4* il = smem4 + 3 * k.wslots;        // 2 input buffers
+  int* etab = (int*)(il + 2 * k.ibuf16);   // entry table: slot offset of (k-step, g) inside an input plane
   const codd_conv_params& p = k.p;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 4, j = lane & 15;
-  const int cgi = wave % CGW, pgi = wave / CGW;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   int bid = blockIdx.x;
+#ifdef CONVB_XCD
+  {  // dev experiment: consecutive work items on ONE XCD (workgroup b runs on XCD b % 8)
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+#endif
+#ifdef CONVB_COG_FAST
+  const int cog = bid % k.ncog; bid /= k.ncog;
+  const int tx = bid % k.tiles_x; bid /= k.tiles_x;
+  const int ty = bid % k.tiles_y;
+  const int b = bid / k.tiles_y;
+#else
   const int tx = bid % k.tiles_x; bid /= k.tiles_x;
   const int ty = bid % k.tiles_y; bid /= k.tiles_y;
   const int cog = bid % k.ncog;
   const int b = bid / k.ncog;
+#endif
 
-  const int hwin = p.Hin * p.Win;
-  const int gy0 = ty * k.th * p.sy - p.pad_t;
-  const int gxs = tx * k.tw * p.sx - p.pad_l - k.xoff;  // 4-aligned start column (may be negative)
-
-  // ---- entry table (once) ----------------------------------------------------------------------------
-  for (int e = tid; e < k.nk * 4; e += NT) {
-    const int tap = e / k.noct, oct = e - tap * k.noct;
-    int off = 0;
-    if (tap < k.ntaps) {
-      const int ky = tap / p.kw, kx = tap - ky * p.kw;
-      off = oct * k.os16 + ky * p.dil_y * k.twp + kx * p.dil_x;
-    }
-    etab[e] = off;
-  }
-
-  // ---- per-thread staging units: (octet, row, float4 column) -------------------------------------------
-  int q_lds[QREG], q_g[QREG], q_c[QREG];
-  unsigned q_m[QREG];
-#pragma unroll
-  for (int r = 0; r < QREG; ++r) {
-    const int u = tid + r * NT;
-    q_c[r] = -1; q_m[r] = 0; q_lds[r] = 0; q_g[r] = 0;
-    if (u < k.nunits) {
-      const int oct = u / k.upo, rem = u - oct * k.upo;
-      const int y = rem / k.twp4, x4 = rem - y * k.twp4;
-      const int gy = gy0 + y, gx = gxs + 4 * x4;
-      unsigned m = 0;
-      if ((unsigned)gy < (unsigned)p.Hin) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) m |= ((unsigned)(gx + q) < (unsigned)p.Win) ? (1u << q) : 0u;
+  if (wave >= NWC) {
+    // =============================== producers ===============================
+    const int pt = tid - NWC * 64;
+    for (int e = pt; e < (k.nk + 1) * 4; e += NTP) {  // one spare row: the consumers fetch one k-step ahead
+      const int tap = e / k.noct, oct = e - tap * k.noct;
+      int off = 0;
+      if (e < k.nk * 4 && tap < k.ntaps) {
+        const int ky = tap / p.kw, kx = tap - ky * p.kw;
+        off = oct * k.os16 + ky * p.dil_y * k.twi + kx * p.dil_x;
       }
-      q_c[r] = 8 * oct; q_m[r] = m;
-      q_lds[r] = oct * k.os16 + y * k.twp + 4 * x4;
-      q_g[r] = gy * p.Win + gx;
+      etab[e] = off;
     }
-  }
-  uint4 wreg[WREG];
-  float4 ireg[QREG][8];
+    const int hwin = p.Hin * p.Win;
+    const int gy0 = ty * k.th * p.sy - p.pad_t;
+    const int gx0 = tx * k.tw * p.sx - p.pad_l;
+    // per-thread staging units: unit u = (octet, pixel of the halo tile); a unit is 8 channels of one pixel
+    int q_lds[QREG], q_g[QREG], q_c[QREG];  // LDS slot, offset inside a channel plane (-1: outside the image), first channel
+#pragma unroll
+    for (int r = 0; r < QREG; ++r) {
+      const int u = pt + r * NTP;
+      q_c[r] = -1; q_lds[r] = 0; q_g[r] = -1;
+      if (u < k.nunits) {
+        const int oct = u / k.npix, pix = u - oct * k.npix;
+        const int y = pix / k.twi, x = pix - y * k.twi;
+        const int gy = gy0 + y, gx = gx0 + x;
+        q_c[r] = 8 * oct;
+        q_lds[r] = oct * k.os16 + pix;
+        if ((unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win) q_g[r] = gy * p.Win + gx;
+      }
+    }
+    float ir0[QREG][8], ir1[QREG][8], ir2[QREG][8];  // input of three chunks in flight (loaded three phases ahead)
+    const int pw = wave - NWC;                      // producer wave index
+    const int nwv = k.wslots >> 6;                  // 1 KiB pieces of a weight image (wslots is a multiple of 64)
+    const int nd = (CONVB_DMA_N(nwv) - pw + CONVB_NWP - 1) / CONVB_NWP;  // DMA pieces this wave issues per chunk
+    constexpr int NL = CONVB_IN_N(QREG) * 8;        // register loads this wave issues per chunk
+    const unsigned wl_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint4*)wl;
 
-#define BF_ISSUE(CH)                                                                                      \
+    // weights: LDS-DMA, 1 KiB per wave-instruction, no registers (the image in global memory IS the LDS image)
+#define BF_DMA_W(CH, BUF)                                                                                 \
   {                                                                                                       \
-    const uint4* src_ = (const uint4*)p.wpacked + ((size_t)(cog * k.nchunks + (CH))) * k.wslots;          \
-    _Pragma("unroll") for (int r = 0; r < WREG; ++r) {                                                    \
-      const int e = tid + r * NT;                                                                         \
-      wreg[r] = e < k.wslots ? src_[e] : make_uint4(0u, 0u, 0u, 0u);                                      \
-    }                                                                                                     \
-    _Pragma("unroll") for (int r = 0; r < QREG; ++r) {                                                    \
-      _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                     \
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
-        const int cg = (CH) * p.ck + q_c[r] + c;                                                          \
-        if (q_c[r] >= 0 && q_m[r] && cg < k.cin) {                                                        \
-          const float* s_ =                                                                               \
-              (cg < p.C0 ? view_ptr(p.in0, b, cg, hwin) : view_ptr(p.in1, b, cg - p.C0, hwin)) + q_g[r];  \
-          if (q_m[r] == 0xFu && k.vec_ok) {                                                               \
-            v = *(const float4*)s_;                                                                       \
-          } else {                                                                                        \
-            if (q_m[r] & 1u) v.x = s_[0];                                                                 \
-            if (q_m[r] & 2u) v.y = s_[1];                                                                 \
-            if (q_m[r] & 4u) v.z = s_[2];                                                                 \
-            if (q_m[r] & 8u) v.w = s_[3];                                                                 \
-          }                                                                                               \
-        }                                                                                                 \
-        ireg[r][c] = v;                                                                                   \
+    const uint4* src_ = (const uint4*)p.wpacked + ((size_t)(cog * k.nchunks + (CH))) * k.wslots + lane;   \
+    const unsigned dst_ = wl_lds + (unsigned)(BUF) * (unsigned)k.wslots * 16u;                            \
+    for (int i_ = pw; i_ < CONVB_DMA_N(nwv); i_ += CONVB_NWP)                                             \
+      convb_dma16(src_ + i_ * 64, __builtin_amdgcn_readfirstlane(dst_ + (unsigned)i_ * 1024u));           \
+  }
+    // input: 8 coalesced dword loads per (pixel, octet) unit into registers ...
+#define BF_LOAD_I(IR, CH)                                                                                 \
+  {                                                                                                       \
+    const int c0_ = (CH) * p.ck;                                                                          \
+    _Pragma("unroll") for (int r_ = 0; r_ < CONVB_IN_N(QREG); ++r_) {                                     \
+      _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                  \
+        /* unconditional load from a clamped address + select: a "load or zero" branch per element would */ \
+        /* serialise the loads (s_cbranch around each, DESIGN.md finding 4) */                            \
+        const int cg_ = c0_ + q_c[r_] + i_;                                                               \
+        const bool ok_ = q_g[r_] >= 0 && q_c[r_] >= 0 && cg_ < k.cin;                                     \
+        const int cs_ = ok_ ? cg_ : 0;                                                                    \
+        const float* s_ = cs_ < p.C0 ? view_ptr(p.in0, b, cs_, hwin) : view_ptr(p.in1, b, cs_ - p.C0, hwin); \
+        IR[r_][i_] = s_[ok_ ? q_g[r_] : 0]; /* NO use of the value here: a select would wait for the load */ \
       }                                                                                                   \
     }                                                                                                     \
   }
-#define BF_COMMIT()                                                                                       \
+    // ... split into (hi, lo) bf16 and written as two 16-byte LDS slots two phases later
+#define BF_COMMIT_I(IR, BUF, CH)                                                                          \
   {                                                                                                       \
-    _Pragma("unroll") for (int r = 0; r < WREG; ++r) {                                                    \
-      const int e = tid + r * NT;                                                                         \
-      if (e < k.wslots) wl[e] = wreg[r];                                                                  \
-    }                                                                                                     \
-    _Pragma("unroll") for (int r = 0; r < QREG; ++r) if (q_c[r] >= 0) {                                   \
-      uint4* d_ = il + q_lds[r]; /* 4 pixels x 8 channels: register transpose + precision split */        \
-      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                     \
-        float v_[8];                                                                                      \
-        _Pragma("unroll") for (int c = 0; c < 8; ++c)                                                     \
-          v_[c] = q == 0 ? ireg[r][c].x : q == 1 ? ireg[r][c].y : q == 2 ? ireg[r][c].z : ireg[r][c].w;   \
-        bf16x8 h_, l_;                                                                                    \
-        split8(v_, h_, l_);                                                                               \
-        d_[q] = __builtin_bit_cast(uint4, h_);                                                            \
-        if (NPL == 2) d_[k.iplane16 + q] = __builtin_bit_cast(uint4, l_);                                 \
+    uint4* id_ = il + (BUF) * k.ibuf16;                                                                   \
+    const int c0_ = (CH) * p.ck;                                                                          \
+    _Pragma("unroll") for (int r_ = 0; r_ < QREG; ++r_) if (q_c[r_] >= 0) {                               \
+      bf16x8 h_, l_;                                                                                      \
+      _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                  \
+        /* padding pixels and channels past Cin were loaded from a clamped address: zero them here */     \
+        const float x_ = (q_g[r_] >= 0 && c0_ + q_c[r_] + i_ < k.cin) ? IR[r_][i_] : 0.f;                 \
+        const __bf16 hh_ = (__bf16)x_;                                                                    \
+        h_[i_] = hh_;                                                                                     \
+        l_[i_] = (__bf16)(x_ - (float)hh_);                                                               \
       }                                                                                                   \
+      id_[q_lds[r_]] = __builtin_bit_cast(uint4, h_);                                                     \
+      if (NPL == 2) id_[k.iplane16 + q_lds[r_]] = __builtin_bit_cast(uint4, l_);                          \
     }                                                                                                     \
   }
+    // Phase c (the consumers compute chunk c from weight buffer c % 3 and input buffer c & 1), in this order:
+    //   1. commit the input of chunk c+1 (registers loaded in phase c-2) to input buffer (c+1) & 1
+    //   2. load the input of chunk c+3 into the register set just freed
+    //   3. DMA the weights of chunk c+2 into weight buffer (c+2) % 3 (last read in phase c-1)
+    //   4. wait until the DMA of chunk c+1 (issued in phase c-1) has landed: everything issued in THIS phase may
+    //      stay in flight (vmcnt counts in order), then lgkmcnt(0) for the ds_writes, then the barrier.
+    // Every global access therefore has two full phases to complete (the round trip measured here is ~1.7 us, a
+    // phase ~1.4 us); hipcc's own waits for the register sets only see its loads and are conservative (never early).
+#define BF_PHASE(C, IRC, IRL, WB)                                                                         \
+  {                                                                                                       \
+    int out_ = 0;                                                                                         \
+    if ((C) + 1 < k.nchunks) BF_COMMIT_I(IRC, ((C) + 1) & 1, (C) + 1);                                             \
+    if ((C) + 3 < k.nchunks) { BF_LOAD_I(IRL, (C) + 3); out_ += NL; }                                     \
+    if ((C) + 2 < k.nchunks) { BF_DMA_W((C) + 2, WB); out_ += nd; }                                       \
+    convb_wait_vmcnt(out_);                                                                               \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
+    __builtin_amdgcn_s_barrier();                                                                         \
+  }
+#ifndef CONVB_NO_PRODUCER
+    BF_LOAD_I(ir0, 0);
+    if (k.nchunks > 1) BF_LOAD_I(ir1, 1);
+    if (k.nchunks > 2) BF_LOAD_I(ir2, 2);
+    BF_DMA_W(0, 0);
+    if (k.nchunks > 1) BF_DMA_W(1, 1);
+    BF_COMMIT_I(ir0, 0, 0);
+    convb_wait_vmcnt(k.nchunks > 1 ? nd : 0);  // chunk 0's weights landed (chunk 1's may still fly)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int c = 0; c < k.nchunks; c += 3) {
+      // register sets rotate with the chunk index mod 3: set (c+1)%3 is committed, set c%3 re-loaded
+      BF_PHASE(c, ir1, ir0, 2);
+      if (c + 1 >= k.nchunks) break;
+      BF_PHASE(c + 1, ir2, ir1, 0);
+      if (c + 2 >= k.nchunks) break;
+      BF_PHASE(c + 2, ir0, ir2, 1);
+    }
+#endif
+#undef BF_PHASE
+#undef BF_DMA_W
+#undef BF_LOAD_I
+#undef BF_COMMIT_I
+    return;
+  }
 
+  // ================================= consumers =================================
+  const int g = lane >> 4, j = lane & 15;
+  const int cgi = wave % CGW, pgi = wave / CGW;
   f32x4 acc[A][B];
 #pragma unroll
   for (int a = 0; a < A; ++a)
@@ -174,99 +335,157 @@ __global__ __launch_bounds__(PGW * CGW * 64) void conv_bf16_kernel(const ConvB k
     int u = pgi * A + a;
     if (u >= k.pu) u = k.pu - 1;
     const int prow = u / k.xb, pcol = (u - prow * k.xb) * 16 + j;
-    pbase[a] = prow * p.sy * k.twp + pcol * p.sx + k.xoff;
+    pbase[a] = prow * p.sy * k.twi + pcol * p.sx;
   }
-  const uint4* wlane = wl + (size_t)g * k.nco + cgi * B * 16 + j;  // + kstep * 4 * nco + m * 16
+  const int woff = g * k.nco + cgi * B * 16 + j;  // + kstep * 4 * nco + m * 16
   const int wstep = 4 * k.nco;
 
-  BF_ISSUE(0);
-  for (int ch = 0; ch < k.nchunks; ++ch) {
-    __syncthreads();  // every wave is done reading the previous chunk (and the entry table is written)
-    BF_COMMIT();
-    __syncthreads();
-    if (ch + 1 < k.nchunks) BF_ISSUE(ch + 1);
-    const uint4* wp = wlane;
-    for (int ks = 0; ks < k.nk; ++ks) {
-      const int eo = etab[ks * 4 + g];
-      bf16x8 ah[B], al[B], bh[A], bl[A];
-#pragma unroll
-      for (int m = 0; m < B; ++m) {
-        ah[m] = __builtin_bit_cast(bf16x8, wp[m * 16]);
-        if (TERMS == 3) al[m] = __builtin_bit_cast(bf16x8, wp[k.wplane16 + m * 16]);
-      }
-#pragma unroll
-      for (int a = 0; a < A; ++a) {
-        bh[a] = __builtin_bit_cast(bf16x8, il[eo + pbase[a]]);
-        if (TERMS == 3) bl[a] = __builtin_bit_cast(bf16x8, il[k.iplane16 + eo + pbase[a]]);
-      }
-      wp += wstep;
-#pragma unroll
-      for (int a = 0; a < A; ++a)
-#pragma unroll
-        for (int m = 0; m < B; ++m) {
-          if (TERMS == 3) {  // small terms first
-            acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh[a], acc[a][m], 0, 0, 0);
-            acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl[a], acc[a][m], 0, 0, 0);
-          }
-          acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[a], acc[a][m], 0, 0, 0);
-        }
-    }
+  struct Frag { bf16x8 ah[B], al[B], bh[A], bl[A]; };
+  // reads the fragments of k-step KS with the entry offset fetched one load earlier, and fetches the next offset
+  // (the table has one spare row), so that no ds_read_b128 waits for a dependent table read
+#define BF_LOAD(F, KS)                                                                                    \
+  {                                                                                                       \
+    const int eo_ = eo;                                                                                   \
+    eo = etab[((KS) + 1) * 4 + g];                                                                        \
+    const uint4* wp_ = wb + woff + (KS) * wstep;                                                          \
+    _Pragma("unroll") for (int m_ = 0; m_ < B; ++m_) {                                                    \
+      F.ah[m_] = __builtin_bit_cast(bf16x8, wp_[m_ * 16]);                                                \
+      if (TERMS == 3) F.al[m_] = __builtin_bit_cast(bf16x8, wp_[k.wplane16 + m_ * 16]);                   \
+    }                                                                                                     \
+    _Pragma("unroll") for (int a_ = 0; a_ < A; ++a_) {                                                    \
+      F.bh[a_] = __builtin_bit_cast(bf16x8, ib[eo_ + pbase[a_]]);                                         \
+      if (TERMS == 3) F.bl[a_] = __builtin_bit_cast(bf16x8, ib[k.iplane16 + eo_ + pbase[a_]]);            \
+    }                                                                                                     \
   }
-#undef BF_ISSUE
-#undef BF_COMMIT
+  // term-major order: consecutive MFMAs go to different accumulators (small terms first)
+#define BF_MFMA(F)                                                                                        \
+  {                                                                                                       \
+    if (TERMS == 3) {                                                                                     \
+      _Pragma("unroll") for (int a = 0; a < A; ++a) _Pragma("unroll") for (int m = 0; m < B; ++m)         \
+        acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bh[a], F.al[m], acc[a][m], 0, 0, 0);        \
+      _Pragma("unroll") for (int a = 0; a < A; ++a) _Pragma("unroll") for (int m = 0; m < B; ++m)         \
+        acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bl[a], F.ah[m], acc[a][m], 0, 0, 0);        \
+    }                                                                                                     \
+    _Pragma("unroll") for (int a = 0; a < A; ++a) _Pragma("unroll") for (int m = 0; m < B; ++m)           \
+      acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bh[a], F.ah[m], acc[a][m], 0, 0, 0);          \
+  }
 
-  // epilogue (as conv_mfma_kernel)
+  __syncthreads();  // chunk 0 and the entry table are in LDS
+#ifndef CONVB_NO_CONSUMER
+  const int klast = k.nk - 1;
+  constexpr int NRD = 1 + NPL * (A + B), NMF = TERMS * A * B;  // LDS reads / MFMAs per k-step
+  int wsel = 0;
+  for (int ch = 0; ch < k.nchunks; ++ch) {
+    const uint4* wb = wl + wsel * k.wslots;  // weight buffer ch % 3
+    const uint4* ib = il + (ch & 1) * k.ibuf16;
+    wsel = wsel == 2 ? 0 : wsel + 1;
+    // software pipeline over the k-steps, two register sets, no branch inside the loop body (hipcc can then count
+    // the outstanding LDS reads instead of draining them): the fragments of step s+1 are in flight while the MFMAs
+    // of step s issue.  A clamped (redundant) load replaces the conditional one at the end of the chunk.
+    Frag f0, f1;
+    int eo = etab[g];
+    BF_LOAD(f0, 0);
+    int ks = 0;
+    for (; ks + 1 < k.nk; ks += 2) {
+      BF_LOAD(f1, ks + 1);
+      BF_MFMA(f0);
+#ifndef CONVB_NO_SCHED
+      ConvbSched<0, NRD, NMF>::run();
+#endif
+      BF_LOAD(f0, ks + 2 < klast ? ks + 2 : klast);
+      BF_MFMA(f1);
+#ifndef CONVB_NO_SCHED
+      ConvbSched<0, NRD, NMF>::run();
+#endif
+    }
+    if (ks < k.nk) BF_MFMA(f0);
+    __syncthreads();  // every consumer is done with buffer ch & 1; the producers have filled the other one
+  }
+#endif
+#undef BF_LOAD
+#undef BF_MFMA
+
+#ifdef CONVB_NO_EPILOGUE
+  {  // dev ablation: one store per lane keeps the accumulators alive
+    float s_ = 0.f;
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+      for (int m = 0; m < B; ++m) s_ += acc[a][m][0] + acc[a][m][1] + acc[a][m][2] + acc[a][m][3];
+    p.out[(size_t)blockIdx.x * 256 + tid] = s_;
+    return;
+  }
+#endif
+  // epilogue.  The MFMA is issued with the im2col fragment as its first operand, so D[m = pixel 4g + r][n = co j]:
+  // a lane holds FOUR CONSECUTIVE PIXELS of one output channel -- bias is one value per tile, residual / output
+  // accesses are 16-byte vectors (4x fewer memory instructions than a channel-major accumulator layout)
   const int hwout = p.Hout * p.Wout;
+  const bool vec = (p.Wout & 3) == 0 && p.store_mode == 0;
 #pragma unroll
   for (int a = 0; a < A; ++a) {
     const int u = pgi * A + a;
     if (u >= k.pu) continue;
     const int prow = u / k.xb;
     const int oy = ty * k.th + prow;
-    const int ox = tx * k.tw + (u - prow * k.xb) * 16 + j;
+    const int ox = tx * k.tw + (u - prow * k.xb) * 16 + 4 * g;
     if (oy >= p.Hout || ox >= p.Wout) continue;
     const int pix = oy * p.Wout + ox;
 #pragma unroll
     for (int m = 0; m < B; ++m) {
+      const int co = (cog * CGW * B + cgi * B + m) * 16 + j;
+      if (co >= k.cout_eff) continue;
+      f32x4 v = acc[a][m];
+      if (p.store_mode == 0) {
+        if (p.bias) v += p.bias[co];
+        float* op = p.out + ((size_t)b * p.out_ctot + p.out_coff + co) * (size_t)hwout + pix;
+        if (vec) {  // ox + 3 < Wout: ox and Wout are multiples of 4
+          if (p.res1.ptr) v += *(const f32x4*)(view_ptr(p.res1, b, co, hwout) + pix);
+          if (p.res2.ptr) v += *(const f32x4*)(view_ptr(p.res2, b, co, hwout) + pix);
+          v = convb_act(v, p.act, co);
+          if (p.post.ptr) v += *(const f32x4*)(view_ptr(p.post, b, co, hwout) + pix);
+          *(f32x4*)op = v;
+        } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = (cog * CGW * B + cgi * B + m) * 16 + 4 * g + r;
-        if (co >= k.cout_eff) continue;
-        float v = acc[a][m][r];
-        if (p.store_mode == 0) {
-          if (p.bias) v += p.bias[co];
-          if (p.res1.ptr) v += view_ptr(p.res1, b, co, hwout)[pix];
-          if (p.res2.ptr) v += view_ptr(p.res2, b, co, hwout)[pix];
-          v = act_apply(v, p.act, co);
-          if (p.post.ptr) v += view_ptr(p.post, b, co, hwout)[pix];
-          p.out[((size_t)b * p.out_ctot + p.out_coff + co) * (size_t)hwout + pix] = v;
-        } else {  // ConvTranspose2d k=2 s=2: co = (a2*2+b2)*Cout + c
-          const int q = co / p.Cout, c = co - q * p.Cout;
-          if (p.bias) v += p.bias[c];
-          v = act_apply(v, p.act, c);
-          const int W2 = 2 * p.Wout;
-          p.out[((size_t)b * p.out_ctot + p.out_coff + c) * (size_t)(4 * hwout) +
-                (size_t)(2 * oy + (q >> 1)) * W2 + 2 * ox + (q & 1)] = v;
+          for (int r = 0; r < 4; ++r)
+            if (ox + r < p.Wout) {
+              if (p.res1.ptr) v[r] += view_ptr(p.res1, b, co, hwout)[pix + r];
+              if (p.res2.ptr) v[r] += view_ptr(p.res2, b, co, hwout)[pix + r];
+            }
+          v = convb_act(v, p.act, co);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (ox + r < p.Wout) op[r] = v[r] + (p.post.ptr ? view_ptr(p.post, b, co, hwout)[pix + r] : 0.f);
         }
+      } else {  // ConvTranspose2d k=2 s=2: co = (a2*2+b2)*Cout + c
+        const int q = co / p.Cout, c = co - q * p.Cout;
+        if (p.bias) v += p.bias[c];
+        v = convb_act(v, p.act, c);
+        const int W2 = 2 * p.Wout;
+        float* op = p.out + ((size_t)b * p.out_ctot + p.out_coff + c) * (size_t)(4 * hwout) +
+                    (size_t)(2 * oy + (q >> 1)) * W2 + (q & 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (ox + r < p.Wout) op[2 * (ox + r)] = v[r];
       }
     }
   }
 }
 
-// ---- instantiation list: X(PGW, CGW, A, B, WREG, QREG), each for TERMS = 1 and 3 ----------------------------
+// ---- instantiation list: X(PGW, CGW, A, B, QREG), each for TERMS = 1 and 3 -------------------------------------
 //   (2,2,5,2): 9/10-unit tiles x 64 channels (the 72x120 GRU maps: 256 workgroups of 144 px x 64 co)
 //   (4,1,4,4) / (4,1,4,2) / (4,1,4,1): 16-unit tiles (8 x 32 px) x 64 / 32 / 16 channels
 //   (4,1,2,2) / (4,1,2,1): 8-unit tiles (4 x 32 or 8 x 16 px) x 32 / 16 channels (small maps)
 //   (4,1,8,1): 32-unit tiles (16 x 32 px) x 16 channels (full-resolution 16-channel layers)
-#define CONVB_GROUP_A(X) X(2, 2, 5, 2, 10, 1) X(2, 2, 5, 2, 20, 2)
-#define CONVB_GROUP_B(X) X(4, 1, 4, 4, 10, 2) X(4, 1, 4, 4, 20, 3)
-#define CONVB_GROUP_C(X) X(4, 1, 4, 2, 6, 2) X(4, 1, 4, 2, 12, 3)
-#define CONVB_GROUP_D(X) X(4, 1, 4, 1, 4, 2) X(4, 1, 8, 1, 4, 4)
-#define CONVB_GROUP_E(X) X(4, 1, 2, 2, 6, 1) X(4, 1, 2, 2, 12, 2) X(4, 1, 2, 1, 4, 1) X(4, 1, 2, 1, 8, 2)
+// QREG = (pixel, octet) staging units per producer thread and chunk (8 VGPRs each)
+#define CONVB_GROUP_A(X) X(2, 2, 5, 2, 2) X(2, 2, 5, 2, 6)
+#define CONVB_GROUP_B(X) X(4, 1, 4, 4, 3) X(4, 1, 4, 4, 6)
+#define CONVB_GROUP_C(X) X(4, 1, 4, 2, 3) X(4, 1, 4, 2, 6)
+#define CONVB_GROUP_D(X) X(4, 1, 4, 1, 3) X(4, 1, 8, 1, 6)
+#define CONVB_GROUP_E(X) X(4, 1, 2, 2, 2) X(4, 1, 2, 2, 8) X(4, 1, 2, 1, 2) X(4, 1, 2, 1, 8)
 #define CONVB_ALL(X) CONVB_GROUP_A(X) CONVB_GROUP_B(X) CONVB_GROUP_C(X) CONVB_GROUP_D(X) CONVB_GROUP_E(X)
-#define CONVB_DECLARE(PGW, CGW, A, B, WREG, QREG)                                                     \
-  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, WREG, QREG>(const ConvB);      \
-  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, WREG, QREG>(const ConvB);
-#define CONVB_DEFINE(PGW, CGW, A, B, WREG, QREG)                                                      \
-  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, WREG, QREG>(const ConvB);             \
-  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, WREG, QREG>(const ConvB);
+#define CONVB_DECLARE(PGW, CGW, A, B, QREG)                                                     \
+  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, QREG>(const ConvB);      \
+  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, QREG>(const ConvB);
+#define CONVB_DEFINE(PGW, CGW, A, B, QREG)                                                      \
+  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, QREG>(const ConvB);             \
+  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, QREG>(const ConvB);

@@ -79,7 +79,19 @@ class PackedConv:
         self.tuned = {}  # launch shape -> (npb, nw, ck)
 
     def packed(self, ck, mb=None, layout=0):
+        """layout 0 / 1: fp32 kernels; 20 + terms (21 | 23): split-bf16 kernel with 1 | 3 product terms."""
         mb = self.mb if mb is None else mb
+        if layout >= 20 and (mb, ck, layout) not in self._packs:
+            lib = _abi.load()
+            terms = layout - 20
+            n = lib.codd_conv2d_packed_bytes_bf16(self.cout_eff, self.cin, self.kh, self.kw, mb, ck, terms)
+            if n <= 0:
+                raise _abi.CoddHipError("no split-bf16 packed layout for ck=%d mb=%d terms=%d" % (ck, mb, terms))
+            wp = torch.empty(n, device=self._w.device, dtype=torch.uint8)
+            _abi.check(lib.codd_conv2d_pack_weights_bf16(self._w.data_ptr(), wp.data_ptr(), self.cout_eff, self.cin,
+                                                         self.kh, self.kw, mb, ck, terms, self.cin * self.kh * self.kw,
+                                                         self.kh * self.kw, 1.0, _stream()), "pack_weights_bf16")
+            self._packs[(mb, ck, layout)] = wp
         if (mb, ck, layout) not in self._packs:
             lib = _abi.load()
             size, pack = ((lib.codd_conv2d_packed_size_quad, lib.codd_conv2d_pack_weights_quad) if layout == 1 else
@@ -94,7 +106,8 @@ class PackedConv:
         return self._packs[(mb, ck, layout)]
 
     def _pack_key(self, c):
-        return (c[3] if len(c) > 3 else self.mb, c[2], c[4] if len(c) > 4 else 0)
+        lay = c[4] if len(c) > 4 else 0
+        return (c[3] if len(c) > 3 else self.mb, c[2], 20 + c[7] if lay == 2 else lay)
 
     def drop_unused_packs(self):
         """Free the packed-weight variants no tuned configuration refers to (after autotuning)."""
@@ -171,6 +184,54 @@ def _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl):
     return npb, nw, ck
 
 
+# Arithmetic of the convolution family (include/codd_hip.h, codd_conv_params.layout / terms):
+#   "split" (default)  split-bf16 operands, three bf16 MFMAs per product, fp32 accumulate (fp32-grade: the parity
+#                      tests at the benchmarked configurations bound its effect on the disparities)
+#   "fp32"             exact-fp32 MFMA kernels (v_mfma_f32_16x16x4_f32)
+#   "bf16"             bf16 operands, fp32 accumulate (BASELINE.json configs[4]; reference auto_fp16 hook)
+CONV_PRECISION = _os.environ.get("CODD_CONV_PRECISION", "split")
+_TERMS = dict(split=3, bf16=1)
+
+
+def set_conv_precision(mode):
+    global CONV_PRECISION
+    if mode not in ("split", "fp32", "bf16"):
+        raise ValueError("conv precision must be 'split', 'fp32' or 'bf16'")
+    prev, CONV_PRECISION = CONV_PRECISION, mode
+    return prev
+
+
+# split-bf16 kernel instantiations (conv_bf16_kernel.h): (pgw, cgw, A, B) and the tiles (rows, units per row) tried
+_B_INST = ((2, 2, 5, 2), (4, 1, 4, 4), (4, 1, 4, 2), (4, 1, 4, 1), (4, 1, 8, 1), (4, 1, 2, 2), (4, 1, 2, 1))
+_B_TILES = {5: ((9, 1), (10, 1), (5, 2)), 4: ((8, 2), (16, 1)), 8: ((16, 2),), 2: ((4, 2), (8, 1))}
+
+
+def _bf16_candidates(pc, Hout, Wout, B, taps, terms):
+    """Launch configurations (xb, th, ck, mb, 2, pgw, cgw, terms) of the split-bf16 kernel for this layer, best guess first:
+    fewest dispatch rounds over the 256 CUs times work per workgroup, larger channel groups and deeper chunks first."""
+    nblk = -(-pc.cout_eff // 16)
+    cands = []
+    for (pgw, cgw, a, b) in _B_INST:
+        mb = b * cgw
+        if mb > 1 and mb // 2 >= nblk:  # a channel group at least twice as wide as the layer
+            continue
+        for (th, xb) in _B_TILES[a]:
+            grid = -(-Hout // th) * -(-Wout // (16 * xb)) * -(-pc.cout_eff // (16 * mb)) * B
+            rounds = -(-grid // 256)
+            cost = rounds * (pgw * a) * mb
+            cands.append((cost, -mb, -th * xb, (xb, th, mb, pgw, cgw)))
+    cands.sort()
+    cin8 = -(-pc.cin // 8) * 8
+    cks = [c for c in ((128, 64, 32, 16, 8) if taps == 1 else (32, 16, 8)) if c <= max(8, cin8)]
+    if not cks or cks[0] < min(cin8, 32):
+        cks.insert(0, min(cin8, 32))
+    out = []
+    for _, _, _, (xb, th, mb, pgw, cgw) in cands:
+        for ck in cks:
+            out.append((xb, th, ck, mb, 2, pgw, cgw, terms))
+    return out
+
+
 def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=None, post=None,
            out=None, pad_tl=None, out_hw=None):
     """act(conv(cat[x, x2]) + bias + res1 + res2) + post  ->  out (tensor or Slice)."""
@@ -203,27 +264,27 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
         out = torch.empty(B, pc.cout, Hout * up, Wout * up, device=xs.buf.device, dtype=torch.float32)
     os_ = _as_slice(out)
     assert os_.shape == (B, pc.cout, Hout * up, Wout * up), (os_.shape, (B, pc.cout, Hout * up, Wout * up))
-    key = (Hout, Wout, B, sy, sx, dy, dx, pl, C1 > 0)
+    terms = _TERMS.get(CONV_PRECISION, 0)
+    key = (Hout, Wout, B, sy, sx, dy, dx, pl, C1 > 0, terms)
     cfg = pc.tuned.get(key)
     tune = False
     if cfg is None:
-        sig = "%d,%d,%d,%d,%d,%d|" % (pc.cout_eff, pc.cin, pc.kh, pc.kw, pc.mb, int(pc.deconv)) + ",".join(
-            str(int(v)) for v in key)
+        sig = ("b%d|" % terms if terms else "") + "%d,%d,%d,%d,%d,%d|" % (
+            pc.cout_eff, pc.cin, pc.kh, pc.kw, pc.mb, int(pc.deconv)) + ",".join(str(int(v)) for v in key[:-1])
         if _AUTOTUNE and sig in TUNE_DB:  # same layer signature already timed (this process or a loaded file)
             cfg = pc.tuned[key] = tuple(TUNE_DB[sig])
+        elif terms:
+            cfg = None  # first candidate the library accepts (below)
+            tune = _AUTOTUNE and not torch.cuda.is_current_stream_capturing()
         else:
             cfg = _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl)
             tune = _AUTOTUNE and not torch.cuda.is_current_stream_capturing()
             if not _AUTOTUNE or tune:
                 pc.tuned[key] = cfg  # (while capturing with autotune on: heuristic for this launch, tune later)
-    npb, nw, ck = cfg[:3]
-    mb = cfg[3] if len(cfg) > 3 else pc.mb
-    layout = cfg[4] if len(cfg) > 4 else 0
     p = ConvParams()
     p.in0 = _view(xs)
     p.in1 = _view(x2)
     p.C0, p.C1, p.B, p.Hin, p.Win = C0, C1, B, Hin, Win
-    p.wpacked = pc.packed(ck, mb, layout).data_ptr()
     p.bias = None if pc.bias is None else pc.bias.data_ptr()
     p.res1, p.res2, p.post = _view(res1), _view(res2), _view(post)
     p.out, p.out_ctot, p.out_coff = os_.buf.data_ptr(), os_.buf.shape[1], os_.coff
@@ -231,6 +292,25 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
     p.kh, p.kw, p.sy, p.sx, p.pad_t, p.pad_l, p.dil_y, p.dil_x = pc.kh, pc.kw, sy, sx, pt, pl, dy, dx
     p.act = ACT[act]
     p.store_mode = 1 if pc.deconv else 0
+    p.terms = terms
+    if terms:  # split-bf16 / bf16 kernel
+        if cfg is None:
+            cands = _bf16_candidates(pc, Hout, Wout, B, pc.kh * pc.kw, terms)
+            if tune:
+                cfg = TUNE_DB[sig] = _autotune_b(lib, p, pc, cands)
+            else:
+                cfg = next((c for c in cands if _cfg_ok(lib, p, c)), None)
+                if cfg is None:
+                    raise _abi.CoddHipError("no split-bf16 launch configuration for conv %dx%d %d->%d" % (
+                        pc.kh, pc.kw, pc.cin, pc.cout))
+            pc.tuned[key] = cfg
+        _set_cfg(p, pc, cfg)
+        _abi.check(_launch_conv(lib, p, _stream()), "codd_conv2d")
+        return out
+    npb, nw, ck = cfg[:3]
+    mb = cfg[3] if len(cfg) > 3 else pc.mb
+    layout = cfg[4] if len(cfg) > 4 else 0
+    p.wpacked = pc.packed(ck, mb, layout).data_ptr()
     p.mb, p.npb, p.nw, p.ck, p.layout = mb, npb, nw, ck, layout
     if tune:
         npb, nw, ck, mb, layout = pc.tuned[key] = TUNE_DB[sig] = _autotune(lib, p, pc, (npb, nw, ck, mb, layout))
@@ -249,6 +329,58 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
         rc = _launch_conv(lib, p, _stream())
     _abi.check(rc, "codd_conv2d")
     return out
+
+
+def _cfg_ok(lib, p, c):
+    """Does the library accept split-bf16 configuration ``c`` for the layer described by ``p``? (nothing is launched)"""
+    p.npb, p.nw, p.ck, p.mb, p.layout, p.pgw, p.cgw = c[:7]
+    return lib.codd_conv2d_check(C.byref(p)) == 0
+
+
+def _set_cfg(p, pc, c):
+    """Fill the launch-configuration fields of ``p`` from a split-bf16 configuration tuple."""
+    xb, th, ck, mb, _, pgw, cgw = c[:7]
+    p.wpacked = pc.packed(ck, mb, 20 + p.terms).data_ptr()
+    p.mb, p.npb, p.nw, p.ck, p.layout, p.pgw, p.cgw = mb, xb, th, ck, 2, pgw, cgw
+
+
+def _autotune_b(lib, p, pc, cands):
+    """Time every split-bf16 candidate the library accepts (scratch output, see _autotune) and keep the fastest."""
+    stream = _stream()
+    real_out = p.out
+    scratch_out = torch.empty(p.B * p.out_ctot * (4 if p.store_mode else 1) * p.Hout * p.Wout, device=pc._w.device,
+                              dtype=torch.float32)
+    p.out = scratch_out.data_ptr()
+    torch.cuda.synchronize()
+    best, best_t, first = None, float("inf"), None
+    cands = [c for c in cands if _cfg_ok(lib, p, c)]
+    for c in cands[:1] + cands:  # first candidate twice: the first pass warms clocks / caches
+        _set_cfg(p, pc, c)
+        if _launch_conv(lib, p, stream) != 0:
+            continue
+        t = float("inf")
+        for _rep in range(2):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(3):
+                _launch_conv(lib, p, stream)
+            e.record()
+            e.synchronize()
+            t = min(t, s.elapsed_time(e) / 3.0)
+        if first is None:
+            first = (c, t)
+            continue
+        if t < best_t * 0.97 or best is None:
+            best, best_t = c, t
+    p.out = real_out
+    if best is None:
+        raise _abi.CoddHipError("no split-bf16 launch configuration for conv %dx%d %d->%d" % (pc.kh, pc.kw, pc.cin, pc.cout))
+    used = {pc._pack_key(c) for c in pc.tuned.values()} | {pc._pack_key(best)}
+    for k in [k for k in pc._packs if k not in used]:
+        del pc._packs[k]
+    AUTOTUNE_LOG.append(("b%d %dx%d k%dx%d %d->%d out %dx%d" % (p.terms, p.sy, p.sx, pc.kh, pc.kw, pc.cin, pc.cout, p.Hout,
+                                                                p.Wout), first[0], first[1] * 1e3, best, best_t * 1e3))
+    return best
 
 
 _AUTOTUNE = bool(int(_os.environ.get("CODD_AUTOTUNE", "0")))

@@ -89,6 +89,10 @@ typedef struct {
 } codd_conv_params;
 
 int codd_conv2d(const codd_conv_params* p, void* stream);
+/* layout 2 only: CODD_OK if codd_conv2d would accept this launch configuration (tile, chunk depth, wave grid: LDS
+ * and register-staging limits of the instantiated kernels), CODD_EUNSUPPORTED otherwise.  Launches nothing and reads
+ * no pointer field: callers probe candidate configurations before packing weights for them. */
+int codd_conv2d_check(const codd_conv_params* p);
 
 /* quad layout (layout = 1): four input channels innermost, [cog][chunk][tap][c/4][co][4] */
 long long codd_conv2d_packed_size_quad(int Cout, int Cin, int kh, int kw, int mb, int ck);

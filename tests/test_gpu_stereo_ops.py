@@ -45,8 +45,21 @@ def _act(v, act):
                 tanh=torch.tanh, mish=F.mish)[act](v)
 
 
+# precision mode of the conv family -> tolerance relative to the output scale (fp32: fma chains vs MKL-DNN;
+# split: three-term split-bf16 products, ~2^-17 per product; bf16: 2^-9 per operand)
+PRECISIONS = [("fp32", 2e-4), ("split", 2e-4), ("bf16", 3e-2)]
+
+
+@pytest.fixture(params=PRECISIONS, ids=[p[0] for p in PRECISIONS])
+def precision(request):
+    from codd_amd import ops
+    prev = ops.set_conv_precision(request.param[0])
+    yield request.param
+    ops.set_conv_precision(prev)
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv2d(case):
+def test_conv2d(case, precision):
     from codd_amd import ops
     cin, cout, k, s, p, d, H, W, act = case
     x, w, b = rnd(2, cin, H, W), rnd(cout, cin, k, k, seed=1) / (cin * k * k) ** 0.5, rnd(cout, seed=2) * 0.1
@@ -55,10 +68,46 @@ def test_conv2d(case):
     got = ops.conv2d(x.to(dev()), pc, stride=s, pad=p, dil=d, act=act).cpu()
     assert got.shape == ref.shape
     err = (got - ref).abs().max().item()
-    assert err < 2e-4 * max(1.0, ref.abs().max().item()), err
+    assert err < precision[1] * max(1.0, ref.abs().max().item()), err
 
 
-def test_conv2d_views_residuals():
+def test_split_bf16_conv_every_launch_configuration():
+    """Every (tile, chunk depth, wave grid) the library accepts for a layer gives the same result to the split-bf16
+    bound: |err| <= 3 * 2^-18 * sum |w||x| per output (dropped lo*lo term + the two split residuals), checked against
+    an fp64 reference; and terms = 1 (plain bf16 operands) to 2^-8 * sum |w||x|."""
+    from codd_amd import _abi, ops
+    lib = _abi.load()
+    for (cin, cout, k, s, p, d, H, W) in [(40, 64, 3, 1, 1, 1, 27, 40), (16, 16, 3, 1, 1, 1, 48, 64),
+                                         (24, 40, 3, 2, 1, 1, 32, 64), (72, 130, 1, 1, 0, 1, 20, 33)]:
+        x, w, b = rnd(1, cin, H, W), rnd(cout, cin, k, k, seed=1) / (cin * k * k) ** 0.5, rnd(cout, seed=2) * 0.1
+        ref = F.conv2d(x.double(), w.double(), b.double(), s, p, d)
+        mag = F.conv2d(x.abs().double(), w.abs().double(), None, s, p, d)
+        Ho, Wo = ref.shape[2:]
+        pc = ops.PackedConv(w.to(dev()), b.to(dev()))
+        for terms, bound in ((3, 3.5 * 2.0 ** -18), (1, 2.0 ** -8)):
+            prev = ops.set_conv_precision("split" if terms == 3 else "bf16")
+            try:
+                n = 0
+                for c in ops._bf16_candidates(pc, Ho, Wo, 1, k * k, terms):
+                    pp = _abi.ConvParams()
+                    pp.C0, pp.C1, pp.B, pp.Hin, pp.Win, pp.Cout, pp.Hout, pp.Wout = cin, 0, 1, H, W, cout, Ho, Wo
+                    pp.kh, pp.kw, pp.sy, pp.sx, pp.pad_t, pp.pad_l, pp.dil_y, pp.dil_x = k, k, s, s, p, p, d, d
+                    pp.terms = terms
+                    if not ops._cfg_ok(lib, pp, c):
+                        continue
+                    pc.tuned.clear()
+                    pc.tuned[(Ho, Wo, 1, s, s, d, d, p, False, terms)] = c
+                    out = torch.full((1, cout, Ho, Wo), float("nan"), device=dev())
+                    ops.conv2d(x.to(dev()), pc, stride=s, pad=p, dil=d, out=out)
+                    err = ((out.cpu().double() - ref).abs() / (mag + 1e-6)).max().item()
+                    assert err < bound + 2e-7, (c, terms, err)
+                    n += 1
+                assert n >= 3, n
+            finally:
+                ops.set_conv_precision(prev)
+
+
+def test_conv2d_views_residuals(precision):
     from codd_amd import ops
     from codd_amd.ops import Slice
     xa, xb = rnd(1, 24, 36, 60), rnd(1, 16, 36, 60, seed=3)
@@ -72,36 +121,36 @@ def test_conv2d_views_residuals():
     ops.conv2d(Slice(big_in.to(dev()), 8, 24), pc, x2=xb.to(dev()), pad=1, act="relu", res1=r1.to(dev()),
                res2=r2.to(dev()), post=post.to(dev()), out=Slice(out, 10, 32))
     out = out.cpu()
-    assert (out[:, 10:42] - ref).abs().max().item() < 2e-4 * ref.abs().max().item()
+    assert (out[:, 10:42] - ref).abs().max().item() < precision[1] * ref.abs().max().item()
     assert (out[:, :10] == -7).all() and (out[:, 42:] == -7).all()
 
 
-def test_conv_right_pad_stride41_and_relu_ch0():
+def test_conv_right_pad_stride41_and_relu_ch0(precision):
     from codd_amd import ops
     x, w, b = rnd(1, 16, 32, 64), rnd(16, 16, 4, 4, seed=1) / 16.0, rnd(16, seed=2) * 0.1
     ref = F.leaky_relu(F.conv2d(F.pad(x, (0, 3, 0, 0)), w, b, (4, 1)), 0.2)
     pc = ops.PackedConv(w.to(dev()), b.to(dev()))
     got = ops.conv2d(x.to(dev()), pc, stride=(4, 1), pad_tl=(0, 0, 0, 3), act="lrelu").cpu()
     assert got.shape == ref.shape == (1, 16, 8, 64)
-    assert (got - ref).abs().max().item() < 2e-4
+    assert (got - ref).abs().max().item() < precision[1] * 3
     w3 = rnd(16, 16, 3, 3, seed=3) / 12.0
     res = rnd(1, 16, 32, 64, seed=4)
     ref = F.conv2d(x, w3, b, 1, 1) + res
     ref[:, :1] = F.relu(ref[:, :1])
     got = ops.conv2d(x.to(dev()), ops.PackedConv(w3.to(dev()), b.to(dev())), pad=1, res1=res.to(dev()),
                      act="relu_ch0").cpu()
-    assert (got - ref).abs().max().item() < 2e-4
+    assert (got - ref).abs().max().item() < precision[1] * 3
 
 
 @pytest.mark.parametrize("cin,cout,H,W", [(32, 24, 9, 15), (16, 16, 72, 120), (24, 16, 36, 60)])
-def test_deconv2x2(cin, cout, H, W):
+def test_deconv2x2(cin, cout, H, W, precision):
     from codd_amd import ops
     x, w, b = rnd(2, cin, H, W), rnd(cin, cout, 2, 2, seed=1) / cin ** 0.5, rnd(cout, seed=2) * 0.1
     ref = F.leaky_relu(F.conv_transpose2d(x, w, b, stride=2), 0.2)
     pc = ops.PackedConv(w.to(dev()), b.to(dev()), deconv=True)
     got = ops.conv2d(x.to(dev()), pc, act="lrelu").cpu()
     assert got.shape == ref.shape
-    assert (got - ref).abs().max().item() < 2e-4
+    assert (got - ref).abs().max().item() < precision[1] * 3
 
 
 @pytest.mark.parametrize("Ht,Wt,D", [(9, 15, 20), (18, 30, 40), (16, 32, 80), (36, 60, 320)])
@@ -183,13 +232,18 @@ def test_c_abi_error_codes_are_loud():
     p = _abi.ConvParams()
     C.memset(C.byref(p), 0, C.sizeof(p))
     assert lib.codd_conv2d(C.byref(p), None) == -1  # CODD_EINVAL: no input / output / weights
-    old = ops._FORCE_NW
+    old, prev = ops._FORCE_NW, ops.set_conv_precision("fp32")
     ops._FORCE_NW = 7  # not an instantiated workgroup height
     try:
         with pytest.raises(_abi.CoddHipError, match="-2"):  # CODD_EUNSUPPORTED
             ops.conv2d(x, pc, pad=1)
+        ops.set_conv_precision("split")
+        pc.tuned[(16, 32, 1, 1, 1, 1, 1, 1, False, 3)] = (2, 7, 16, 2, 2, 4, 1, 3)  # 7-row tiles: not instantiated
+        with pytest.raises(_abi.CoddHipError, match="-2"):
+            ops.conv2d(x, pc, pad=1)
     finally:
         ops._FORCE_NW = old
+        ops.set_conv_precision(prev)
     assert lib.codd_tile_costvol_argmin(None, None, 1, 16, 4, 8, 32, 4, None, 1, 0, None, 1, 0, 4, None) == -1
     with pytest.raises(_abi.CoddHipError):
         ops.conv2d(x.cpu(), pc, pad=1)  # host tensor: the product path has no CPU fallback
@@ -300,18 +354,34 @@ def test_tunable_configurations_with_views_and_two_inputs():
     ref = F.relu(F.conv2d(torch.cat([big[:, 6:30], x2], 1), w, b, padding=1) + res) + post
     bd, x2d, resd, postd = big.to("cuda"), x2.to("cuda"), res.to("cuda"), post.to("cuda")
     pc = ops.PackedConv(w.to("cuda"), b.to("cuda"))
-    key = (H, W, 1, 1, 1, 1, 1, 1, True)
+    key = (H, W, 1, 1, 1, 1, 1, 1, True, 0)
     n = 0
-    for cfg in [(1, 4, 12, 2, 0), (2, 4, 8, 1, 0), (1, 9, 16, 2, 0), (1, 2, 8, 2, 0), (1, 8, 16, 1, 0),
-                (1, 4, 16, 2, 1), (2, 4, 16, 2, 1), (1, 9, 16, 2, 1), (1, 4, 32, 1, 1), (4, 4, 16, 1, 1)]:
-        pc.tuned[key] = cfg
-        outbuf = torch.zeros(1, 64, H, W, device="cuda")
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
+    prev = ops.set_conv_precision("fp32")
+    try:
+        for cfg in [(1, 4, 12, 2, 0), (2, 4, 8, 1, 0), (1, 9, 16, 2, 0), (1, 2, 8, 2, 0), (1, 8, 16, 1, 0),
+                    (1, 4, 16, 2, 1), (2, 4, 16, 2, 1), (1, 9, 16, 2, 1), (1, 4, 32, 1, 1), (4, 4, 16, 1, 1)]:
+            pc.tuned[key] = cfg
+            outbuf = torch.zeros(1, 64, H, W, device="cuda")
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                ops.conv2d(Slice(bd, 6, 24), pc, x2=x2d, pad=1, act="relu", res1=resd, post=postd, out=Slice(outbuf, 8, 48))
+            if tuple(pc.tuned[key]) != cfg:
+                continue
+            n += 1
+            assert (outbuf[:, 8:56].cpu() - ref).abs().max().item() < 5e-5, cfg
+            assert outbuf[:, :8].abs().max().item() == 0 and outbuf[:, 56:].abs().max().item() == 0, cfg
+        assert n >= 6, n
+        # split-bf16 kernel: the channel octet 24..31 straddles both inputs; every wave grid / tile / chunk depth
+        ops.set_conv_precision("split")
+        key = key[:-1] + (3,)
+        n = 0
+        for cfg in [(2, 8, 16, 4, 2, 4, 1), (1, 9, 32, 4, 2, 2, 2), (2, 5, 8, 4, 2, 2, 2), (2, 8, 32, 2, 2, 4, 1),
+                    (1, 16, 8, 1, 2, 4, 1), (2, 16, 16, 1, 2, 4, 1), (2, 4, 16, 2, 2, 4, 1), (1, 8, 32, 1, 2, 4, 1)]:
+            pc.tuned[key] = cfg + (3,)
+            outbuf = torch.zeros(1, 64, H, W, device="cuda")
             ops.conv2d(Slice(bd, 6, 24), pc, x2=x2d, pad=1, act="relu", res1=resd, post=postd, out=Slice(outbuf, 8, 48))
-        if tuple(pc.tuned[key]) != cfg:
-            continue
-        n += 1
-        assert (outbuf[:, 8:56].cpu() - ref).abs().max().item() < 5e-5, cfg
-        assert outbuf[:, :8].abs().max().item() == 0 and outbuf[:, 56:].abs().max().item() == 0, cfg
-    assert n >= 6, n
+            n += 1
+            assert (outbuf[:, 8:56].cpu() - ref).abs().max().item() < 1e-4, cfg
+            assert outbuf[:, :8].abs().max().item() == 0 and outbuf[:, 56:].abs().max().item() == 0, cfg
+    finally:
+        ops.set_conv_precision(prev)
