@@ -26,6 +26,7 @@ class ConvParams(C.Structure):
         ("pad_t", C.c_int), ("pad_l", C.c_int), ("dil_y", C.c_int), ("dil_x", C.c_int),
         ("act", C.c_int), ("store_mode", C.c_int), ("mb", C.c_int), ("npb", C.c_int), ("nw", C.c_int), ("ck", C.c_int), ("layout", C.c_int),
         ("terms", C.c_int), ("pgw", C.c_int), ("cgw", C.c_int),
+        ("xs", C.c_void_p), ("xs_c8", C.c_int), ("xs_hp", C.c_int), ("xs_wp", C.c_int),
     ]
 
 
@@ -70,6 +71,8 @@ SIGNATURES = {
     "codd_raft_geometry_lookup": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p]),
     "codd_conv2d_packed_size_quad": (C.c_longlong, [_i, _i, _i, _i, _i, _i]),
     "codd_conv2d_pack_weights_quad": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "codd_split_bf16_bytes": (_ll, [_i] * 5),
+    "codd_split_bf16": (_i, [View, _i, View, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "codd_conv2d_packed_bytes_bf16": (_ll, [_i] * 7),
     "codd_conv2d_pack_weights_bf16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _f, _p]),
     "codd_fusion_select": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p]),
@@ -79,7 +82,7 @@ SIGNATURES = {
     "codd_fusion_blend": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 2  # CODD_ABI_VERSION of include/codd_hip.h
+ABI_VERSION = 3  # CODD_ABI_VERSION of include/codd_hip.h
 _lib = None
 MISSING = []
 

@@ -49,14 +49,14 @@ extern "C" int codd_conv2d_pack_weights_bf16(const float* w, void* wpacked, int 
   return CODD_OK;
 }
 
-template <int PGW, int CGW, int A, int B, int TERMS, int QREG>
+template <int PGW, int CGW, int A, int B, int TERMS>
 static int launch_b(const ConvB& k, size_t lds, int grid, hipStream_t s) {
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_bf16_kernel<PGW, CGW, A, B, TERMS, QREG>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_bf16_kernel<PGW, CGW, A, B, TERMS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  conv_bf16_kernel<PGW, CGW, A, B, TERMS, QREG><<<grid, (PGW * CGW + CONVB_NWP) * 64, lds, s>>>(k);
+  conv_bf16_kernel<PGW, CGW, A, B, TERMS><<<grid, (PGW * CGW + CONVB_NWP) * 64, lds, s>>>(k);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }
@@ -66,18 +66,73 @@ int codd_conv2d_bf16(const codd_conv_params* pp, void* stream, int dry_run) {
   ConvB k;
   size_t lds;
   long long grid;
-  const int rc = convb_geometry(pp, k, lds, grid);
+  const int rc = convb_geometry(pp, k, lds, grid, !dry_run);
   if (rc != CODD_OK) return rc;
   const codd_conv_params& p = k.p;
-  const int ntp = CONVB_NWP * 64;  // producer threads stage the chunk
   const int a = cdiv(k.pu, p.pgw), bb = p.mb / p.cgw;
-  const int qr = cdiv(k.nunits, ntp);
   hipStream_t s = (hipStream_t)stream;
-#define X(PGW, CGW, A, B, QREG)                                                                            \
-  if (p.pgw == PGW && p.cgw == CGW && a == A && bb == B && qr <= QREG)                                     \
-    return dry_run ? CODD_OK : p.terms == 3 ? launch_b<PGW, CGW, A, B, 3, QREG>(k, lds, (int)grid, s)      \
-                                            : launch_b<PGW, CGW, A, B, 1, QREG>(k, lds, (int)grid, s);
+#define X(PGW, CGW, A, B)                                                                        \
+  if (p.pgw == PGW && p.cgw == CGW && a == A && bb == B)                                         \
+    return dry_run ? CODD_OK : p.terms == 3 ? launch_b<PGW, CGW, A, B, 3>(k, lds, (int)grid, s)  \
+                                            : launch_b<PGW, CGW, A, B, 1>(k, lds, (int)grid, s);
   CONVB_ALL(X)
 #undef X
   return CODD_EUNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// fp32 NCHW (one or two channel-slice views = the conv's concatenated input) -> split-bf16 records
+//   xs[b][plane][octet][yp][xp][8],  pixel (y, x) of the image at (yp, xp) = (y + bt, x + bl), zeros elsewhere and
+//   in the channels past C0 + C1.  One thread = one record position: 8 coalesced dword loads, 1-2 16-byte stores.
+// ------------------------------------------------------------------------------------------------------------
+__global__ void split_bf16_kernel(codd_view in0, codd_view in1, int C0, int C1, int B, int H, int W, int bt, int bl,
+                                  int c8, int hp, int wp, int planes, uint4* __restrict__ xs) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long per = (long long)c8 * hp * wp;
+  if (e >= (long long)B * per) return;
+  const int xp = (int)(e % wp);
+  long long t = e / wp;
+  const int yp = (int)(t % hp); t /= hp;
+  const int oct = (int)(t % c8);
+  const int b = (int)(t / c8);
+  const int y = yp - bt, x = xp - bl;
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = 0.f;
+  if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+    const int hw = H * W, pix = y * W + x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = oct * 8 + i;
+      if (c < C0) v[i] = view_ptr(in0, b, c, hw)[pix];
+      else if (c < C0 + C1) v[i] = view_ptr(in1, b, c - C0, hw)[pix];
+    }
+  }
+  bf16x8 h, l;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 hh = (__bf16)v[i];
+    h[i] = hh;
+    l[i] = (__bf16)(v[i] - (float)hh);
+  }
+  uint4* dst = xs + (size_t)b * planes * per + ((size_t)oct * hp + yp) * wp + xp;
+  dst[0] = __builtin_bit_cast(uint4, h);
+  if (planes == 2) dst[per] = __builtin_bit_cast(uint4, l);
+}
+
+extern "C" long long codd_split_bf16_bytes(int B, int c8, int hp, int wp, int terms) {
+  if (B < 1 || c8 < 1 || hp < 1 || wp < 1 || !(terms == 1 || terms == 3)) return -1;
+  return (long long)B * (terms == 3 ? 2 : 1) * c8 * hp * wp * 16;
+}
+
+extern "C" int codd_split_bf16(codd_view in0, int C0, codd_view in1, int C1, int B, int H, int W, int bt, int bl,
+                               int c8, int hp, int wp, int terms, void* xs, void* stream) {
+  if (!in0.ptr || C0 < 1 || C1 < 0 || (C1 > 0 && !in1.ptr) || !xs || bt < 0 || bl < 0 || hp < bt + H || wp < bl + W ||
+      8 * c8 < C0 + C1 || codd_split_bf16_bytes(B, c8, hp, wp, terms) <= 0)
+    return CODD_EINVAL;
+  const long long total = (long long)B * c8 * hp * wp;
+  split_bf16_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(in0, in1, C0, C1, B, H, W, bt, bl, c8, hp, wp,
+                                                                       terms == 3 ? 2 : 1, (uint4*)xs);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
 }

@@ -18,18 +18,18 @@
 // runs through the same loop; entries beyond ntaps * noct point at entry 0 and carry zero weights.
 //
 // Workgroup = PGW x CGW CONSUMER waves + 4 PRODUCER waves (wave specialisation).  With the matrix pipe 5x faster
-// than on the fp32 path the kernel lives or dies by its staging, so staging gets its own waves:
-//   producers  global -> registers (issued two chunks ahead) -> bf16 split -> LDS buffer (c+1) & 1
-//   consumers  LDS buffer c & 1 -> operand fragments (read one k-step ahead) -> MFMA
-// one __syncthreads per chunk; a producer shares its SIMD with one consumer, so its VALU / LDS-write work runs in
-// the shadow of the consumer's MFMAs (separate pipes).
-// LDS images (16-byte slots = 8 bf16, one ds_read_b128 per operand fragment; hi and lo planes back to back; x2):
-//   weights [plane][k-step][g][co (16 * mb)][8]  = the packed global layout, copied 16 bytes at a time
-//   input   [plane][octet][y][x][8]              fp32 NCHW -> (hi, lo) while staging: a producer lane owns ONE pixel
-//                                                 and 8 channels (8 coalesced dword loads, 2 conflict-free 16-byte
-//                                                 LDS writes), so rows need no alignment; the octet stride is a
-//                                                 multiple of 256 B so the 16-lane groups of a ds_read_b128 never
-//                                                 meet on a bank
+// than on the fp32 path the kernel lives or dies by its staging, so staging gets its own waves and is pure LDS-DMA:
+//   producers  global_load_lds_dwordx4 (1 KiB per wave-instruction, no registers, no VALU) of BOTH operands, issued
+//              two chunks ahead into a ring of three LDS buffers; counted s_waitcnt vmcnt + s_barrier per chunk
+//   consumers  LDS buffer c % 3 -> operand fragments (read one k-step ahead, interleaved 1 read : 2 MFMAs) -> MFMA
+// Both operands therefore exist in global memory in exactly their LDS form:
+//   weights [plane][k-step][g][co (16 * mb)][8]  packed once per layer (codd_conv2d_pack_weights_bf16)
+//   input   [plane][octet][y][x][8]              the activation tensor re-laid-out by codd_split_bf16 (conv_bf16.hip):
+//                                                 8 channels innermost, (hi, lo) bf16 planes, ZERO BORDER of the
+//                                                 conv's padding plus the tile overhang, so a halo tile is plain
+//                                                 row segments of 16-byte records and needs no bounds logic.
+// LDS images are in 16-byte slots (= 8 bf16, one ds_read_b128 per operand fragment); the octet stride of the input
+// image is a multiple of 256 B so the 16-lane groups of a ds_read_b128 never meet on a bank.
 // Consumer wave (pg, cg) owns pixel units [pg*A, pg*A + A) (a unit = 16 consecutive pixels of one tile row; the tile
 // has th rows x xb units) and the B 16-channel blocks [cg*B, cg*B + B) of the workgroup's 16*mb output channels
 // (mb = B * CGW): A*B accumulator tiles per wave, (A + B) fragment reads per plane and k-step.
@@ -44,7 +44,8 @@ struct ConvB {
   int th, tw, thi, twi;           // tile: th x tw output pixels, thi x twi input pixels (halo)
   int pu, xb;                     // pixel units per tile (th * xb), units per tile row
   int npix;                       // thi * twi
-  int nunits;                     // staging units per chunk = noct * npix (one pixel x 8 channels each)
+  int xplane;                     // 16-byte records per precision plane of the split input = xs_c8 * xs_hp * xs_wp
+  int nring;                      // LDS ring depth: 3 (DMA two chunks ahead) when it fits, else 2
   int os16;                       // 16-byte slots per octet plane of the input image (multiple of 16)
   int iplane16;                   // slots per precision plane of the input image = noct * os16
   int ibuf16;                     // slots of one input buffer = planes * iplane16
@@ -55,6 +56,7 @@ struct ConvB {
 };
 
 constexpr int CONVB_NWP = 4;  // producer waves per workgroup
+constexpr int CONVB_MAXP = 6; // input DMA pieces per producer wave whose source offsets are kept in registers
 // dev ablations (tools/ubench/convb_ablate.hip): drop the weight DMA / the input loads
 #ifdef CONVB_NO_DMA
 #define CONVB_DMA_N(n) 0
@@ -70,7 +72,7 @@ constexpr int CONVB_NWP = 4;  // producer waves per workgroup
 /* launch geometry of the split-bf16 kernel for layout-2 parameters: fills k, the dynamic LDS size and the grid.
  * Field use: nw = tile rows, npb = 16-pixel units per tile row (1 or 2), mb = 16-channel blocks per workgroup,
  * ck = channels per chunk (multiple of 8), pgw x cgw = consumer wave grid, terms = 1 | 3. */
-static inline int convb_geometry(const codd_conv_params* pp, ConvB& k, size_t& lds, long long& grid) {
+static inline int convb_geometry(const codd_conv_params* pp, ConvB& k, size_t& lds, long long& grid, bool need_xs) {
   k.p = *pp;
   const codd_conv_params& p = k.p;
   if (p.ck < 8 || (p.ck & 7) || !(p.terms == 1 || p.terms == 3) || p.nw < 1 || p.npb < 1 || p.npb > 2 ||
@@ -86,8 +88,8 @@ static inline int convb_geometry(const codd_conv_params* pp, ConvB& k, size_t& l
   k.thi = (k.th - 1) * p.sy + (p.kh - 1) * p.dil_y + 1;
   k.twi = (k.tw - 1) * p.sx + (p.kw - 1) * p.dil_x + 1;
   k.npix = k.thi * k.twi;
-  k.nunits = k.noct * k.npix;
   k.os16 = ((k.npix + 15) / 16) * 16;
+  while ((planes * k.noct * k.os16) & 63) k.os16 += 16;  // an input buffer is a whole number of 1 KiB DMA pieces
   k.iplane16 = k.noct * k.os16;
   k.ibuf16 = planes * k.iplane16;
   k.nco = 16 * p.mb;
@@ -97,8 +99,19 @@ static inline int convb_geometry(const codd_conv_params* pp, ConvB& k, size_t& l
   k.tiles_y = cdiv(p.Hout, k.th);
   k.cout_eff = p.store_mode ? 4 * p.Cout : p.Cout;
   k.ncog = cdiv(k.cout_eff, k.nco);
-  lds = (3 * (size_t)k.wslots + 2 * (size_t)k.ibuf16) * 16 + ((size_t)k.nk + 1) * 16;  // 3 weight + 2 input buffers + table
+  // ring of (weights + input) buffers + entry table: three deep when that fits the 160 KiB of a CU, else two
+  const size_t per = ((size_t)k.wslots + (size_t)k.ibuf16) * 16, tab = ((size_t)k.nk + 1) * 16;
+  k.nring = (k.nchunks >= 3 && 3 * per + tab <= 160 * 1024) ? 3 : 2;
+  lds = k.nring * per + tab;
   if (lds > 160 * 1024) return CODD_EUNSUPPORTED;
+  // DMA pieces a producer wave issues per chunk; nring - 1 chunks are in flight and vmcnt counts to 63
+  if ((k.nring - 1) * (cdiv(k.wslots >> 6, CONVB_NWP) + cdiv(k.ibuf16 >> 6, CONVB_NWP)) > 56) return CODD_EUNSUPPORTED;
+  k.xplane = p.xs_c8 * p.xs_hp * p.xs_wp;
+  // the split input must hold every halo tile (codd_split_bf16_dims gives a sufficient size)
+  if (need_xs && (!p.xs || p.xs_c8 < k.nchunks * k.noct || p.xs_hp < p.pad_t + p.Hin || p.xs_wp < p.pad_l + p.Win ||
+                  p.xs_hp < (k.tiles_y * k.th - 1) * p.sy + (p.kh - 1) * p.dil_y + 1 ||
+                  p.xs_wp < (k.tiles_x * k.tw - 1) * p.sx + (p.kw - 1) * p.dil_x + 1))
+    return CODD_EINVAL;
   grid = (long long)k.tiles_x * k.tiles_y * k.ncog * p.B;
   if (grid <= 0 || grid > 0x7fffffffLL) return CODD_EINVAL;
   return CODD_OK;
@@ -163,15 +176,15 @@ struct ConvbSched {
   }
 };
 
-template <int PGW, int CGW, int A, int B, int TERMS, int QREG>
+template <int PGW, int CGW, int A, int B, int TERMS>
 __global__ __launch_bounds__((PGW * CGW + CONVB_NWP) * 64) void conv_bf16_kernel(const ConvB k) {
   constexpr int NWC = PGW * CGW;          // consumer waves
   constexpr int NTP = CONVB_NWP * 64;     // producer threads
   constexpr int NPL = TERMS == 1 ? 1 : 2; // precision planes
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
-  uint4* wl = smem4;                       // 3 weight buffers (the DMA runs two chunks ahead)
-  uint4* il = smem4 + 3 * k.wslots;        // 2 input buffers
-  int* etab = (int*)(il + 2 * k.ibuf16);   // entry table: slot offset of (k-step, g) inside an input plane
+  uint4* wl = smem4;                             // ring of nring weight buffers (the DMA runs nring - 1 chunks ahead)
+  uint4* il = smem4 + k.nring * k.wslots;        // ring of nring input buffers
+  int* etab = (int*)(il + k.nring * k.ibuf16);   // entry table: slot offset of (k-step, g) inside an input plane
   const codd_conv_params& p = k.p;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -207,114 +220,69 @@ __global__ __launch_bounds__((PGW * CGW + CONVB_NWP) * 64) void conv_bf16_kernel
       }
       etab[e] = off;
     }
-    const int hwin = p.Hin * p.Win;
-    const int gy0 = ty * k.th * p.sy - p.pad_t;
-    const int gx0 = tx * k.tw * p.sx - p.pad_l;
-    // per-thread staging units: unit u = (octet, pixel of the halo tile); a unit is 8 channels of one pixel
-    int q_lds[QREG], q_g[QREG], q_c[QREG];  // LDS slot, offset inside a channel plane (-1: outside the image), first channel
-#pragma unroll
-    for (int r = 0; r < QREG; ++r) {
-      const int u = pt + r * NTP;
-      q_c[r] = -1; q_lds[r] = 0; q_g[r] = -1;
-      if (u < k.nunits) {
-        const int oct = u / k.npix, pix = u - oct * k.npix;
-        const int y = pix / k.twi, x = pix - y * k.twi;
-        const int gy = gy0 + y, gx = gx0 + x;
-        q_c[r] = 8 * oct;
-        q_lds[r] = oct * k.os16 + pix;
-        if ((unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win) q_g[r] = gy * p.Win + gx;
-      }
-    }
-    float ir0[QREG][8], ir1[QREG][8], ir2[QREG][8];  // input of three chunks in flight (loaded three phases ahead)
     const int pw = wave - NWC;                      // producer wave index
-    const int nwv = k.wslots >> 6;                  // 1 KiB pieces of a weight image (wslots is a multiple of 64)
-    const int nd = (CONVB_DMA_N(nwv) - pw + CONVB_NWP - 1) / CONVB_NWP;  // DMA pieces this wave issues per chunk
-    constexpr int NL = CONVB_IN_N(QREG) * 8;        // register loads this wave issues per chunk
+    const int nwv = k.wslots >> 6, niv = k.ibuf16 >> 6;  // 1 KiB pieces of a weight / an input image
+    const int nd = (nwv - pw + CONVB_NWP - 1) / CONVB_NWP + (niv - pw + CONVB_NWP - 1) / CONVB_NWP;  // pieces per chunk, this wave
     const unsigned wl_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint4*)wl;
-
-    // weights: LDS-DMA, 1 KiB per wave-instruction, no registers (the image in global memory IS the LDS image)
-#define BF_DMA_W(CH, BUF)                                                                                 \
+    const unsigned il_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint4*)il;
+    // first record of this tile in an octet plane of the split input (its border makes every halo tile in-bounds)
+    const uint4* xs0 = (const uint4*)p.xs + (size_t)b * NPL * k.xplane +
+                       (size_t)(ty * k.th * p.sy) * p.xs_wp + tx * k.tw * p.sx;
+    const int oct_rec = p.xs_hp * p.xs_wp;  // records per octet plane
+    // per-lane record offset of this wave's input pieces (chunk-independent; the first CONVB_MAXP pieces live in
+    // registers, configurations with more fall back to recomputing the two divisions per piece)
+    auto piece_off = [&](int i_) -> int {
+      const int s_ = i_ * 64 + lane;
+      const int pl_ = s_ / k.iplane16, r_ = s_ - pl_ * k.iplane16;
+      const int oc_ = r_ / k.os16;
+      int px_ = r_ - oc_ * k.os16;
+      px_ = px_ < k.npix ? px_ : 0;  // slots in the octet padding re-read pixel 0 (never consumed)
+      const int y_ = px_ / k.twi, x_ = px_ - y_ * k.twi;
+      return pl_ * k.xplane + oc_ * oct_rec + y_ * p.xs_wp + x_;
+    };
+    int ioff[CONVB_MAXP];
+#pragma unroll
+    for (int q_ = 0; q_ < CONVB_MAXP; ++q_) ioff[q_] = piece_off(pw + q_ * CONVB_NWP);
+    // Chunk CH -> ring slot BUF: weights are a linear copy; an input piece is 64 consecutive LDS slots
+    // s = (plane, octet, pixel) gathered from per-lane record addresses
+#define BF_DMA(CH, BUF)                                                                                   \
   {                                                                                                       \
-    const uint4* src_ = (const uint4*)p.wpacked + ((size_t)(cog * k.nchunks + (CH))) * k.wslots + lane;   \
-    const unsigned dst_ = wl_lds + (unsigned)(BUF) * (unsigned)k.wslots * 16u;                            \
-    for (int i_ = pw; i_ < CONVB_DMA_N(nwv); i_ += CONVB_NWP)                                             \
-      convb_dma16(src_ + i_ * 64, __builtin_amdgcn_readfirstlane(dst_ + (unsigned)i_ * 1024u));           \
-  }
-    // input: 8 coalesced dword loads per (pixel, octet) unit into registers ...
-#define BF_LOAD_I(IR, CH)                                                                                 \
-  {                                                                                                       \
-    const int c0_ = (CH) * p.ck;                                                                          \
-    _Pragma("unroll") for (int r_ = 0; r_ < CONVB_IN_N(QREG); ++r_) {                                     \
-      _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                  \
-        /* unconditional load from a clamped address + select: a "load or zero" branch per element would */ \
-        /* serialise the loads (s_cbranch around each, DESIGN.md finding 4) */                            \
-        const int cg_ = c0_ + q_c[r_] + i_;                                                               \
-        const bool ok_ = q_g[r_] >= 0 && q_c[r_] >= 0 && cg_ < k.cin;                                     \
-        const int cs_ = ok_ ? cg_ : 0;                                                                    \
-        const float* s_ = cs_ < p.C0 ? view_ptr(p.in0, b, cs_, hwin) : view_ptr(p.in1, b, cs_ - p.C0, hwin); \
-        IR[r_][i_] = s_[ok_ ? q_g[r_] : 0]; /* NO use of the value here: a select would wait for the load */ \
-      }                                                                                                   \
+    const uint4* wsrc_ = (const uint4*)p.wpacked + ((size_t)(cog * k.nchunks + (CH))) * k.wslots + lane;  \
+    const unsigned wdst_ = wl_lds + (unsigned)(BUF) * (unsigned)k.wslots * 16u;                           \
+    for (int i_ = pw; i_ < nwv; i_ += CONVB_NWP)                                                          \
+      convb_dma16(wsrc_ + i_ * 64, __builtin_amdgcn_readfirstlane(wdst_ + (unsigned)i_ * 1024u));         \
+    const uint4* xsrc_ = xs0 + (size_t)(CH) * k.noct * oct_rec;                                           \
+    const unsigned idst_ = il_lds + (unsigned)(BUF) * (unsigned)k.ibuf16 * 16u;                           \
+    _Pragma("unroll") for (int q_ = 0; q_ < CONVB_MAXP; ++q_) {                                           \
+      const int i_ = pw + q_ * CONVB_NWP;                                                                 \
+      if (i_ < niv) convb_dma16(xsrc_ + ioff[q_], __builtin_amdgcn_readfirstlane(idst_ + (unsigned)i_ * 1024u)); \
     }                                                                                                     \
+    for (int i_ = pw + CONVB_MAXP * CONVB_NWP; i_ < niv; i_ += CONVB_NWP)                                 \
+      convb_dma16(xsrc_ + piece_off(i_), __builtin_amdgcn_readfirstlane(idst_ + (unsigned)i_ * 1024u));   \
   }
-    // ... split into (hi, lo) bf16 and written as two 16-byte LDS slots two phases later
-#define BF_COMMIT_I(IR, BUF, CH)                                                                          \
-  {                                                                                                       \
-    uint4* id_ = il + (BUF) * k.ibuf16;                                                                   \
-    const int c0_ = (CH) * p.ck;                                                                          \
-    _Pragma("unroll") for (int r_ = 0; r_ < QREG; ++r_) if (q_c[r_] >= 0) {                               \
-      bf16x8 h_, l_;                                                                                      \
-      _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                  \
-        /* padding pixels and channels past Cin were loaded from a clamped address: zero them here */     \
-        const float x_ = (q_g[r_] >= 0 && c0_ + q_c[r_] + i_ < k.cin) ? IR[r_][i_] : 0.f;                 \
-        const __bf16 hh_ = (__bf16)x_;                                                                    \
-        h_[i_] = hh_;                                                                                     \
-        l_[i_] = (__bf16)(x_ - (float)hh_);                                                               \
-      }                                                                                                   \
-      id_[q_lds[r_]] = __builtin_bit_cast(uint4, h_);                                                     \
-      if (NPL == 2) id_[k.iplane16 + q_lds[r_]] = __builtin_bit_cast(uint4, l_);                          \
-    }                                                                                                     \
-  }
-    // Phase c (the consumers compute chunk c from weight buffer c % 3 and input buffer c & 1), in this order:
-    //   1. commit the input of chunk c+1 (registers loaded in phase c-2) to input buffer (c+1) & 1
-    //   2. load the input of chunk c+3 into the register set just freed
-    //   3. DMA the weights of chunk c+2 into weight buffer (c+2) % 3 (last read in phase c-1)
-    //   4. wait until the DMA of chunk c+1 (issued in phase c-1) has landed: everything issued in THIS phase may
-    //      stay in flight (vmcnt counts in order), then lgkmcnt(0) for the ds_writes, then the barrier.
-    // Every global access therefore has two full phases to complete (the round trip measured here is ~1.7 us, a
-    // phase ~1.4 us); hipcc's own waits for the register sets only see its loads and are conservative (never early).
-#define BF_PHASE(C, IRC, IRL, WB)                                                                         \
-  {                                                                                                       \
-    int out_ = 0;                                                                                         \
-    if ((C) + 1 < k.nchunks) BF_COMMIT_I(IRC, ((C) + 1) & 1, (C) + 1);                                             \
-    if ((C) + 3 < k.nchunks) { BF_LOAD_I(IRL, (C) + 3); out_ += NL; }                                     \
-    if ((C) + 2 < k.nchunks) { BF_DMA_W((C) + 2, WB); out_ += nd; }                                       \
-    convb_wait_vmcnt(out_);                                                                               \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
-    __builtin_amdgcn_s_barrier();                                                                         \
-  }
+    // Phase c (the consumers compute chunk c from ring slot c % nring): issue the DMA of chunk c + nring - 1 into the
+    // slot last read in phase c-1, then wait until the DMA of chunk c+1 has landed -- vmcnt counts in order, so "at
+    // most the younger chunks' pieces outstanding" -- and meet the consumers at the barrier.  With a ring of three
+    // every global access has two full phases to complete (round trip measured here ~1.7 us, a phase ~1.4 us).
 #ifndef CONVB_NO_PRODUCER
-    BF_LOAD_I(ir0, 0);
-    if (k.nchunks > 1) BF_LOAD_I(ir1, 1);
-    if (k.nchunks > 2) BF_LOAD_I(ir2, 2);
-    BF_DMA_W(0, 0);
-    if (k.nchunks > 1) BF_DMA_W(1, 1);
-    BF_COMMIT_I(ir0, 0, 0);
-    convb_wait_vmcnt(k.nchunks > 1 ? nd : 0);  // chunk 0's weights landed (chunk 1's may still fly)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int ahead = k.nring - 1;
+    BF_DMA(0, 0);
+    if (ahead > 1 && k.nchunks > 1) BF_DMA(1, 1);
+    convb_wait_vmcnt(ahead > 1 && k.nchunks > 1 ? nd : 0);  // chunk 0 landed (chunk 1 may still fly)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // entry table
     __builtin_amdgcn_s_barrier();
-    for (int c = 0; c < k.nchunks; c += 3) {
-      // register sets rotate with the chunk index mod 3: set (c+1)%3 is committed, set c%3 re-loaded
-      BF_PHASE(c, ir1, ir0, 2);
-      if (c + 1 >= k.nchunks) break;
-      BF_PHASE(c + 1, ir2, ir1, 0);
-      if (c + 2 >= k.nchunks) break;
-      BF_PHASE(c + 2, ir0, ir2, 1);
+    int slot = ahead == k.nring ? 0 : ahead;  // ring slot of chunk c + ahead
+    for (int c = 0; c < k.nchunks; ++c) {
+      if (c + ahead < k.nchunks) BF_DMA(c + ahead, slot);
+      slot = slot + 1 == k.nring ? 0 : slot + 1;
+      // chunk c + 1 must have landed; the chunks issued after it (c + 2 .. c + ahead, where they exist) may fly on
+      int fly_ = k.nchunks - (c + 2);
+      fly_ = fly_ < 0 ? 0 : (fly_ > ahead - 1 ? ahead - 1 : fly_);
+      convb_wait_vmcnt(fly_ * nd);
+      __builtin_amdgcn_s_barrier();
     }
 #endif
-#undef BF_PHASE
-#undef BF_DMA_W
-#undef BF_LOAD_I
-#undef BF_COMMIT_I
+#undef BF_DMA
     return;
   }
 
@@ -376,9 +344,9 @@ __global__ __launch_bounds__((PGW * CGW + CONVB_NWP) * 64) void conv_bf16_kernel
   constexpr int NRD = 1 + NPL * (A + B), NMF = TERMS * A * B;  // LDS reads / MFMAs per k-step
   int wsel = 0;
   for (int ch = 0; ch < k.nchunks; ++ch) {
-    const uint4* wb = wl + wsel * k.wslots;  // weight buffer ch % 3
-    const uint4* ib = il + (ch & 1) * k.ibuf16;
-    wsel = wsel == 2 ? 0 : wsel + 1;
+    const uint4* wb = wl + wsel * k.wslots;  // ring slot ch % nring
+    const uint4* ib = il + wsel * k.ibuf16;
+    wsel = wsel + 1 == k.nring ? 0 : wsel + 1;
     // software pipeline over the k-steps, two register sets, no branch inside the loop body (hipcc can then count
     // the outstanding LDS reads instead of draining them): the fragments of step s+1 are in flight while the MFMAs
     // of step s issue.  A clamped (redundant) load replaces the conditional one at the end of the chunk.
@@ -471,21 +439,20 @@ __global__ __launch_bounds__((PGW * CGW + CONVB_NWP) * 64) void conv_bf16_kernel
   }
 }
 
-// ---- instantiation list: X(PGW, CGW, A, B, QREG), each for TERMS = 1 and 3 -------------------------------------
+// ---- instantiation list: X(PGW, CGW, A, B), each for TERMS = 1 and 3 -------------------------------------------
 //   (2,2,5,2): 9/10-unit tiles x 64 channels (the 72x120 GRU maps: 256 workgroups of 144 px x 64 co)
 //   (4,1,4,4) / (4,1,4,2) / (4,1,4,1): 16-unit tiles (8 x 32 px) x 64 / 32 / 16 channels
 //   (4,1,2,2) / (4,1,2,1): 8-unit tiles (4 x 32 or 8 x 16 px) x 32 / 16 channels (small maps)
 //   (4,1,8,1): 32-unit tiles (16 x 32 px) x 16 channels (full-resolution 16-channel layers)
-// QREG = (pixel, octet) staging units per producer thread and chunk (8 VGPRs each)
-#define CONVB_GROUP_A(X) X(2, 2, 5, 2, 2) X(2, 2, 5, 2, 6)
-#define CONVB_GROUP_B(X) X(4, 1, 4, 4, 3) X(4, 1, 4, 4, 6)
-#define CONVB_GROUP_C(X) X(4, 1, 4, 2, 3) X(4, 1, 4, 2, 6)
-#define CONVB_GROUP_D(X) X(4, 1, 4, 1, 3) X(4, 1, 8, 1, 6)
-#define CONVB_GROUP_E(X) X(4, 1, 2, 2, 2) X(4, 1, 2, 2, 8) X(4, 1, 2, 1, 2) X(4, 1, 2, 1, 8)
+#define CONVB_GROUP_A(X) X(2, 2, 5, 2)
+#define CONVB_GROUP_B(X) X(4, 1, 4, 4)
+#define CONVB_GROUP_C(X) X(4, 1, 4, 2)
+#define CONVB_GROUP_D(X) X(4, 1, 4, 1) X(4, 1, 8, 1)
+#define CONVB_GROUP_E(X) X(4, 1, 2, 2) X(4, 1, 2, 1)
 #define CONVB_ALL(X) CONVB_GROUP_A(X) CONVB_GROUP_B(X) CONVB_GROUP_C(X) CONVB_GROUP_D(X) CONVB_GROUP_E(X)
-#define CONVB_DECLARE(PGW, CGW, A, B, QREG)                                                     \
-  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, QREG>(const ConvB);      \
-  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, QREG>(const ConvB);
-#define CONVB_DEFINE(PGW, CGW, A, B, QREG)                                                      \
-  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, QREG>(const ConvB);             \
-  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, QREG>(const ConvB);
+#define CONVB_DECLARE(PGW, CGW, A, B)                                                     \
+  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1>(const ConvB);      \
+  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3>(const ConvB);
+#define CONVB_DEFINE(PGW, CGW, A, B)                                                      \
+  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1>(const ConvB);             \
+  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3>(const ConvB);

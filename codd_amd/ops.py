@@ -297,6 +297,8 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
         if cfg is None:
             cands = _bf16_candidates(pc, Hout, Wout, B, pc.kh * pc.kw, terms)
             if tune:
+                cands = [c for c in cands if _cfg_ok(lib, p, c)]
+                keep = _make_split(lib, p, xs, x2, cands)  # noqa: F841 one split input that serves every candidate
                 cfg = TUNE_DB[sig] = _autotune_b(lib, p, pc, cands)
             else:
                 cfg = next((c for c in cands if _cfg_ok(lib, p, c)), None)
@@ -304,6 +306,8 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
                     raise _abi.CoddHipError("no split-bf16 launch configuration for conv %dx%d %d->%d" % (
                         pc.kh, pc.kw, pc.cin, pc.cout))
             pc.tuned[key] = cfg
+        if not p.xs:
+            keep = _make_split(lib, p, xs, x2, [cfg])  # noqa: F841 (alive until the launch below is enqueued)
         _set_cfg(p, pc, cfg)
         _abi.check(_launch_conv(lib, p, _stream()), "codd_conv2d")
         return out
@@ -342,6 +346,31 @@ def _set_cfg(p, pc, c):
     xb, th, ck, mb, _, pgw, cgw = c[:7]
     p.wpacked = pc.packed(ck, mb, 20 + p.terms).data_ptr()
     p.mb, p.npb, p.nw, p.ck, p.layout, p.pgw, p.cgw = mb, xb, th, ck, 2, pgw, cgw
+
+
+def _split_dims(p, cands):
+    """(c8, hp, wp) of a split-bf16 input that serves every configuration in ``cands`` for the conv described by
+    ``p`` (include/codd_hip.h, codd_split_bf16): borders (pad_t, pad_l) + the largest tile overhang."""
+    cin = p.C0 + p.C1
+    c8 = hp = wp = 0
+    for c in cands:
+        xb, th, ck = c[0], c[1], c[2]
+        c8 = max(c8, -(-cin // ck) * (ck // 8))
+        hp = max(hp, p.pad_t + p.Hin, (-(-p.Hout // th) * th - 1) * p.sy + (p.kh - 1) * p.dil_y + 1)
+        wp = max(wp, p.pad_l + p.Win, (-(-p.Wout // (16 * xb)) * 16 * xb - 1) * p.sx + (p.kw - 1) * p.dil_x + 1)
+    return c8, hp, wp
+
+
+def _make_split(lib, p, xs, x2, cands):
+    """Run codd_split_bf16 for the conv input (x | x2) and attach the result to ``p``; returns the buffer (the
+    caller keeps it alive until the conv is enqueued -- the caching allocator is stream-ordered)."""
+    c8, hp, wp = _split_dims(p, cands)
+    n = lib.codd_split_bf16_bytes(p.B, c8, hp, wp, p.terms)
+    buf = torch.empty(n, device=xs.buf.device, dtype=torch.uint8)
+    _abi.check(lib.codd_split_bf16(_view(xs), p.C0, _view(x2), p.C1, p.B, p.Hin, p.Win, p.pad_t, p.pad_l, c8, hp, wp,
+                                   p.terms, buf.data_ptr(), _stream()), "codd_split_bf16")
+    p.xs, p.xs_c8, p.xs_hp, p.xs_wp = buf.data_ptr(), c8, hp, wp
+    return buf
 
 
 def _autotune_b(lib, p, pc, cands):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CODD_ABI_VERSION 2
+#define CODD_ABI_VERSION 3
 
 #define CODD_OK 0
 #define CODD_EINVAL (-1)
@@ -86,6 +86,10 @@ typedef struct {
                  tile row (1 | 2), ck a multiple of 8) */
   int terms;  /* layout 2: 1 = bf16 operands, 3 = split-bf16 (hi/lo) operands */
   int pgw, cgw; /* layout 2: wave grid of a workgroup (pixel-unit groups x channel-block groups), mb % cgw == 0 */
+  /* layout 2: the input (channel concatenation of C0 + C1 channels; in0 / in1 are not read) re-laid-out by
+   * codd_split_bf16 with borders (pad_t, pad_l): [B][plane][xs_c8 octets][xs_hp][xs_wp][8] bf16 */
+  const void* xs;
+  int xs_c8, xs_hp, xs_wp;
 } codd_conv_params;
 
 int codd_conv2d(const codd_conv_params* p, void* stream);
@@ -98,6 +102,16 @@ int codd_conv2d_check(const codd_conv_params* p);
 long long codd_conv2d_packed_size_quad(int Cout, int Cin, int kh, int kw, int mb, int ck);
 int codd_conv2d_pack_weights_quad(const float* w, float* wpacked, int Cout, int Cin, int kh, int kw, int mb,
                                   int ck, void* stream);
+
+/* Activation re-layout for layout 2: fp32 NCHW views (in0 | in1 concatenated) -> split-bf16 records
+ * xs[b][plane hi|lo][octet][yp][xp][8 bf16]; pixel (y, x) sits at (y + bt, x + bl); the border and the channels past
+ * C0 + C1 are zero, so that every halo tile of the convolution is in-bounds row segments of 16-byte records (the
+ * kernel's LDS-DMA copies them verbatim).  A conv needs bt = pad_t, bl = pad_l, 8 * c8 >= ceil(Cin / ck) * ck and
+ * hp >= max(pad_t + H, (tiles_y * th - 1) * sy + (kh - 1) * dil_y + 1), wp likewise (th x 16*npb = its tile).
+ * terms = 1: hi plane only. */
+long long codd_split_bf16_bytes(int B, int c8, int hp, int wp, int terms);
+int codd_split_bf16(codd_view in0, int C0, codd_view in1, int C1, int B, int H, int W, int bt, int bl,
+                    int c8, int hp, int wp, int terms, void* xs, void* stream);
 
 /* split-bf16 layout (layout = 2): [cog][chunk][plane hi|lo][k-step][g][co][8 bf16]; element (co, ci, tap) is read
  * from w[co*co_stride + ci*ci_stride + tap] and scaled (as codd_conv2d_pack_weights_ex). */

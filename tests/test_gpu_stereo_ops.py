@@ -238,7 +238,7 @@ def test_c_abi_error_codes_are_loud():
         with pytest.raises(_abi.CoddHipError, match="-2"):  # CODD_EUNSUPPORTED
             ops.conv2d(x, pc, pad=1)
         ops.set_conv_precision("split")
-        pc.tuned[(16, 32, 1, 1, 1, 1, 1, 1, False, 3)] = (2, 7, 16, 2, 2, 4, 1, 3)  # 7-row tiles: not instantiated
+        pc.tuned[(16, 32, 1, 1, 1, 1, 1, 1, False, 3)] = (2, 8, 16, 3, 2, 4, 1, 3)  # 48-channel groups: not instantiated
         with pytest.raises(_abi.CoddHipError, match="-2"):
             ops.conv2d(x, pc, pad=1)
     finally:
@@ -375,7 +375,7 @@ def test_tunable_configurations_with_views_and_two_inputs():
         ops.set_conv_precision("split")
         key = key[:-1] + (3,)
         n = 0
-        for cfg in [(2, 8, 16, 4, 2, 4, 1), (1, 9, 32, 4, 2, 2, 2), (2, 5, 8, 4, 2, 2, 2), (2, 8, 32, 2, 2, 4, 1),
+        for cfg in [(2, 8, 16, 4, 2, 4, 1), (1, 9, 32, 4, 2, 2, 2), (2, 5, 8, 4, 2, 2, 2), (2, 8, 16, 2, 2, 4, 1),
                     (1, 16, 8, 1, 2, 4, 1), (2, 16, 16, 1, 2, 4, 1), (2, 4, 16, 2, 2, 4, 1), (1, 8, 32, 1, 2, 4, 1)]:
             pc.tuned[key] = cfg + (3,)
             outbuf = torch.zeros(1, 64, H, W, device="cuda")

@@ -6,7 +6,7 @@
 #include <vector>
 
 #ifndef CFG
-#define CFG 2, 2, 5, 2, 3, 2
+#define CFG 2, 2, 5, 2, 3
 #endif
 template __global__ void conv_bf16_kernel<CFG>(const ConvB);
 
@@ -36,10 +36,16 @@ int main(int argc, char** argv) {
   p.wpacked = (const float*)wp; p.out = out; p.out_ctot = cout; p.Cout = cout; p.Hout = H; p.Wout = W;
   p.kh = p.kw = ks; p.sy = p.sx = 1; p.pad_t = p.pad_l = ks / 2; p.dil_y = p.dil_x = 1;
   p.mb = mb; p.npb = xb; p.nw = th; p.ck = ck; p.layout = 2; p.terms = 3; p.pgw = pgw; p.cgw = cgw;
+  // split input with borders (pad, pad) and room for the tile overhang
+  const int c8 = ((cin + ck - 1) / ck) * (ck / 8), hp = H + 2 * (ks / 2) + 16, wpx = W + 2 * (ks / 2) + 32;
+  void* xs;
+  hipMalloc(&xs, (size_t)2 * c8 * hp * wpx * 16);
+  hipMemset(xs, 0, (size_t)2 * c8 * hp * wpx * 16);
+  p.xs = xs; p.xs_c8 = c8; p.xs_hp = hp; p.xs_wp = wpx;
   ConvB k;
   size_t lds;
   long long grid;
-  int rc = convb_geometry(&p, k, lds, grid);
+  int rc = convb_geometry(&p, k, lds, grid, true);
   if (rc) { printf("geometry rc %d\n", rc); return 1; }
   auto kern = conv_bf16_kernel<CFG>;
   hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -66,7 +72,7 @@ int main(int argc, char** argv) {
 #else
          "full",
 #endif
-         cin, cout, th, 16 * xb, ck, mb, grid, lds, k.nk, k.nchunks, (k.nunits + 255) / 256, best * 1e3, gf / best,
+         cin, cout, th, 16 * xb, ck, mb, grid, lds, k.nk, k.nchunks, k.ibuf16 >> 6, best * 1e3, gf / best,
          hipGetErrorString(hipGetLastError()));
   return 0;
 }
