@@ -201,6 +201,33 @@ def set_conv_precision(mode):
     return prev
 
 
+# Stage policy under the default "split" mode.  Measured on MI355X (tools/debug_split_layers.py, headline parity tests):
+# a split-bf16 conv is accurate to ~1e-5 of its OUTPUT SCALE.  HITNet's propagation layers carry raw disparities
+# (~100 px) in their input channels and emit the disparity itself, so 1e-5 relative is ~1e-3 px absolute -- the whole
+# north-star budget -- and its arg-min / arg-max selections flip for ~1.5 % of the pixels; the stereo network
+# (7 % of the frame's conv FLOPs) therefore stays on the exact-fp32 kernels, everything else (RAFT3D encoders and the
+# 16 update iterations, Fusion: 93 % of the FLOPs, O(1) feature scales, smooth outputs) runs split-bf16.
+_STAGE_PRECISION = dict(stereo="fp32")
+
+
+class stage:
+    """``with ops.stage("stereo"): ...`` -- conv precision of a pipeline stage (only the "split" default is refined;
+    explicit "fp32" / "bf16" modes apply to every stage)."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.prev = None
+        if CONV_PRECISION == "split" and self.name in _STAGE_PRECISION:
+            self.prev = set_conv_precision(_STAGE_PRECISION[self.name])
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            set_conv_precision(self.prev)
+        return False
+
+
 # split-bf16 kernel instantiations (conv_bf16_kernel.h): (pgw, cgw, A, B) and the tiles (rows, units per row) tried
 _B_INST = ((2, 2, 5, 2), (4, 1, 4, 4), (4, 1, 4, 2), (4, 1, 4, 1), (4, 1, 8, 1), (4, 1, 2, 2), (4, 1, 2, 1))
 _B_TILES = {5: ((9, 1), (10, 1), (5, 2)), 4: ((8, 2), (16, 1)), 8: ((16, 2),), 2: ((4, 2), (8, 1))}

@@ -306,9 +306,10 @@ class HITNetMF(nn.Module):
     def stereo_matching(self, left_img, right_img, img_metas=None, state=None):
         """reference hitnet.py:75-100 (eval branch) -> dict(pred_disp, left_feat, right_feat, left_img)."""
         B = left_img.shape[0]
-        pyr = self.extract_feat(torch.cat([left_img, right_img], 0))
-        fea_l = [p[:B] for p in pyr]
-        fea_r = [p[B:] for p in pyr]
-        _, init = self.tile_init(fea_l, fea_r)
-        disp = self.tile_update(fea_l, fea_r, init)
+        with ops.stage("stereo"):  # exact-fp32 convs: the disparity itself flows through these layers (ops.stage)
+            pyr = self.extract_feat(torch.cat([left_img, right_img], 0))
+            fea_l = [p[:B] for p in pyr]
+            fea_r = [p[B:] for p in pyr]
+            _, init = self.tile_init(fea_l, fea_r)
+            disp = self.tile_update(fea_l, fea_r, init)
         return dict(pred_disp=disp, left_feat=fea_l[2], right_feat=fea_r[2], left_img=left_img)
