@@ -13,11 +13,14 @@ processes its own video (weak scaling; no data-path collective); the only collec
 all_reduce of the [3,12] metric tensor after the timed frames, inside the timed region.
 
 Prints ONE JSON line on rank 0 (see README / task contract), including
-  roofline     -- fp32-MFMA roofline of the dominant kernel family (conv_mfma_kernel): algorithmic
-                  conv FLOPs of one frame / summed conv launch time measured with HIP events on the
-                  launch stream, vs the 157.3 TFLOP/s fp32 matrix peak;
+  roofline     -- MFMA roofline of the dominant kernel family (conv_bf16_kernel, the split-bf16 convolutions of
+                  RAFT3D + Fusion): MFMA FLOPs ISSUED (3 bf16 MFMAs per product) by its launches of one frame /
+                  their summed duration measured with HIP events on the launch stream, vs the 2.5 PFLOP/s dense
+                  bf16 matrix peak; the same on ALGORITHMIC direct-conv FLOPs, and the exact-fp32 family (HITNet)
+                  vs the 157.3 TFLOP/s fp32 matrix peak, are reported beside it;
   cpu_baseline -- the CPU oracle (port of the reference's PyTorch-CPU path) timed on this host's
-                  cores on a bounded sample.
+                  cores: BASELINE.json configs[0] (512x256, 2 frames, stereo only) and ONE measured
+                  steady-state frame of the benchmarked configuration (no scaling).
 """
 import argparse
 import json
@@ -34,6 +37,7 @@ sys.path.insert(0, ROOT)
 RAW_H, RAW_W = 540, 960
 PAD_H, PAD_W = 576, 960
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip-level parameters
+BF16_MATRIX_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (same table)
 
 
 _T0 = time.time()
@@ -56,7 +60,12 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--precision", default="split", choices=["split", "fp32", "bf16"],
+                    help="arithmetic of the convolution family (codd_amd.ops.set_conv_precision): split = split-bf16 "
+                         "operands / fp32 accumulate for RAFT3D + Fusion and exact fp32 for HITNet (default, parity-"
+                         "tested at 1e-3 px); fp32 = exact-fp32 kernels everywhere; bf16 = bf16 operands / fp32 "
+                         "accumulate everywhere (BASELINE.json configs[4])")
     ap.add_argument("--stereo-only", action="store_true")
     ap.add_argument("--tune-db", default=None,
                     help="JSON file of tuned launch configurations: loaded if it exists (no tuning launches, e.g. under "
@@ -102,7 +111,8 @@ def conv_roofline(runner, frames, device):
         e.record(torch.cuda.current_stream(device))
         cout = p.Cout * (4 if p.store_mode else 1)
         recs.append((s, e, 2.0 * (p.C0 + p.C1) * cout * p.kh * p.kw * p.Hout * p.Wout * p.B,
-                     (p.B, p.C0 + p.C1, cout, p.kh, p.kw, p.Hout, p.Wout, p.sy, p.store_mode)))
+                     (p.B, p.C0 + p.C1, cout, p.kh, p.kw, p.Hout, p.Wout, p.sy, p.store_mode),
+                     p.terms if p.layout == 2 else 0))
         return rc
 
     ops._launch_conv = timed
@@ -115,34 +125,55 @@ def conv_roofline(runner, frames, device):
     finally:
         ops._launch_conv = orig
         ops.Fork.serial = serial_before
-    t_ms = sum(s.elapsed_time(e) for s, e, _, _ in recs)
-    flops = sum(f for _, _, f, _ in recs)
+    t_ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+    flops = sum(r[2] for r in recs)
+    fam = {}  # kernel family -> [launches, ms, algorithmic flop, issued MFMA flop]
+    for s, e, f, _, terms in recs:
+        c = fam.setdefault("split_bf16" if terms == 3 else "bf16" if terms == 1 else "fp32", [0, 0.0, 0.0, 0.0])
+        c[0] += 1; c[1] += s.elapsed_time(e); c[2] += f; c[3] += f * max(terms, 1)
     if os.environ.get("CODD_BENCH_VERBOSE"):  # per-shape table (dev aid): count, total ms, TFLOP/s
         by = {}
-        for s, e, f, key in recs:
+        for s, e, f, key, terms in recs:
+            key = key + (terms,)
             c = by.setdefault(key, [0, 0.0, 0.0])
             c[0] += 1; c[1] += s.elapsed_time(e); c[2] += f
         for key, (n, ms, f) in sorted(by.items(), key=lambda kv: -kv[1][1]):
-            log("conv B%d Cin%-4d Cout%-4d k%dx%d out %3dx%-3d s%d m%d : n=%3d  %7.3f ms  %6.1f us/launch  %5.1f TF"
+            log("conv B%d Cin%-4d Cout%-4d k%dx%d out %3dx%-3d s%d m%d terms%d : n=%3d  %7.3f ms  %6.1f us/launch  %5.1f TF"
                 % (*key, n, ms, ms / n * 1e3, f / ms / 1e9))
-    return dict(launches=len(recs), time_ms=t_ms, gflop=flops / 1e9)
+    return dict(launches=len(recs), time_ms=t_ms, gflop=flops / 1e9,
+                families={k: dict(launches=v[0], ms=round(v[1], 3), gflop=round(v[2] / 1e9, 2),
+                                  issued_gflop=round(v[3] / 1e9, 2)) for k, v in fam.items()})
 
 
 def cpu_baseline(args):
-    """Oracle (CPU port of the reference's PyTorch path) on a bounded sample: one steady-state frame
-    of full CODD at ~1/5 of the pixels (448x256), iters=16, on min(host cores, --cpu-threads) threads
-    (the 256-hardware-thread GPU host stalls torch's CPU pool when all of them are requested)."""
+    """Oracle (CPU port of the reference's PyTorch path), MEASURED, no scaling:
+      (a) BASELINE.json configs[0]: HITNetMF stereo-only, 2-frame 512x256 sequence;
+      (b) one steady-state frame (frame 1: motion + fusion run) of the benchmarked configuration at its full
+          size (960x576, iters=16) -- this is `value`.
+    min(host cores, --cpu-threads) threads (the 256-hardware-thread GPU host stalls torch's CPU pool when all of
+    them are requested)."""
     from codd_amd import configs, synth
     from codd_amd.registry import build_estimator
     from oracle import codd as oc
-    h, w = 256, 448  # multiple of 64 (the pipeline pads to 64)
     cores = max(1, min(os.cpu_count() or 1, args.cpu_threads))
     torch.set_num_threads(cores)
+    # (a) configs[0]
+    est = build_estimator(configs.stereo_only()).eval()
+    synth.load_synthetic_weights(est, gain=1.4)
+    sd = est.state_dict()
+    img, r_img, _ = synth.stereo_sequence(256, 512, 2)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        for f in range(2):
+            oc.frame(sd, img[:, f], r_img[:, f], {}, None, with_motion=False, with_fusion=False)
+        dt1 = time.perf_counter() - t0
+    # (b) the benchmarked configuration, one steady-state frame
+    h, w = args.height, args.width
     est = build_estimator(configs.stereo_only() if args.stereo_only else configs.codd(iters=args.iters)).eval()
     synth.load_synthetic_weights(est, gain=1.4)
     sd = est.state_dict()
     img, r_img, _ = synth.stereo_sequence(h, w, 2)
-    intr = (1050.0 * w / PAD_W, 1050.0 * w / PAD_W, w / 2.0, h / 2.0)
+    intr = (1050.0, 1050.0, 480.0, 270.0)
     state = {}
     with torch.no_grad():
         oc.frame(sd, img[:, 0], r_img[:, 0], state, intr, iters=args.iters, with_motion=not args.stereo_only,
@@ -151,18 +182,20 @@ def cpu_baseline(args):
         oc.frame(sd, img[:, 1], r_img[:, 1], state, intr, iters=args.iters, with_motion=not args.stereo_only,
                  with_fusion=not args.stereo_only)
         dt = time.perf_counter() - t0
-    scale = (h * w) / float(PAD_H * PAD_W)
-    return dict(value=round(scale / dt, 5), unit="frames/s", cores=cores, kind="port",
-                sample=f"1 steady-state frame of the CPU oracle at {w}x{h} ({scale:.3f} of the 960x576 pixels, "
-                       f"iters={args.iters}) took {dt:.2f} s on {cores} threads; value = pixel-scaled estimate "
-                       f"for 960x576 (measured {1.0 / dt:.4f} frames/s at {w}x{h})")
+    return dict(value=round(1.0 / dt, 5), unit="frames/s", cores=cores, kind="port",
+                sample=f"1 steady-state frame (frame 1) of the CPU oracle at the benchmarked configuration {w}x{h}, "
+                       f"iters={args.iters}: {dt:.2f} s on {cores} threads (measured, not scaled); "
+                       f"BASELINE.json configs[0] (HITNetMF stereo-only, 2 frames 512x256): {dt1:.2f} s = "
+                       f"{2.0 / dt1:.3f} frames/s on the same threads",
+                configs0_frames_per_s=round(2.0 / dt1, 4))
 
 
-def cpu_baseline_subprocess(args, timeout=240):
+def cpu_baseline_subprocess(args, timeout=420):
     """Run the CPU leg in a child process with a hard wall-clock bound so it can never stall the bench."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--iters", str(args.iters),
-           "--cpu-threads", str(args.cpu_threads)] + (["--stereo-only"] if args.stereo_only else [])
+           "--cpu-threads", str(args.cpu_threads), "--height", str(args.height), "--width", str(args.width)] + (
+               ["--stereo-only"] if args.stereo_only else [])
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     try:
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
@@ -173,6 +206,21 @@ def cpu_baseline_subprocess(args, timeout=240):
                     sample=f"CPU oracle sample did not finish within {timeout} s")
     except Exception as e:  # pragma: no cover
         return dict(value=None, unit="frames/s", cores=args.cpu_threads, kind="port", sample=f"failed: {e!r}")
+
+
+def pin_rank_to_cores(local_rank, local_world):
+    """Give every rank its own contiguous slice of the host cores (the slice of a GPU's own NUMA node when the node
+    exposes one domain per GPU pair, which contiguous numbering does on the 2-socket MI355X hosts) and cap the
+    intra-op thread pools: N launcher processes otherwise all spin on the same cores."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = max(1, len(cores) // max(1, local_world))
+        mine = cores[local_rank * per:(local_rank + 1) * per] or cores
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(8, len(mine))))
+        return mine
+    except (AttributeError, OSError):  # pragma: no cover (non-Linux)
+        return None
 
 
 def main():
@@ -191,6 +239,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    pin_rank_to_cores(local, max(world, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
 
     from codd_amd import metrics, synth
     from codd_amd.runtime import FrameRunner, PipelinedRunner
@@ -202,13 +251,14 @@ def main():
     _ops_tune.enable_autotune(not args.no_autotune, shipped=not args.retune and not args.tune_db)
     if args.tune_db and os.path.exists(args.tune_db):
         _ops_tune.load_tune_db(args.tune_db)
+    _ops_tune.set_conv_precision(args.precision)
     est = build_model(args, device)
     if args.serial_streams:
         from codd_amd import ops as _ops
         _ops.Fork.serial = True
     H, W = args.height, args.width
     MF = 6  # distinct synthetic frames, cycled (frame t+1 = frame t translated by a sub-pixel flow)
-    img, r_img, gt = synth.stereo_sequence(H, W, MF)
+    img, r_img, gt = synth.stereo_sequence(H, W, MF, flow=(0.75 + 0.125 * rank, 0.25))  # a different video per rank
     img, r_img, gt = img.to(device), r_img.to(device), gt.to(device)
     raw_h, raw_w = (RAW_H, RAW_W) if (H, W) == (PAD_H, PAD_W) else (H, W)
     metas = synth.default_metas(H, W, img_shape=(raw_h, raw_w, 3))
@@ -277,17 +327,30 @@ def main():
                 for i in range(2):
                     rr.step(*frame(i)[:2])
             cr = conv_roofline(rr, (l, r), device)
-            ach = cr["gflop"] / cr["time_ms"]  # GFLOP/ms = TFLOP/s
+            fams = cr["families"]
+            dom = max(fams, key=lambda k_: fams[k_]["ms"])  # dominant kernel family of the frame
+            fd = fams[dom]
+            peak = FP32_MATRIX_PEAK_TFLOPS if dom == "fp32" else BF16_MATRIX_PEAK_TFLOPS
+            ach = fd["issued_gflop"] / fd["ms"]  # GFLOP/ms = TFLOP/s of MFMA work issued
             traffic, tsrc = None, None
-            tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_final_conv_traffic.json")
-            if os.path.exists(tp):  # HBM-side bytes per conv launch from the committed rocprofv3 PMC passes
+            tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_conv_traffic.json")
+            if os.path.exists(tp):  # HBM-side bytes per launch of that family from the committed rocprofv3 PMC passes
                 tj = json.load(open(tp))
-                traffic, tsrc = round(tj["traffic_bytes_per_launch"]), "profiles/r01_final_conv_traffic.json: " + tj["correction"]
-            roof = dict(bound="mfma", achieved=round(ach, 3), peak=FP32_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), traffic=traffic, traffic_unit="bytes/launch (PMC, "
-                        "not collected in this run)", traffic_source=tsrc, kernel="conv_mfma_kernel<*> + conv_quad_kernel<*>",
-                        launches_per_frame=cr["launches"], gflop_per_frame=round(cr["gflop"], 2),
-                        conv_ms_per_frame=round(cr["time_ms"], 3))
+                if tj.get("family") == dom:
+                    traffic, tsrc = round(tj["traffic_bytes_per_launch"]), "profiles/r02_conv_traffic.json: " + tj["correction"]
+            kern = {"split_bf16": "conv_bf16_kernel<*, TERMS=3> (split-bf16: 3 bf16 MFMAs per product, fp32 accumulate)",
+                    "bf16": "conv_bf16_kernel<*, TERMS=1> (bf16 operands, fp32 accumulate)",
+                    "fp32": "conv_mfma_kernel<*> + conv_quad_kernel<*> (exact fp32 MFMA)"}[dom]
+            roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+                        traffic=traffic, traffic_unit="bytes/launch (PMC, separate rocprofv3 passes)", traffic_source=tsrc,
+                        kernel=kern, basis="MFMA FLOPs issued by the family's launches of one frame / their summed HIP-event "
+                        "durations (algorithmic direct-conv FLOPs x MFMA terms per product)",
+                        launches_per_frame=fd["launches"], ms_per_frame=fd["ms"],
+                        algorithmic_tflops=round(fd["gflop"] / fd["ms"], 2),
+                        algorithmic_frac_of_fp32_matrix_peak=round(fd["gflop"] / fd["ms"] / FP32_MATRIX_PEAK_TFLOPS, 4),
+                        families=fams, conv_launches_per_frame=cr["launches"], conv_gflop_per_frame=round(cr["gflop"], 2),
+                        conv_ms_per_frame=round(cr["time_ms"], 3),
+                        whole_conv_algorithmic_tflops=round(cr["gflop"] / cr["time_ms"], 2))
         except Exception as e:  # pragma: no cover
             roof = dict(error=repr(e))
         log(f"roofline pass done: {roof}")
@@ -301,11 +364,15 @@ def main():
                        "frames/sec full CODD forward @960x540 (whole job)"),
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": {"split": "f32 (split-bf16 MFMA operands, f32 accumulate; HITNet exact f32)", "fp32": "f32",
+                      "bf16": "bf16 (MFMA operands; f32 accumulate, f32 everywhere outside the convolutions)"}[args.precision],
+            "data": "synthetic",
             "config": {"workload": ("HITNetMF stereo-only" if args.stereo_only else
                                     "full CODD (HITNetMF + Motion/RAFT3D iters=%d + Fusion)" % args.iters) +
                                    f" {raw_w}x{raw_h} padded to {W}x{H}, max_disp=320, one video per GPU, "
                                    "steady-state frames (idx>=1), synthetic stereo sequence, random-init weights",
+                       "conv_precision": args.precision,
                        "hip_graph": bool(runner.graph is not None), "frames_per_gpu": args.steps,
                        "prewarm_frames": args.prewarm, "side_streams": not args.serial_streams,
                        "conv_autotune": ("off" if args.no_autotune else "%d layer signatures tuned (%d timed in this run's "

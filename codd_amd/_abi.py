@@ -27,6 +27,7 @@ class ConvParams(C.Structure):
         ("act", C.c_int), ("store_mode", C.c_int), ("mb", C.c_int), ("npb", C.c_int), ("nw", C.c_int), ("ck", C.c_int), ("layout", C.c_int),
         ("terms", C.c_int), ("pgw", C.c_int), ("cgw", C.c_int),
         ("xs", C.c_void_p), ("xs_c8", C.c_int), ("xs_hp", C.c_int), ("xs_wp", C.c_int),
+        ("xs_bt", C.c_int), ("xs_bl", C.c_int), ("xs_o8", C.c_int),
     ]
 
 
@@ -82,7 +83,7 @@ SIGNATURES = {
     "codd_fusion_blend": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 3  # CODD_ABI_VERSION of include/codd_hip.h
+ABI_VERSION = 4  # CODD_ABI_VERSION of include/codd_hip.h
 _lib = None
 MISSING = []
 

@@ -108,9 +108,10 @@ static inline int convb_geometry(const codd_conv_params* pp, ConvB& k, size_t& l
   if ((k.nring - 1) * (cdiv(k.wslots >> 6, CONVB_NWP) + cdiv(k.ibuf16 >> 6, CONVB_NWP)) > 56) return CODD_EUNSUPPORTED;
   k.xplane = p.xs_c8 * p.xs_hp * p.xs_wp;
   // the split input must hold every halo tile (codd_split_bf16_dims gives a sufficient size)
-  if (need_xs && (!p.xs || p.xs_c8 < k.nchunks * k.noct || p.xs_hp < p.pad_t + p.Hin || p.xs_wp < p.pad_l + p.Win ||
-                  p.xs_hp < (k.tiles_y * k.th - 1) * p.sy + (p.kh - 1) * p.dil_y + 1 ||
-                  p.xs_wp < (k.tiles_x * k.tw - 1) * p.sx + (p.kw - 1) * p.dil_x + 1))
+  if (need_xs && (!p.xs || p.xs_o8 < 0 || p.xs_c8 < p.xs_o8 + k.nchunks * k.noct || p.xs_bt < p.pad_t ||
+                  p.xs_bl < p.pad_l || p.xs_hp < p.xs_bt + p.Hin || p.xs_wp < p.xs_bl + p.Win ||
+                  p.xs_hp < p.xs_bt - p.pad_t + (k.tiles_y * k.th - 1) * p.sy + (p.kh - 1) * p.dil_y + 1 ||
+                  p.xs_wp < p.xs_bl - p.pad_l + (k.tiles_x * k.tw - 1) * p.sx + (p.kw - 1) * p.dil_x + 1))
     return CODD_EINVAL;
   grid = (long long)k.tiles_x * k.tiles_y * k.ncog * p.B;
   if (grid <= 0 || grid > 0x7fffffffLL) return CODD_EINVAL;
@@ -226,9 +227,9 @@ __global__ __launch_bounds__((PGW * CGW + CONVB_NWP) * 64) void conv_bf16_kernel
     const unsigned wl_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint4*)wl;
     const unsigned il_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint4*)il;
     // first record of this tile in an octet plane of the split input (its border makes every halo tile in-bounds)
-    const uint4* xs0 = (const uint4*)p.xs + (size_t)b * NPL * k.xplane +
-                       (size_t)(ty * k.th * p.sy) * p.xs_wp + tx * k.tw * p.sx;
     const int oct_rec = p.xs_hp * p.xs_wp;  // records per octet plane
+    const uint4* xs0 = (const uint4*)p.xs + (size_t)b * NPL * k.xplane + (size_t)p.xs_o8 * oct_rec +
+                       (size_t)(ty * k.th * p.sy + p.xs_bt - p.pad_t) * p.xs_wp + tx * k.tw * p.sx + p.xs_bl - p.pad_l;
     // per-lane record offset of this wave's input pieces (chunk-independent; the first CONVB_MAXP pieces live in
     // registers, configurations with more fall back to recomputing the two divisions per piece)
     auto piece_off = [&](int i_) -> int {

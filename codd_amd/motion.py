@@ -115,9 +115,19 @@ class BasicUpdateBlock(nn.Module):
         step instead of competing with the next correlation-encoder chain."""
         g = self.gru
         fk = self._forks(net.device)[1]
-        t2 = fk.run(0, lambda: ops.conv2d(net, packed_cat((g.convz2, g.convr2)), pad=4, dil=4))
-        t1 = fk.run(1, lambda: ops.conv2d(net, packed_cat((g.convz1, g.convr1)), pad=1))
+        ns = self._split(net)
+        t2 = fk.run(0, lambda: ops.conv2d(net, packed_cat((g.convz2, g.convr2)), pad=4, dil=4, xs=ns))
+        t1 = fk.run(1, lambda: ops.conv2d(net, packed_cat((g.convz1, g.convr1)), pad=1, xs=ns))
         return t1, t2
+
+    def _split(self, t):
+        """One split-bf16 re-layout (border 4: serves the 3x3 and the dilated 3x3 convolutions) of a hidden-state
+        sized tensor, shared by all of its consumers; cached per tensor so that the forked z|r convolutions of the
+        next update and this update's head convolution use the same one."""
+        c = getattr(self, "_xs", None)
+        if c is None or c[0] is not t:
+            c = self._xs = (t, ops.split_input(t, border=4))
+        return c[1]
 
     def _forks(self, dev):
         if getattr(self, "_fk", None) is None or self._fk[0].dev != dev:
@@ -151,19 +161,21 @@ class BasicUpdateBlock(nn.Module):
         fk.join()
         fkz.join()
         zr_g, rh = ops.gru_gate_zr(t1, t2, inp, cor, mot, net)
-        q2 = fk.run(0, lambda: cv(g.convq2, rh))
-        q1 = cv(g.convq1, rh)
+        rs = ops.split_input(rh, border=4)  # one re-layout for both q convolutions
+        q2 = fk.run(0, lambda: cv(g.convq2, rh, xs=rs))
+        q1 = cv(g.convq1, rh, xs=rs)
         fk.join()
         net = ops.gru_gate_q(q1, q2, inp, cor, mot, zr_g, net)
         zr_next = self.zr_convs(net) if prefetch_next else None
         # the four 3x3 head convs share their input: one 768/1024-channel conv; the mask head (576
         # up-sampling weights) is only consumed after the last iteration (raft3d.py:267-273)
         heads = (self.ae[0], self.delta[0], self.weight[0]) + ((self.mask[0],) if need_mask else ())
-        hid = ops.conv2d(net, packed_cat(heads), pad=1, act="relu")
-        delta = fk.run(0, lambda: cv(self.delta[2], Slice(hid, 256, 256)))
-        weight = fk.run(1, lambda: cv(self.weight[2], Slice(hid, 512, 256), act="sigmoid"))
-        mask = fk.run(2, lambda: cv(self.mask[2], Slice(hid, 768, 256))) if need_mask else None
-        ae = cv(self.ae[2], Slice(hid, 0, 256))
+        hid = ops.conv2d(net, packed_cat(heads), pad=1, act="relu", xs=self._split(net))
+        hs = ops.split_input(hid)  # one re-layout of the 768 / 1024 channels for the four 1x1 heads
+        delta = fk.run(0, lambda: cv(self.delta[2], Slice(hid, 256, 256), xs=hs, xs_coff=256))
+        weight = fk.run(1, lambda: cv(self.weight[2], Slice(hid, 512, 256), act="sigmoid", xs=hs, xs_coff=512))
+        mask = fk.run(2, lambda: cv(self.mask[2], Slice(hid, 768, 256), xs=hs, xs_coff=768)) if need_mask else None
+        ae = cv(self.ae[2], Slice(hid, 0, 256), xs=hs, xs_coff=0)
         fk.join()
         return net, mask, ae, delta, weight, zr_next
 

@@ -259,13 +259,48 @@ def _bf16_candidates(pc, Hout, Wout, B, taps, terms):
     return out
 
 
-def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=None, post=None,
-           out=None, pad_tl=None, out_hw=None):
-    """act(conv(cat[x, x2]) + bias + res1 + res2) + post  ->  out (tensor or Slice)."""
+class SplitTensor:
+    """An activation in the split-bf16 conv-input form (include/codd_hip.h, codd_split_bf16): made once by
+    ``split_input`` and consumed by any number of convolutions of that activation (same spatial size, padding up to
+    the border, channel slices at multiples of 8)."""
+    __slots__ = ("buf", "B", "C", "H", "W", "bt", "bl", "hp", "wp", "c8", "terms")
+
+    def __init__(self, buf, B, C, H, W, bt, bl, hp, wp, c8, terms):
+        self.buf, self.B, self.C, self.H, self.W = buf, B, C, H, W
+        self.bt, self.bl, self.hp, self.wp, self.c8, self.terms = bt, bl, hp, wp, c8, terms
+
+
+def split_input(x, x2=None, border=0, c8=None, hp=None, wp=None):
+    """codd_split_bf16 of (x | x2) with a zero border of ``border`` pixels (int or (top, left)); hp / wp default to
+    the size that serves every instantiated tile (rows up to 16, 32-pixel columns) of a stride-1 'same' convolution
+    whose padding does not exceed the border.  Returns None outside the split / bf16 precision modes."""
+    terms = _TERMS.get(CONV_PRECISION, 0)
+    if not terms:
+        return None
     lib = _abi.load()
     xs = _as_slice(x)
     _require_gpu(xs.buf)
-    B, C0, Hin, Win = xs.shape
+    B, C0, H, W = xs.shape
+    C1 = 0 if x2 is None else _as_slice(x2).c
+    bt, bl = (border, border) if isinstance(border, int) else border
+    c8 = -(-(C0 + C1) // 32) * 4 if c8 is None else c8  # whole 32-channel chunks
+    hp = 2 * bt + -(-H // 16) * 16 if hp is None else hp
+    wp = 2 * bl + -(-W // 32) * 32 if wp is None else wp
+    buf = torch.empty(lib.codd_split_bf16_bytes(B, c8, hp, wp, terms), device=xs.buf.device, dtype=torch.uint8)
+    _abi.check(lib.codd_split_bf16(_view(xs), C0, _view(x2), C1, B, H, W, bt, bl, c8, hp, wp, terms, buf.data_ptr(),
+                                   _stream()), "codd_split_bf16")
+    return SplitTensor(buf, B, C0 + C1, H, W, bt, bl, hp, wp, c8, terms)
+
+
+def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=None, post=None,
+           out=None, pad_tl=None, out_hw=None, xs=None, xs_coff=0):
+    """act(conv(cat[x, x2]) + bias + res1 + res2) + post  ->  out (tensor or Slice).
+    ``xs``: a SplitTensor of the input made by split_input (channels [xs_coff, xs_coff + Cin) of it): used instead of
+    a private re-layout when this layer runs on the split-bf16 kernel and the tensor fits its tiles."""
+    lib = _abi.load()
+    xsl = _as_slice(x)
+    _require_gpu(xsl.buf)
+    B, C0, Hin, Win = xsl.shape
     C1 = 0
     if x2 is not None:
         x2s = _as_slice(x2)
@@ -288,28 +323,13 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
         Wout = (Win + pl + pr_ - dx * (pc.kw - 1) - 1) // sx + 1
     up = 2 if pc.deconv else 1
     if out is None:
-        out = torch.empty(B, pc.cout, Hout * up, Wout * up, device=xs.buf.device, dtype=torch.float32)
+        out = torch.empty(B, pc.cout, Hout * up, Wout * up, device=xsl.buf.device, dtype=torch.float32)
     os_ = _as_slice(out)
     assert os_.shape == (B, pc.cout, Hout * up, Wout * up), (os_.shape, (B, pc.cout, Hout * up, Wout * up))
     terms = _TERMS.get(CONV_PRECISION, 0)
     key = (Hout, Wout, B, sy, sx, dy, dx, pl, C1 > 0, terms)
-    cfg = pc.tuned.get(key)
-    tune = False
-    if cfg is None:
-        sig = ("b%d|" % terms if terms else "") + "%d,%d,%d,%d,%d,%d|" % (
-            pc.cout_eff, pc.cin, pc.kh, pc.kw, pc.mb, int(pc.deconv)) + ",".join(str(int(v)) for v in key[:-1])
-        if _AUTOTUNE and sig in TUNE_DB:  # same layer signature already timed (this process or a loaded file)
-            cfg = pc.tuned[key] = tuple(TUNE_DB[sig])
-        elif terms:
-            cfg = None  # first candidate the library accepts (below)
-            tune = _AUTOTUNE and not torch.cuda.is_current_stream_capturing()
-        else:
-            cfg = _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl)
-            tune = _AUTOTUNE and not torch.cuda.is_current_stream_capturing()
-            if not _AUTOTUNE or tune:
-                pc.tuned[key] = cfg  # (while capturing with autotune on: heuristic for this launch, tune later)
     p = ConvParams()
-    p.in0 = _view(xs)
+    p.in0 = _view(xsl)
     p.in1 = _view(x2)
     p.C0, p.C1, p.B, p.Hin, p.Win = C0, C1, B, Hin, Win
     p.bias = None if pc.bias is None else pc.bias.data_ptr()
@@ -320,35 +340,65 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
     p.act = ACT[act]
     p.store_mode = 1 if pc.deconv else 0
     p.terms = terms
-    if terms:  # split-bf16 / bf16 kernel
-        if cfg is None:
-            cands = _bf16_candidates(pc, Hout, Wout, B, pc.kh * pc.kw, terms)
-            if tune:
-                cands = [c for c in cands if _cfg_ok(lib, p, c)]
-                keep = _make_split(lib, p, xs, x2, cands)  # noqa: F841 one split input that serves every candidate
-                cfg = TUNE_DB[sig] = _autotune_b(lib, p, pc, cands)
+
+    cfg = pc.tuned.get(key)
+    if cfg is None:
+        sig = ("b%d|" % terms if terms else "") + "%d,%d,%d,%d,%d,%d|" % (
+            pc.cout_eff, pc.cin, pc.kh, pc.kw, pc.mb, int(pc.deconv)) + ",".join(str(int(v)) for v in key[:-1])
+        capturing = torch.cuda.is_current_stream_capturing()
+        if _AUTOTUNE and sig in TUNE_DB:  # same layer signature already timed (this process or a loaded file)
+            cfg = pc.tuned[key] = tuple(TUNE_DB[sig])
+        elif terms:
+            cands = [c for c in _bf16_candidates(pc, Hout, Wout, B, pc.kh * pc.kw, terms) if _cfg_ok(lib, p, c)]
+            if _AUTOTUNE and not capturing:
+                # measure: best split-bf16 configuration (incl. its re-layout pass) against the best exact-fp32 one --
+                # small or large-map layers can be faster (and are more exact) on the fp32 kernels
+                h32 = _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl)
+                f32cfg, t32 = _autotune(lib, p, pc, h32 + (pc.mb, 0), with_time=True)
+                p.terms = terms
+                bcfg, tb = (None, float("inf"))
+                if cands:
+                    keep = _make_split(lib, p, xsl, x2, cands)  # noqa: F841 one split input serving every candidate
+                    bcfg, tb = _autotune_b(lib, p, pc, cands, xsl, x2)
+                cfg = bcfg if tb < t32 else f32cfg
+                AUTOTUNE_LOG.append(("choice %dx%d %d->%d out %dx%d" % (pc.kh, pc.kw, pc.cin, pc.cout, Hout, Wout),
+                                     f32cfg, t32 * 1e3, cfg, min(tb, t32) * 1e3))
+                pc.tuned[key] = TUNE_DB[sig] = cfg
             else:
-                cfg = next((c for c in cands if _cfg_ok(lib, p, c)), None)
-                if cfg is None:
-                    raise _abi.CoddHipError("no split-bf16 launch configuration for conv %dx%d %d->%d" % (
-                        pc.kh, pc.kw, pc.cin, pc.cout))
-            pc.tuned[key] = cfg
-        if not p.xs:
-            keep = _make_split(lib, p, xs, x2, [cfg])  # noqa: F841 (alive until the launch below is enqueued)
+                cfg = cands[0] if cands else _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl) + (pc.mb, 0)
+                if not _AUTOTUNE:
+                    pc.tuned[key] = cfg  # (capturing with autotune on: heuristic for this launch, tune later)
+        else:
+            cfg = _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl)
+            if _AUTOTUNE and not capturing:
+                cfg = TUNE_DB[sig] = _autotune(lib, p, pc, cfg + (pc.mb, 0))
+            if not _AUTOTUNE or not capturing:
+                pc.tuned[key] = cfg
+
+    if len(cfg) > 4 and cfg[4] == 2:  # split-bf16 / bf16 kernel
+        keep = None
+        if (xs is not None and xs.terms == terms and (xs.B, xs.H, xs.W) == (B, Hin, Win) and xs_coff % 8 == 0 and
+                xs_coff + pc.cin <= xs.C):
+            p.xs, p.xs_c8, p.xs_hp, p.xs_wp = xs.buf.data_ptr(), xs.c8, xs.hp, xs.wp
+            p.xs_bt, p.xs_bl, p.xs_o8 = xs.bt, xs.bl, xs_coff // 8
+            _set_cfg(p, pc, cfg)
+            rc = _launch_conv(lib, p, _stream())
+            if rc == 0:
+                return out
+            if rc != -1:  # -1: the shared tensor does not fit this configuration's tiles -> private re-layout below
+                _abi.check(rc, "codd_conv2d")
+        keep = _make_split(lib, p, xsl, x2, [cfg])  # noqa: F841 (alive until the launch below is enqueued)
         _set_cfg(p, pc, cfg)
         _abi.check(_launch_conv(lib, p, _stream()), "codd_conv2d")
         return out
     npb, nw, ck = cfg[:3]
     mb = cfg[3] if len(cfg) > 3 else pc.mb
     layout = cfg[4] if len(cfg) > 4 else 0
+    p.terms = 0
     p.wpacked = pc.packed(ck, mb, layout).data_ptr()
     p.mb, p.npb, p.nw, p.ck, p.layout = mb, npb, nw, ck, layout
-    if tune:
-        npb, nw, ck, mb, layout = pc.tuned[key] = TUNE_DB[sig] = _autotune(lib, p, pc, (npb, nw, ck, mb, layout))
-        p.wpacked = pc.packed(ck, mb, layout).data_ptr()
-        p.mb, p.npb, p.nw, p.ck, p.layout = mb, npb, nw, ck, layout
     rc = _launch_conv(lib, p, _stream())
-    if rc == -2 and not tune:
+    if rc == -2:
         # a tuned / loaded configuration this build does not support (e.g. a tune db from another version):
         # fall back to the heuristic for this launch shape, loudly
         import warnings
@@ -397,11 +447,13 @@ def _make_split(lib, p, xs, x2, cands):
     _abi.check(lib.codd_split_bf16(_view(xs), p.C0, _view(x2), p.C1, p.B, p.Hin, p.Win, p.pad_t, p.pad_l, c8, hp, wp,
                                    p.terms, buf.data_ptr(), _stream()), "codd_split_bf16")
     p.xs, p.xs_c8, p.xs_hp, p.xs_wp = buf.data_ptr(), c8, hp, wp
+    p.xs_bt, p.xs_bl, p.xs_o8 = p.pad_t, p.pad_l, 0
     return buf
 
 
-def _autotune_b(lib, p, pc, cands):
-    """Time every split-bf16 candidate the library accepts (scratch output, see _autotune) and keep the fastest."""
+def _autotune_b(lib, p, pc, cands, xsl, x2):
+    """Time every split-bf16 candidate the library accepts (scratch output, see _autotune) and keep the fastest;
+    returns (configuration, ms) where the time includes the layer's own re-layout pass (codd_split_bf16)."""
     stream = _stream()
     real_out = p.out
     scratch_out = torch.empty(p.B * p.out_ctot * (4 if p.store_mode else 1) * p.Hout * p.Wout, device=pc._w.device,
@@ -409,7 +461,6 @@ def _autotune_b(lib, p, pc, cands):
     p.out = scratch_out.data_ptr()
     torch.cuda.synchronize()
     best, best_t, first = None, float("inf"), None
-    cands = [c for c in cands if _cfg_ok(lib, p, c)]
     for c in cands[:1] + cands:  # first candidate twice: the first pass warms clocks / caches
         _set_cfg(p, pc, c)
         if _launch_conv(lib, p, stream) != 0:
@@ -434,9 +485,18 @@ def _autotune_b(lib, p, pc, cands):
     used = {pc._pack_key(c) for c in pc.tuned.values()} | {pc._pack_key(best)}
     for k in [k for k in pc._packs if k not in used]:
         del pc._packs[k]
+    # the re-layout pass of the winner (private tensor of exactly its size)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    _make_split(lib, p, xsl, x2, [best])
+    s.record()
+    for _ in range(3):
+        keep = _make_split(lib, p, xsl, x2, [best])  # noqa: F841
+    e.record()
+    e.synchronize()
+    t_split = s.elapsed_time(e) / 3.0
     AUTOTUNE_LOG.append(("b%d %dx%d k%dx%d %d->%d out %dx%d" % (p.terms, p.sy, p.sx, pc.kh, pc.kw, pc.cin, pc.cout, p.Hout,
                                                                 p.Wout), first[0], first[1] * 1e3, best, best_t * 1e3))
-    return best
+    return best, best_t + t_split
 
 
 _AUTOTUNE = bool(int(_os.environ.get("CODD_AUTOTUNE", "0")))
@@ -476,7 +536,8 @@ def enable_autotune(flag=True, shipped=True):
             pass
 
 
-def _autotune(lib, p, pc, default):
+def _autotune(lib, p, pc, default, with_time=False):
+    p.terms = 0
     cin_pad = -(-pc.cin // 4) * 4
     cks = sorted({c for c in (8, 12, 16, 24, 32) if c <= cin_pad} | {min(cin_pad, 32)})
     mbs = [m for m in (1, 2, 4) if m == pc.mb or (16 * m <= max(16, -(-pc.cout_eff // 16) * 16) and pc.cout_eff > 16)]
@@ -532,7 +593,7 @@ def _autotune(lib, p, pc, default):
     p.out = real_out
     AUTOTUNE_LOG.append(("%dx%d k%dx%d %d->%d out %dx%d" % (p.sy, p.sx, pc.kh, pc.kw, pc.cin, pc.cout, p.Hout, p.Wout),
                          default, None if t_default is None else t_default * 1e3, best, best_t * 1e3))
-    return best
+    return (best, best_t) if with_time else best
 
 
 # ----------------------------------------------------------------------------------------- stereo

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CODD_ABI_VERSION 3
+#define CODD_ABI_VERSION 4
 
 #define CODD_OK 0
 #define CODD_EINVAL (-1)
@@ -90,6 +90,9 @@ typedef struct {
    * codd_split_bf16 with borders (pad_t, pad_l): [B][plane][xs_c8 octets][xs_hp][xs_wp][8] bf16 */
   const void* xs;
   int xs_c8, xs_hp, xs_wp;
+  int xs_bt, xs_bl; /* borders the split tensor was made with (>= pad_t, pad_l: one split input can serve several
+                       convolutions of the same activation, e.g. a 3x3 and a dilated 3x3) */
+  int xs_o8;        /* first channel octet of this conv's input inside the split tensor (channel-slice views) */
 } codd_conv_params;
 
 int codd_conv2d(const codd_conv_params* p, void* stream);
@@ -106,8 +109,8 @@ int codd_conv2d_pack_weights_quad(const float* w, float* wpacked, int Cout, int 
 /* Activation re-layout for layout 2: fp32 NCHW views (in0 | in1 concatenated) -> split-bf16 records
  * xs[b][plane hi|lo][octet][yp][xp][8 bf16]; pixel (y, x) sits at (y + bt, x + bl); the border and the channels past
  * C0 + C1 are zero, so that every halo tile of the convolution is in-bounds row segments of 16-byte records (the
- * kernel's LDS-DMA copies them verbatim).  A conv needs bt = pad_t, bl = pad_l, 8 * c8 >= ceil(Cin / ck) * ck and
- * hp >= max(pad_t + H, (tiles_y * th - 1) * sy + (kh - 1) * dil_y + 1), wp likewise (th x 16*npb = its tile).
+ * kernel's LDS-DMA copies them verbatim).  A conv needs bt >= pad_t, bl >= pad_l, 8 * (c8 - xs_o8) >= ceil(Cin / ck) * ck
+ * and hp >= max(bt + H, bt - pad_t + (tiles_y * th - 1) * sy + (kh - 1) * dil_y + 1), wp likewise (th x 16*npb = its tile).
  * terms = 1: hi plane only. */
 long long codd_split_bf16_bytes(int B, int c8, int hp, int wp, int terms);
 int codd_split_bf16(codd_view in0, int C0, codd_view in1, int C1, int B, int H, int W, int bt, int bl,

@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
   void* xs;
   hipMalloc(&xs, (size_t)2 * c8 * hp * wpx * 16);
   hipMemset(xs, 0, (size_t)2 * c8 * hp * wpx * 16);
-  p.xs = xs; p.xs_c8 = c8; p.xs_hp = hp; p.xs_wp = wpx;
+  p.xs = xs; p.xs_c8 = c8; p.xs_hp = hp; p.xs_wp = wpx; p.xs_bt = ks / 2; p.xs_bl = ks / 2;
   ConvB k;
   size_t lds;
   long long grid;
