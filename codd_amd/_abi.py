@@ -61,7 +61,8 @@ SIGNATURES = {
     "codd_cvx_upsample": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "codd_disp_to_depth": (_i, [_p, _ll, _f, _p, _p]),
     "codd_splat": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f,
-                        _p, _p, _p, _i, _p]),
+                        _p, _p, _p, _p]),
+    "codd_splat_scratch": (_ll, [_i, _i, _i, _f]),
     "codd_resize_bilinear": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p]),
     "codd_add_relu": (_i, [_p, _p, _ll, _i, _p, _p]),
     "codd_gru_gate_zr": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),

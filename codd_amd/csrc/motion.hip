@@ -639,18 +639,24 @@ extern "C" int codd_disp_to_depth(const float* disp, long long n, float bf, floa
 
 // ------------------------------------------------------------------------------------------------
 // Forward splat (Motion.transform_and_project, reference motion.py:82-130).
-//   pass 1 (per source point): project, append the point id to the candidate list of every covered
-//           pixel (atomic slot counter; the slot ORDER is irrelevant, see pass 2);
-//   pass 2 (per output pixel): read the candidates' projections back, keep the 8 nearest by (z, id) --
-//           deterministic regardless of the append order -- and composite front to back.
+//   count   (per source point): project, store (u, v, z); count the point on every covered pixel;
+//   reserve (per pixel): claim exactly cnt[pixel] list slots from a global cursor;
+//   fill    (per source point): write the point id into its pixels' lists;
+//   gather  (per output pixel): read ALL of the pixel's candidates back, keep the 8 nearest by (z, id) and
+//           composite front to back.
+// The lists are exact-size (a point covers at most (2*ceil(R)+1)^2 pixel centres, which bounds the buffer), so no
+// candidate is ever dropped however many points pile up on a pixel, and the result does not depend on the order in
+// which the atomics resolve: the slot ORDER inside a list and the list's POSITION in the buffer are arbitrary, the
+// (z, id) selection in pass 4 is not.
 // Pixel centres sit at +0.5 (pytorch3d NDC convention); R = radius * min(H,W) / (2H) pixels.
 // ------------------------------------------------------------------------------------------------
 struct SplatP {
   const float* T; const float* depth; int HT, WT, oy, ox, ds;
   const float* featA; int CA; const float* featB; int CB; int with_flow;
   int H, W; float fx, fy, cx, cy, R; float bf;
-  float* out; float* zout; int* cnt; int* list; int cap;
-  float4* uvz;  // per source point: projected (u, v, z) written by pass 1, read back by pass 2
+  float* out; float* zout;
+  int* cnt; int* off; int* cur; int* cursor; int* list;
+  float4* uvz;  // per source point: projected (u, v, z, valid) written by the count pass
 };
 
 __device__ __forceinline__ bool splat_point(const SplatP& p, int b, int n, float* u, float* v, float* z,
@@ -671,14 +677,9 @@ __device__ __forceinline__ bool splat_point(const SplatP& p, int b, int n, float
   return fabsf(*u) < 1e7f && fabsf(*v) < 1e7f;  // also rejects NaN / inf
 }
 
-__global__ void splat_scatter_kernel(const SplatP p) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  const int b = blockIdx.y;
-  if (n >= p.H * p.W) return;
-  float u = 0.f, v = 0.f, z = 0.f;
-  const bool ok = splat_point(p, b, n, &u, &v, &z, nullptr);
-  p.uvz[(size_t)b * p.H * p.W + n] = make_float4(u, v, z, ok ? 1.f : 0.f);
-  if (!ok) return;
+// visits the pixels covered by the point (u, v): f(global pixel index)
+template <typename F>
+__device__ __forceinline__ void splat_cover(const SplatP& p, int b, float u, float v, F f) {
   const int span = (int)(p.R + 1.5f);
   const int bx = (int)floorf(u - 0.5f), by = (int)floorf(v - 0.5f);
   const float R2 = p.R * p.R;
@@ -689,13 +690,38 @@ __global__ void splat_scatter_kernel(const SplatP p) {
       const int xx = bx + ox;
       if ((unsigned)xx >= (unsigned)p.W) continue;
       const float du = u - ((float)xx + 0.5f), dv = v - ((float)yy + 0.5f);
-      const float d2 = du * du + dv * dv;
-      if (!(d2 < R2)) continue;
-      const size_t pix = (size_t)b * p.H * p.W + (size_t)yy * p.W + xx;
-      const int slot = atomicAdd(&p.cnt[pix], 1);
-      if (slot < p.cap) p.list[pix * p.cap + slot] = n;
+      if (!(du * du + dv * dv < R2)) continue;
+      f((size_t)b * p.H * p.W + (size_t)yy * p.W + xx);
     }
   }
+}
+
+__global__ void splat_count_kernel(const SplatP p) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (n >= p.H * p.W) return;
+  float u = 0.f, v = 0.f, z = 0.f;
+  const bool ok = splat_point(p, b, n, &u, &v, &z, nullptr);
+  p.uvz[(size_t)b * p.H * p.W + n] = make_float4(u, v, z, ok ? 1.f : 0.f);
+  if (!ok) return;
+  splat_cover(p, b, u, v, [&](size_t pix) { atomicAdd(&p.cnt[pix], 1); });
+}
+
+__global__ void splat_reserve_kernel(const SplatP p, long long npix) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= npix) return;
+  const int c = p.cnt[e];
+  p.off[e] = c > 0 ? atomicAdd(p.cursor, c) : 0;
+  p.cur[e] = 0;
+}
+
+__global__ void splat_fill_kernel(const SplatP p) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (n >= p.H * p.W) return;
+  const float4 q = p.uvz[(size_t)b * p.H * p.W + n];
+  if (q.w == 0.f) return;
+  splat_cover(p, b, q.x, q.y, [&](size_t pix) { p.list[p.off[pix] + atomicAdd(&p.cur[pix], 1)] = n; });
 }
 
 __global__ void splat_gather_kernel(const SplatP p) {
@@ -705,7 +731,8 @@ __global__ void splat_gather_kernel(const SplatP p) {
   if (pix >= HW) return;
   const int py = pix / p.W, px = pix - py * p.W;
   const size_t gp = (size_t)b * HW + pix;
-  const int cnt = min(p.cnt[gp], p.cap);
+  const int cnt = p.cnt[gp];
+  const int* lp = p.list + p.off[gp];
   // sorted (z, id) top-8 kept in REGISTERS: every array index below is a compile-time constant after unrolling
   // (a run-time index would push the arrays to scratch memory); empty slots hold (+inf, INT_MAX)
   float kz[8], ka[8];
@@ -715,7 +742,7 @@ __global__ void splat_gather_kernel(const SplatP p) {
   int nk = 0;
   const float R2 = p.R * p.R;
   for (int s = 0; s < cnt; ++s) {
-    const int n = p.list[gp * p.cap + s];
+    const int n = lp[s];
     // 16 bytes written by pass 1 instead of re-loading T (28 B) + depth and redoing the SE3 action per candidate
     const float4 q4 = p.uvz[(size_t)b * HW + n];
     const float du = q4.x - ((float)px + 0.5f), dv = q4.y - ((float)py + 0.5f);
@@ -780,11 +807,26 @@ __global__ void zero_int_kernel(int* p, long long n) {
   if (e < n) p[e] = 0;
 }
 
+static inline float splat_radius_px(float radius, int H, int W) { return radius * (float)(H < W ? H : W) / (2.f * (float)H); }
+static inline long long splat_cover_bound(float R) {  // pixel centres inside an open disc of radius R: <= (2 ceil(R) + 1)^2
+  const long long s = 2 * (long long)ceilf(R) + 1;
+  return s * s;
+}
+
+/* ints of `scratch` codd_splat needs: [cnt | off | cur] (3 B H W) + cursor (4, padding) + candidate lists
+ * (B H W * cover bound) + one float4 (u, v, z, valid) per source point */
+extern "C" long long codd_splat_scratch(int B, int H, int W, float radius) {
+  if (B < 1 || H < 1 || W < 1 || !(radius > 0.f)) return -1;
+  const long long n = (long long)B * H * W;
+  return ((3 * n + 4 + 3) & ~3LL) + ((n * splat_cover_bound(splat_radius_px(radius, H, W)) + 3) & ~3LL) + 4 * n;
+}
+
 extern "C" int codd_splat(const float* T, const float* depth, int HT, int WT, int oy, int ox, int ds,
                           const float* featA, int CA, const float* featB, int CB, int with_flow, int B, int H, int W,
                           float fx, float fy, float cx, float cy, float radius, float bf, float* out, float* zout,
-                          int* scratch, int cap, void* stream) {
-  if (!T || !depth || !out || !scratch || ((uintptr_t)scratch & 15) || cap < 8 || CA < 0 || CB < 0 || (CA > 0 && !featA) || (CB > 0 && !featB))
+                          int* scratch, void* stream) {
+  if (!T || !depth || !out || !scratch || ((uintptr_t)scratch & 15) || !(radius > 0.f) || CA < 0 || CB < 0 ||
+      (CA > 0 && !featA) || (CB > 0 && !featB))
     return CODD_EINVAL;
   if (oy + ds * (H - 1) >= HT || ox + ds * (W - 1) >= WT) return CODD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
@@ -792,17 +834,25 @@ extern "C" int codd_splat(const float* T, const float* depth, int HT, int WT, in
   p.T = T; p.depth = depth; p.HT = HT; p.WT = WT; p.oy = oy; p.ox = ox; p.ds = ds;
   p.featA = featA; p.CA = CA; p.featB = featB; p.CB = CB; p.with_flow = with_flow;
   p.H = H; p.W = W; p.fx = fx; p.fy = fy; p.cx = cx; p.cy = cy;
-  p.R = radius * (float)(H < W ? H : W) / (2.f * (float)H);
+  p.R = splat_radius_px(radius, H, W);
   p.bf = bf; p.out = out; p.zout = zout;
-  p.cnt = scratch; p.list = scratch + (size_t)B * H * W; p.cap = cap;
-  p.uvz = (float4*)(scratch + ((((size_t)B * H * W * (1 + cap)) + 3) & ~(size_t)3));  // 16-byte aligned
-  // zero the per-pixel candidate counters with a kernel (a plain kernel node under graph capture;
-  // hipMemsetAsync becomes a memset node whose ordering against neighbouring kernel nodes is not
-  // relied upon)
-  zero_int_kernel<<<cdiv((long long)B * H * W, 256), 256, 0, s>>>(p.cnt, (long long)B * H * W);
+  const long long n = (long long)B * H * W;
+  const long long nlist = (n * splat_cover_bound(p.R) + 3) & ~3LL;
+  if (nlist > 0x7fffffffLL) return CODD_EUNSUPPORTED;  // list offsets are 32-bit
+  const long long nhead = (3 * n + 4 + 3) & ~3LL;  // counters + cursor, padded to 16 bytes
+  p.cnt = scratch; p.off = scratch + n; p.cur = scratch + 2 * n; p.cursor = scratch + 3 * n;
+  p.list = scratch + nhead;
+  p.uvz = (float4*)(scratch + nhead + nlist);  // 16-byte aligned: scratch is, nhead and nlist are multiples of 4 ints
+  // zero the counters + cursor with a kernel (a plain kernel node under graph capture; hipMemsetAsync becomes a
+  // memset node whose ordering against neighbouring kernel nodes is not relied upon)
+  zero_int_kernel<<<cdiv(3 * n + 4, 256), 256, 0, s>>>(scratch, 3 * n + 4);
   CODD_LAUNCH_CHECK();
   dim3 grid(cdiv(H * W, 256), B);
-  splat_scatter_kernel<<<grid, 256, 0, s>>>(p);
+  splat_count_kernel<<<grid, 256, 0, s>>>(p);
+  CODD_LAUNCH_CHECK();
+  splat_reserve_kernel<<<cdiv(n, 256), 256, 0, s>>>(p, n);
+  CODD_LAUNCH_CHECK();
+  splat_fill_kernel<<<grid, 256, 0, s>>>(p);
   CODD_LAUNCH_CHECK();
   splat_gather_kernel<<<grid, 256, 0, s>>>(p);
   CODD_LAUNCH_CHECK();

@@ -295,11 +295,9 @@ class Motion(nn.Module):
         T_up = outputs["Ts"]
         B, H, W = depth_prev.shape
         # full-resolution warp of [img_prev | induced flow | confidence]; depth -> disparity fused
-        warped, disp_warp = ops.splat(T_up, depth_prev, img_prev, outputs["weight"], True, H, W, 0, 0, 1, K, 2.0,
-                                      bf=bf, cap=16)
+        warped, disp_warp = ops.splat(T_up, depth_prev, img_prev, outputs["weight"], True, H, W, 0, 0, 1, K, 2.0, bf=bf)
         # 1/ds-resolution feature warp with T, depth sampled at [o::ds, o::ds] and K / ds
         ds, o = self.ds_scale, self.ds_scale // 2 - 1
         Kd = [float(v / np.float32(ds)) for v in intr]
-        feat_warp, _ = ops.splat(T_up, depth_prev, feat_prev, None, False, H // ds, W // ds, o, o, ds, Kd, 4.0,
-                                 cap=48)
+        feat_warp, _ = ops.splat(T_up, depth_prev, feat_prev, None, False, H // ds, W // ds, o, o, ds, Kd, 4.0)
         state["memory"] = [warped[:, :3], feat_warp, warped[:, 6:], disp_warp, warped[:, 3:6]]

@@ -738,7 +738,7 @@ def disp_to_depth(disp, bf):
     return out
 
 
-def splat(T, depth, featA, featB, with_flow, H, W, oy, ox, ds, K, radius, bf=0.0, cap=32):
+def splat(T, depth, featA, featB, with_flow, H, W, oy, ox, ds, K, radius, bf=0.0):
     """T [B,HT,WT,7], depth [B,HT,WT] sampled at (oy+ds*y, ox+ds*x) -> (out [B,C,H,W], z [B,1,H,W])."""
     lib = _abi.load()
     B, HT, WT, _ = T.shape
@@ -747,12 +747,12 @@ def splat(T, depth, featA, featB, with_flow, H, W, oy, ox, ds, K, radius, bf=0.0
     Cc = CA + (3 if with_flow else 0) + CB
     out = _f32(B, Cc, H, W, like=T)
     z = _f32(B, 1, H, W, like=T)
-    scratch = torch.empty(-(-(B * H * W * (1 + cap)) // 4) * 4 + 4 * B * H * W, device=T.device, dtype=torch.int32)
+    scratch = torch.empty(lib.codd_splat_scratch(B, H, W, float(radius)), device=T.device, dtype=torch.int32)
     _abi.check(lib.codd_splat(T.data_ptr(), depth.data_ptr(), HT, WT, oy, ox, ds,
                               None if featA is None else featA.data_ptr(), CA,
                               None if featB is None else featB.data_ptr(), CB, int(with_flow), B, H, W, *K,
-                              float(radius), float(bf), out.data_ptr(), z.data_ptr(), scratch.data_ptr(), cap,
-                              _stream()), "splat")
+                              float(radius), float(bf), out.data_ptr(), z.data_ptr(), scratch.data_ptr(), _stream()),
+               "splat")
     return out, z
 
 

@@ -226,12 +226,14 @@ int codd_disp_to_depth(const float* disp, long long n, float bf, float* depth, v
  *   feat channels = concat(featA [CA], flow(3, computed when with_flow), featB [CB]);
  *   out [B,C,H,W], zout [B,1,H,W] (nearest z, 0 when empty) or disparity when bf > 0:
  *   disp = bf/(z+1e-5), > W -> 0 (motion.py:190-193).
- * scratch: 16-byte aligned, round_up(B*H*W*(1+cap), 4) + 4*B*H*W ints (counters, candidate lists, one
- * float4 (u, v, z, valid) per source point); cap = candidate-list capacity per pixel (>= 8). */
+ * scratch: 16-byte aligned, codd_splat_scratch(B, H, W, radius) ints (per-pixel counters / list offsets, EXACT-SIZE
+ * candidate lists -- a point covers at most (2 ceil(R) + 1)^2 pixel centres, R = radius min(H,W) / (2H) px, which
+ * bounds them: no candidate is ever dropped -- and one float4 (u, v, z, valid) per source point). */
+long long codd_splat_scratch(int B, int H, int W, float radius);
 int codd_splat(const float* T, const float* depth, int HT, int WT, int oy, int ox, int ds,
                const float* featA, int CA, const float* featB, int CB, int with_flow,
                int B, int H, int W, float fx, float fy, float cx, float cy, float radius,
-               float bf, float* out, float* zout, int* scratch, int cap, void* stream);
+               float bf, float* out, float* zout, int* scratch, void* stream);
 
 /* induced_flow (projective_ops.py:55-68): out [B,H,W,3] = project(T*X0) - project(X0). */
 int codd_induced_flow(const float* T, const float* depth, int B, int H, int W,

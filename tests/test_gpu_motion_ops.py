@@ -126,7 +126,7 @@ def test_splat(ds, radius, C):
     feat = rnd(B, C, H, W, seed=2)
     Ts, ds_ = T[:, o::ds, o::ds], depth[:, o::ds, o::ds]
     ref, zref = om.splat(Ts, ds_, feat, torch.tensor([K]), radius)
-    got, z = ops.splat(T.to(DEV), depth.to(DEV), feat.to(DEV), None, False, H, W, o, o, ds, K, radius, cap=48)
+    got, z = ops.splat(T.to(DEV), depth.to(DEV), feat.to(DEV), None, False, H, W, o, o, ds, K, radius)
     bad = ((got.cpu() - ref).abs().amax(1) > 1e-3).float().mean().item()
     badz = ((z.cpu() - zref).abs() > 1e-3).float().mean().item()
     print("splat mismatching pixels", bad, badz, "coverage", (zref > 0).float().mean().item())
@@ -135,13 +135,45 @@ def test_splat(ds, radius, C):
     if ds == 1:
         bf = 210.0
         got, dsp = ops.splat(T.to(DEV), depth.to(DEV), feat[:, :3].to(DEV), feat[:, 3:].to(DEV), True, H, W, 0, 0, 1, K,
-                             radius, bf=bf, cap=16)
+                             radius, bf=bf)
         flow = om.induced_flow2d(T, depth, torch.tensor([K])).permute(0, 3, 1, 2)
         ref, zref = om.splat(T, depth, torch.cat([feat[:, :3], flow, feat[:, 3:]], 1), torch.tensor([K]), radius)
         dref = bf / (zref + 1e-5)
         dref = torch.where(dref > W, torch.zeros_like(dref), dref)
         assert ((got.cpu() - ref).abs().amax(1) > 1e-3).float().mean().item() < 1e-3
         assert ((dsp.cpu() - dref).abs() > 1e-3 * (1 + dref.abs())).float().mean().item() < 1e-3
+
+
+def test_splat_pileup_keeps_the_eight_nearest_of_all_candidates():
+    """Thousands of points driven onto three pixels (far beyond any fixed per-pixel capacity), many with EXACTLY
+    equal depth: the exact-size candidate lists must give the oracle's top-8-by-(z, index) composite, bit-for-bit
+    reproducibly across runs (the atomics' order must not matter)."""
+    from codd_amd import ops
+    from oracle import motion as om
+    B, H, W, C = 1, 48, 64, 5
+    K = [40.0, 42.0, 32.0, 24.0]
+    Kt = torch.tensor([K])
+    g = torch.Generator().manual_seed(5)
+    depth = torch.rand(B, H, W, generator=g) * 10 + 3
+    X0 = om.inv_project(depth, Kt).reshape(-1, 3)
+    n = torch.arange(H * W)
+    tgt = torch.tensor([[20.5, 10.5], [21.5, 10.5], [40.5, 30.5]])[n % 3]  # three target pixels (two adjacent)
+    tz = torch.where(n % 4 == 0, torch.full((H * W,), 4.0), 4.0 + 0.001 * (n % 211).float())
+    tu = tgt[:, 0] + 0.4 * torch.sin(n.float() * 0.37)
+    tv = tgt[:, 1] + 0.4 * torch.cos(n.float() * 0.73)
+    P = torch.stack([(tu - K[2]) * tz / K[0], (tv - K[3]) * tz / K[1], tz], -1)
+    T = torch.zeros(B, H, W, 7)
+    T[..., 6] = 1.0
+    T[0].view(-1, 7)[:, :3] = P - X0  # pure translations: T * X0 = P
+    feat = rnd(B, C, H, W, seed=2)
+    ref, zref = om.splat(T, depth, feat, Kt, 2.0)
+    outs = []
+    for _ in range(3):
+        got, z = ops.splat(T.to(DEV), depth.to(DEV), feat.to(DEV), None, False, H, W, 0, 0, 1, K, 2.0)
+        outs.append((got.cpu(), z.cpu()))
+    assert all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:]), "run-to-run differences"
+    assert (outs[0][0] - ref).abs().max().item() < 1e-4 and (outs[0][1] - zref).abs().max().item() < 1e-5
+    assert (zref > 0).sum().item() <= 30  # everything really is piled onto a handful of pixels (~1000 points each)
 
 
 def _model(iters=2):
