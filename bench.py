@@ -51,7 +51,7 @@ def log(msg):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=200, help="timed steady-state frames (reference benchmark_speed.py:36-65 uses 200)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--prewarm", type=int, default=150,
                     help="untimed steady-state frames run before the W warm-up steps so that the GPU clocks and "
@@ -208,6 +208,41 @@ def cpu_baseline_subprocess(args, timeout=420):
         return dict(value=None, unit="frames/s", cores=args.cpu_threads, kind="port", sample=f"failed: {e!r}")
 
 
+def timed_region(step, frame_fn, steps, update_metric, metric_row, device, use_dist):
+    """The contract's timed region: barrier + device sync on both sides of EXACTLY ``steps`` steps, the job's single
+    collective (the all_reduce of the [3,12] metric tensor, codd_amd.metrics.reduce_rows) inside it, and the MAX over
+    ranks of the elapsed time.  ``step(l, r) -> disparity``; ``frame_fn(i) -> (l, r, gt)``; ``update_metric(d, gt)``
+    accumulates on the device without a host sync.  Device-agnostic so that tests/test_bench_dist.py can drive it
+    under gloo with a stub runner.  Returns (seconds, reduced metric dict)."""
+    import torch.distributed as dist
+    from codd_amd import metrics
+
+    def sync():
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+
+    sync()
+    if use_dist:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        l, r, g = frame_fn(i)
+        d = step(l, r)
+        update_metric(d, g)  # on-device EPE meters: 2 HIP launches, no sync
+    red = metrics.reduce_rows([metric_row()], device)  # the job's only collective (RCCL all_reduce)
+    sync()
+    if use_dist:
+        dist.barrier()
+    sync()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    return dt, red
+
+
 def pin_rank_to_cores(local_rank, local_world):
     """Give every rank its own contiguous slice of the host cores (the slice of a GPU's own NUMA node when the node
     exposes one domain per GPU pair, which contiguous numbering does on the 2-socket MI355X hosts) and cap the
@@ -289,25 +324,8 @@ def main():
     log(f"{args.prewarm} pre-warm + {max(args.warmup, 1)} warm-up frames done")
     seqm = metrics.SequenceMetrics(metas[0][0], device)
 
-    torch.cuda.synchronize(device)
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        l, r, g = frame(1 + args.prewarm + args.warmup + i)
-        d = step(l, r)
-        seqm.update_disparity_device(d, g, (raw_h, raw_w))  # on-device EPE meters: 2 HIP launches, no sync
-    red = metrics.reduce_rows([seqm.row()], device)  # the job's only collective (RCCL all_reduce)
-    torch.cuda.synchronize(device)
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
+    dt, red = timed_region(step, lambda i: frame(1 + args.prewarm + args.warmup + i), args.steps,
+                           lambda d, g: seqm.update_disparity_device(d, g, (raw_h, raw_w)), seqm.row, device, use_dist)
 
     log(f"timed region done: {dt:.3f} s")
     if args.tune_db and rank == 0 and not os.path.exists(args.tune_db):
@@ -328,7 +346,9 @@ def main():
                     rr.step(*frame(i)[:2])
             cr = conv_roofline(rr, (l, r), device)
             fams = cr["families"]
-            dom = max(fams, key=lambda k_: fams[k_]["ms"])  # dominant kernel family of the frame
+            # dominant family = where the frame's MFMA work is (the eager event brackets of this pass over-count the
+            # launch-bound small fp32 layers: ~8 us of host launch gap each; profiles/r02_* hold the rocprofv3 durations)
+            dom = max(fams, key=lambda k_: fams[k_]["issued_gflop"])
             fd = fams[dom]
             peak = FP32_MATRIX_PEAK_TFLOPS if dom == "fp32" else BF16_MATRIX_PEAK_TFLOPS
             ach = fd["issued_gflop"] / fd["ms"]  # GFLOP/ms = TFLOP/s of MFMA work issued

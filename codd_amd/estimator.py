@@ -68,7 +68,7 @@ class ConsistentOnlineDynamicDepth(nn.Module):
         returns disparities [B, MF, h, w] cropped to ``img_shape``."""
         self.reset_inference_state()
         img_h, img_w = img_meta[0]["img_shape"][:2]
-        seqm, gt_disp, gt_flow = None, None, None
+        seqm, gt_disp, gt_flow, gt_dc, gt_occ = None, None, None, None, None
         if evaluate:
             # metrics stay on the device (HIP reduction kernels, no per-frame .item() syncs); the
             # reference's calc_metric (model/codd.py:435-521) is restated in codd_amd.metrics.
@@ -77,11 +77,30 @@ class ConsistentOnlineDynamicDepth(nn.Module):
             gt_disp = [g.contiguous() for g in torch.unbind(kwargs["gt_disp"][0], 1)]
             if kwargs.get("gt_flow") is not None:
                 gt_flow = [g.contiguous() for g in torch.unbind(kwargs["gt_flow"][0], 1)]
+            if kwargs.get("gt_disp_change") is not None:  # scene-flow columns (model/codd.py:519-575)
+                gt_dc = [g.contiguous() for g in torch.unbind(kwargs["gt_disp_change"][0], 1)]
+            if kwargs.get("gt_flow_occ") is not None:
+                gt_occ = [(g > 0).contiguous() for g in torch.unbind(kwargs["gt_flow_occ"][0], 1)]
             seqm = SequenceMetrics(img_meta[0], img.device)
         outputs = []
+        # ``use_graph`` (set by the CLI unless --no-graph): steady-state frames run by hipGraph replay through
+        # codd_amd.runtime.FrameRunner (one capture per input shape and camera, reused across videos) instead of ~900
+        # eager launches per frame.  The scene-flow columns need the per-frame SE3 field, so that evaluation stays eager.
+        runner = None
+        if getattr(self, "use_graph", False) and self.motion is not None and self.fusion is not None and gt_dc is None:
+            from .runtime import FrameRunner
+            rkey = (tuple(img.shape[-2:]), tuple(img_meta[0].get("intrinsics", ())), img.device)
+            cache = self.__dict__.setdefault("_runners", {})
+            runner = cache.get(rkey)
+            if runner is None:
+                runner = cache[rkey] = FrameRunner(self, img_meta, use_graph=True)
+            runner.reset()
         for idx, (l_img, r) in enumerate(zip(torch.unbind(img, 1), torch.unbind(r_img, 1))):
-            out = self.consistent_online_depth_estimation(l_img.contiguous(), r.contiguous(), img_meta,
-                                                          self.inference_state)
+            if runner is not None:
+                out = dict(pred_disp=runner.step(l_img.contiguous(), r.contiguous()).clone())
+            else:
+                out = self.consistent_online_depth_estimation(l_img.contiguous(), r.contiguous(), img_meta,
+                                                              self.inference_state)
             pred = out["pred_disp"]
             if reciprocal:
                 pred = img_meta[0]["calib"] / pred
@@ -92,6 +111,12 @@ class ConsistentOnlineDynamicDepth(nn.Module):
                 if idx > 0 and gt_flow is not None:
                     seqm.update_temporal_device(pred, gt_disp[idx], self.inference_state["pred_disp"][-2],
                                                 gt_disp[idx - 1], gt_flow[idx - 1], (img_h, img_w))
+                    if gt_dc is not None and out.get("Ts") is not None:
+                        # with occlusion maps the disparity change belongs to the CURRENT entry and the occlusion to
+                        # the previous frame; without, the change of the PREVIOUS entry is used (model/codd.py:521-540)
+                        seqm.update_scene_flow_device(out["Ts"], self.inference_state["pred_disp"][-2], gt_disp[idx - 1],
+                                                      gt_flow[idx - 1], gt_dc[idx] if gt_occ is not None else gt_dc[idx - 1],
+                                                      None if gt_occ is None else gt_occ[idx - 1], (img_h, img_w))
         if evaluate:
             from .metrics import COLUMNS
             row = seqm.row()
@@ -118,6 +143,11 @@ class ConsistentOnlineDynamicDepth(nn.Module):
                 os.makedirs(os_dir, exist_ok=True)
             with open(out_file.replace(osp.splitext(out_file)[1], ".disp.pred.npz"), "wb") as f:
                 np.savez_compressed(f, disp=disp)
+
+    def invalidate_packed(self):
+        """Drop every cached re-laid-out weight tensor (called by apis.load_checkpoint after a state dict is loaded)."""
+        from .stereo import invalidate_packed
+        invalidate_packed(self)
 
     def train(self, mode=True):
         """reference model/codd.py:601-612 overrides train(); kept chainable here."""

@@ -13,23 +13,21 @@ from . import ops
 from .ops import Slice
 from .registry import register
 
-_PC = {}
-
-
 def packed_cbn(conv, bn):
-    """PackedConv of conv followed by eval-mode BatchNorm (folded); cached per parameter version."""
-    key = (id(conv), id(bn))
+    """PackedConv of conv followed by eval-mode BatchNorm (folded); cached ON the conv module per parameter version
+    (freed with the model; the entry keeps its BatchNorm partner alive, so the id in the key cannot be recycled)."""
     ver = (conv.weight.data_ptr(), conv.weight._version, bn.weight._version, bn.bias._version,
            bn.running_mean._version, bn.running_var._version)
-    ent = _PC.get(key)
+    cache = conv.__dict__.setdefault("_codd_packed_cat", {})
+    key = ("bn", id(bn))
+    ent = cache.get(key)
     if ent is None or ent[0] != ver:
         s = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
         w = conv.weight.detach() * s.view(-1, 1, 1, 1)
         b = bn.bias.detach() - bn.running_mean.detach() * s
         if conv.bias is not None:
             b = b + conv.bias.detach() * s
-        ent = (ver, ops.PackedConv(w, b))
-        _PC[key] = ent
+        ent = cache[key] = (ver, ops.PackedConv(w, b), bn)
     return ent[1]
 
 

@@ -34,7 +34,7 @@ def parse_args(argv=None):
     p.add_argument("--eval", action="store_true", help="needs --disp-dir with .npy ground truth")
     p.add_argument("--disp-dir")
     p.add_argument("--launcher", choices=["none", "pytorch"], default="none")
-    p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay of the frame")
     p.add_argument("--no-autotune", action="store_true", help="static launch heuristics (bit-reproducible runs)")
     return p.parse_args(argv)
 
@@ -98,6 +98,7 @@ def main(argv=None):
         print("no checkpoint given: synthetic weights (outputs are meaningless, timing is not)")
         synth.load_synthetic_weights(model, gain=1.4)
     model = model.to(device).eval()
+    model.use_graph = not args.no_graph  # steady-state frames by hipGraph replay (estimator.inference / FrameRunner)
     ops.enable_autotune(not args.no_autotune)  # time the conv launch configurations once per layer shape
     videos = list_videos(args.img_dir, args.r_img_dir, args.img_suffix)
     mine = apis.shard_loader(videos) if distributed else videos

@@ -27,6 +27,39 @@ def valid_mask(gt_disp, meta, gt_flow_prev=None):
     return m
 
 
+def scene_flow_sums(Ts, pred_prev, gt_disp_prev, gt_flow_prev, gt_disp_change, gt_flow_occ, meta, K):
+    """reference model/codd.py:519-575 restated with torch ops: the five accumulators (count, sum of 3-D end-point
+    errors, sum of 2-D ones, #(3-D < 1 px), #(2-D < 1 px)) of one frame pair as a [5] fp64 tensor.
+    Ts [B,h,w,7] (t, q_xyzw); pred_prev, gt_disp_prev, gt_disp_change [B,1,h,w]; gt_flow_prev [B,2,h,w];
+    gt_flow_occ [B,1,h,w] bool or None.  The SE3 action is the one of the HIP kernels' oracle (oracle/se3.py)."""
+    fx, fy, cx, cy = [float(v) for v in K]
+    mask = valid_mask(gt_disp_prev, meta, gt_flow_prev=gt_flow_prev) & (gt_disp_change.abs() < BF_DEFAULT)
+    if gt_flow_occ is not None:
+        mask = mask & ~gt_flow_occ.bool()
+    depth1 = torch.clip(BF_DEFAULT / pred_prev, max=BF_DEFAULT, min=0).squeeze(1)  # [B,h,w]
+    h, w = depth1.shape[-2:]
+    y, x = torch.meshgrid(torch.arange(h, device=depth1.device, dtype=depth1.dtype),
+                          torch.arange(w, device=depth1.device, dtype=depth1.dtype), indexing="ij")
+    X0 = torch.stack([depth1 * ((x - cx) / fx), depth1 * ((y - cy) / fy), depth1], -1)
+    q, t = Ts[..., 3:], Ts[..., :3]
+    u, wq = q[..., :3], q[..., 3:4]
+    uv = 2.0 * torch.cross(u, X0, dim=-1)
+    X1 = X0 + wq * uv + torch.cross(u, uv, dim=-1) + t
+
+    def proj(X):
+        Z = X[..., 2] + 1e-5
+        return torch.stack([fx * (X[..., 0] / Z) + cx, fy * (X[..., 1] / Z) + cy, 1.0 / Z], -1)
+
+    est = proj(X1) - proj(X0)
+    est = torch.cat([est[..., :2], est[..., 2:] * BF_DEFAULT], -1)
+    gt = torch.cat([gt_flow_prev.permute(0, 2, 3, 1), gt_disp_change.permute(0, 2, 3, 1)], -1)
+    d = est - gt
+    e3 = (d ** 2).sum(-1).sqrt()[mask.squeeze(1)]
+    e2 = (d[..., :2] ** 2).sum(-1).sqrt()[mask.squeeze(1)]
+    return torch.stack([torch.as_tensor(float(e3.numel())), e3.double().sum(), e2.double().sum(),
+                        (e3 < 1.0).double().sum(), (e2 < 1.0).double().sum()]).double().to(depth1.device)
+
+
 def flow_warp_nearest(img, flow):
     """reference utils/warp.py:69-92 with padding_mode='zeros', mode='nearest'."""
     B, _, H, W = img.shape
@@ -70,6 +103,7 @@ class SequenceMetrics:
         self.m = {k: _Meter(device) for k in COLUMNS[:7]}
         self.prev = None
         self.device = device
+        self.sf = None  # [5] fp64 scene-flow accumulators (None until the first update)
 
     def update_disparity_device(self, pred, gt, crop_hw):
         """EPE / 3-px rate of one frame through the HIP metric kernel (2 launches, no torch ops, no
@@ -90,6 +124,22 @@ class SequenceMetrics:
             self._dev_tscratch = torch.empty(6 * 128 * pred.shape[0], device=self.device, dtype=torch.float64)
         ops.tepe_metrics(pred, gt, pred_prev, gt_prev, flow_prev, crop_hw, self.meta["disp_range"][0],
                          self.meta["disp_range"][1], BF_DEFAULT, self._dev_tmeters, self._dev_tscratch)
+
+    def update_scene_flow(self, Ts, pred_prev, gt_disp_prev, gt_flow_prev, gt_disp_change, gt_flow_occ=None):
+        """torch restatement of the reference's scene-flow block for one frame pair (cropped [h,w] maps)."""
+        s = scene_flow_sums(Ts, pred_prev, gt_disp_prev, gt_flow_prev, gt_disp_change, gt_flow_occ, self.meta,
+                            self.meta["intrinsics"])
+        self.sf = s if self.sf is None else self.sf + s
+
+    def update_scene_flow_device(self, Ts, pred_prev, gt_disp_prev, gt_flow_prev, gt_disp_change, gt_flow_occ, crop_hw):
+        """The same through the HIP kernel on full padded [B,*,H,W] device maps (no host sync)."""
+        from . import ops
+        if self.sf is None:
+            self.sf = torch.zeros(5, device=self.device, dtype=torch.float64)
+            self._dev_sscratch = torch.empty(5 * 128 * pred_prev.shape[0], device=self.device, dtype=torch.float64)
+        ops.sceneflow_metrics(Ts, pred_prev, gt_disp_prev, gt_flow_prev, gt_disp_change, gt_flow_occ, crop_hw,
+                              self.meta["disp_range"][0], self.meta["disp_range"][1], BF_DEFAULT,
+                              self.meta["intrinsics"], self.sf, self._dev_sscratch)
 
     def update(self, pred, gt, gt_flow=None):
         """pred, gt [B,1,h,w]; gt_flow [B,2,h,w] = flow from THIS frame to the next (reference
@@ -117,9 +167,12 @@ class SequenceMetrics:
         self.prev = (pred, gt, mask, gt_flow)
 
     def row(self):
-        """[12] fp64 tensor; columns without data are NaN (reference nanmean semantics)."""
+        """[12] fp64 tensor; meter columns without data are NaN (reference nanmean semantics), the five scene-flow
+        accumulators are sums (0 without data, as the reference reports them)."""
         nan = torch.full((), float("nan"), device=self.device, dtype=torch.float64)
-        vals = [self.m[k].avg() for k in COLUMNS[:7]] + [nan] * 5
+        # scene-flow columns are raw sums in the reference (collect_metric, utils/misc.py:62-77): 0 without data
+        sf = self.sf if self.sf is not None else torch.zeros(5, device=self.device, dtype=torch.float64)
+        vals = [self.m[k].avg() for k in COLUMNS[:7]] + [sf[i] for i in range(5)]
         if getattr(self, "_dev_meters", None) is not None:  # HIP-kernel meters take precedence
             dm = self._dev_meters
             ok = dm[2] > 0

@@ -21,19 +21,17 @@ from .stereo import cv, packed
 
 BF_DEFAULT = 1050 * 0.2  # reference motion.py:45
 
-_PCAT = {}
-
-
 def packed_cat(mods):
-    """One PackedConv whose output channels are the concatenation of several same-shape convs."""
-    key = tuple(id(m) for m in mods)
+    """One PackedConv whose output channels are the concatenation of several same-shape convs; cached on the first
+    module (keyed by the partners' identities, which the cache entry keeps alive)."""
     ver = tuple((m.weight.data_ptr(), m.weight._version, m.bias._version) for m in mods)
-    ent = _PCAT.get(key)
+    cache = mods[0].__dict__.setdefault("_codd_packed_cat", {})
+    key = tuple(id(m) for m in mods)
+    ent = cache.get(key)
     if ent is None or ent[0] != ver:
         w = torch.cat([m.weight.detach() for m in mods], 0)
         b = torch.cat([m.bias.detach() for m in mods], 0)
-        ent = (ver, ops.PackedConv(w, b))
-        _PCAT[key] = ent
+        ent = cache[key] = (ver, ops.PackedConv(w, b), tuple(mods))
     return ent[1]
 
 
@@ -257,6 +255,8 @@ class RAFT3D(nn.Module):
             ops.se3_gn_step(T, ae, xyz, delta, weight, d1, K8, radius=32)
         T_up = ops.cvx_upsample(T, mask, 1)
         outputs["Ts"] = T_up
+        # reference raft3d.py:268-270: the induced 2-D flow + inverse-depth change of the up-sampled field
+        outputs["flow2d_est_induced"] = ops.induced_flow(T_up, depth_prev, [float(v) for v in K])
         outputs["weight"] = ops.cvx_upsample(weight, mask, 2)
         state["raft_feat"] = fmap_curr
         ni = self._join("netinp", dev)

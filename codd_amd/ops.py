@@ -890,6 +890,7 @@ def disp_metrics(pred, gt, crop_hw, lo, hi, thr, meters, scratch=None):
     lib = _abi.load()
     _require_gpu(pred)
     B, _, H, W = pred.shape
+    _same_hw(pred, gt)
     if scratch is None:
         scratch = torch.empty(3 * 128 * B, device=pred.device, dtype=torch.float64)
     _abi.check(lib.codd_disp_metrics(pred.data_ptr(), gt.data_ptr(), B, H, W, crop_hw[0], crop_hw[1], float(lo),
@@ -903,11 +904,41 @@ def tepe_metrics(pred, gt, pred_prev, gt_prev, flow_prev, crop_hw, lo, hi, bf, m
     lib = _abi.load()
     _require_gpu(pred)
     B, _, H, W = pred.shape
+    _same_hw(pred, gt, pred_prev, gt_prev, flow_prev)
     if scratch is None:
         scratch = torch.empty(6 * 128 * B, device=pred.device, dtype=torch.float64)
     _abi.check(lib.codd_tepe_metrics(pred.data_ptr(), gt.data_ptr(), pred_prev.data_ptr(), gt_prev.data_ptr(),
                                      flow_prev.data_ptr(), B, H, W, crop_hw[0], crop_hw[1], float(lo), float(hi),
                                      float(bf), scratch.data_ptr(), meters.data_ptr(), _stream()), "tepe_metrics")
+    return meters
+
+
+def _same_hw(ref, *ts):
+    """GT / flow maps handed to the metric kernels must be padded like the prediction: the kernels index them with
+    the prediction's strides (a smaller tensor would be read out of bounds)."""
+    for t in ts:
+        if t is not None and tuple(t.shape[-2:]) != tuple(ref.shape[-2:]):
+            raise ValueError("metric inputs must share the prediction's padded size %s, got %s" % (
+                tuple(ref.shape[-2:]), tuple(t.shape[-2:])))
+
+
+def sceneflow_metrics(Ts, pred_prev, gt_disp_prev, gt_flow_prev, gt_disp_change, gt_flow_occ, crop_hw, lo, hi, bf, K,
+                      meters, scratch=None):
+    """Accumulate the five scene-flow sums of one frame pair into ``meters`` ([5] fp64 on the device)."""
+    lib = _abi.load()
+    _require_gpu(pred_prev)
+    B, _, H, W = pred_prev.shape
+    _same_hw(pred_prev, gt_disp_prev, gt_flow_prev, gt_disp_change, gt_flow_occ)
+    if tuple(Ts.shape) != (B, H, W, 7):
+        raise ValueError("Ts must be [B,H,W,7] at the prediction's padded size")
+    occ = None if gt_flow_occ is None else gt_flow_occ.to(torch.uint8).contiguous()
+    if scratch is None:
+        scratch = torch.empty(5 * 128 * B, device=pred_prev.device, dtype=torch.float64)
+    _abi.check(lib.codd_sceneflow_metrics(Ts.contiguous().data_ptr(), pred_prev.data_ptr(), gt_disp_prev.data_ptr(),
+                                          gt_flow_prev.data_ptr(), gt_disp_change.data_ptr(),
+                                          None if occ is None else occ.data_ptr(), B, H, W, crop_hw[0], crop_hw[1],
+                                          float(lo), float(hi), float(bf), *[float(v) for v in K], scratch.data_ptr(),
+                                          meters.data_ptr(), _stream()), "sceneflow_metrics")
     return meters
 
 

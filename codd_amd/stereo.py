@@ -24,18 +24,22 @@ def _lrelu():
     return nn.LeakyReLU(0.2, inplace=True)
 
 
-_PC = {}
-
-
 def packed(m, deconv=False, cout_keep=None):
-    """PackedConv of an nn.Conv2d / nn.ConvTranspose2d, rebuilt when its parameters change."""
-    key = (id(m), cout_keep)
+    """PackedConv of an nn.Conv2d / nn.ConvTranspose2d, rebuilt when its parameters change.  The pack lives ON the
+    module (``m._codd_packed``), so it is freed with the model and can never be served to another module."""
     ver = (m.weight.data_ptr(), m.weight._version, None if m.bias is None else m.bias._version)
-    ent = _PC.get(key)
+    cache = m.__dict__.setdefault("_codd_packed", {})
+    ent = cache.get(cout_keep)
     if ent is None or ent[0] != ver:
-        ent = (ver, ops.PackedConv(m.weight, m.bias, deconv, cout_keep))
-        _PC[key] = ent
+        ent = cache[cout_keep] = (ver, ops.PackedConv(m.weight, m.bias, deconv, cout_keep))
     return ent[1]
+
+
+def invalidate_packed(module):
+    """Drop every cached pack below ``module`` (apis.load_checkpoint calls this after loading a state dict)."""
+    for m in module.modules():
+        m.__dict__.pop("_codd_packed", None)
+        m.__dict__.pop("_codd_packed_cat", None)
 
 
 def cv(m, x, x2=None, act="none", **kw):

@@ -301,6 +301,17 @@ int codd_tepe_metrics(const float* pred, const float* gt, const float* pred_prev
                       const float* flow_prev, int B, int H, int W, int h, int w, float lo, float hi,
                       float bf, double* scratch, double* meters, void* stream);
 
+/* Scene-flow metric columns (model/codd.py:519-575; utils/misc.py:12-36, 62-77): over the crop [0,h) x [0,w) of
+ * [B,*,H,W] maps and the mask lo < gt_disp_prev < hi & |gt_flow_prev| < bf & |gt_disp_change| < bf (& gt_flow_occ == 0
+ * when given), with est = induced_flow(Ts, clip(bf / pred_prev, 0, bf), K) and est.z * bf (inverse depth ->
+ * disparity): meters[0..4] += count, sum of 3-D end-point errors, sum of 2-D ones, #(3-D < 1 px), #(2-D < 1 px) -- the
+ * reference's count / epe2d_scene_flow / epe2d_optical_flow / 1px_scene_flow / 1px_optical_flow accumulators.
+ * Ts [B,H,W,7]; gt_flow_prev [B,2,H,W]; gt_flow_occ: bytes [B,1,H,W] or NULL.  scratch: 5*128*B doubles. */
+int codd_sceneflow_metrics(const float* Ts, const float* pred_prev, const float* gt_disp_prev,
+                           const float* gt_flow_prev, const float* gt_disp_change, const unsigned char* gt_flow_occ,
+                           int B, int H, int W, int h, int w, float lo, float hi, float bf, float fx, float fy,
+                           float cx, float cy, double* scratch, double* meters, void* stream);
+
 /* Input pre-processing (datasets/transforms.py:147-161,373-427; formating.py:65-85): uint8 HWC image
  * (device) -> fp32 CHW RGB, (x - mean)/std, reflect-padded bottom/right to [3,H,W].  mean/stdv: host
  * pointers to 3 floats in RGB order. */

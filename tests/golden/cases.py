@@ -87,6 +87,25 @@ def metric_case(H=128, W=192, MF=3, h=120, w=180):
     return img, r_img, gt, flow, meta
 
 
+def sceneflow_case(H=64, W=96, MF=3, h=60, w=90):
+    """Inputs of the reference's calc_metric INCLUDING its scene-flow block (model/codd.py:519-575): per-frame
+    predictions, ground truth (disparity, flow, disparity change, flow occlusion) and a dense SE3 field."""
+    from oracle import se3
+    R = _gen(900)
+    pred = (R(1, MF, 1, H, W) * 4 + 30).abs() + 1.0
+    pred[:, 1, :, 3:6, 5:9] = 0.0  # zero disparity: depth = BF / 0 -> clipped to BF
+    gt = pred + 0.5 * R(1, MF, 1, H, W)
+    gt[:, :, :, 10:14, 20:40] = 0.0
+    flow = 2.0 * R(1, MF, 2, H, W)
+    flow[:, :, :, 40:44, 10:20] = 300.0
+    dchange = 0.7 * R(1, MF, 1, H, W)
+    dchange[:, :, :, 30:33, 50:70] = 400.0  # |disp change| >= BF_DEFAULT: excluded
+    occ = R(1, MF, 1, H, W) > 1.2
+    Ts = se3.exp(0.02 * R(1, MF, H, W, 6) + torch.tensor([0.05, -0.03, 0.1, 0.0, 0.0, 0.0]))
+    meta = dict(img_shape=(h, w, 3), disp_range=(1, 210), intrinsics=[80.0, 82.0, W / 2.0, H / 2.0])
+    return dict(pred=pred, gt=gt, flow=flow, dchange=dchange, occ=occ, Ts=Ts, meta=meta, h=h, w=w)
+
+
 def ablation_case(H=32, W=48, hg=30, wg=44):
     """Inputs of the GT / Kalman ablation plug-ins (model/fusion/others.py, model/motion/others.py)."""
     R = _gen(800)

@@ -41,6 +41,7 @@ from model.motion.raft3d.blocks.extractor import BasicEncoder  # noqa: E402
 from model.motion.raft3d.raft3d import BasicUpdateBlock  # noqa: E402
 from model.motion.raft3d.sampler_ops import depth_sampler  # noqa: E402
 from utils import disp_warp  # noqa: E402
+from utils.misc import collect_metric  # noqa: E402
 
 
 def load(module, sd, prefix):
@@ -114,6 +115,37 @@ def main():
         names = [k for k in res.keys()]
         out["metric_values"] = torch.stack([res[k].double().reshape(()) for k in names]).float()
         globals()["_METRIC_NAMES"] = names
+        # ---- scene-flow columns: the reference's own calc_metric (model/codd.py:435-575) driven frame by frame ----
+        # Ts is a lietorch.SE3 in the reference (un-vendored): the stand-in below supplies only indexing and the
+        # action T * X (oracle/se3.py); masks, depth clipping, induced_flow, BF scaling and the sums are the reference's.
+        from oracle import se3 as ose3
+
+        class SE3Field:
+            def __init__(self, data):
+                self.data = data
+
+            def __getitem__(self, idx):
+                return SE3Field(self.data[idx])
+
+            def __mul__(self, X):
+                return ose3.act(self.data, X)
+
+        sc = cases.sceneflow_case()
+        h, w = sc["h"], sc["w"]
+        for tag, with_occ in (("sf", False), ("sfocc", True)):
+            est.reset_inference_state()
+            st = est.inference_state
+            for f in range(sc["pred"].shape[1]):
+                st["gt_disp"].append(sc["gt"][:, f, :, :h, :w])
+                st["gt_flow"].append(sc["flow"][:, f, :, :h, :w])
+                st["gt_disp_change"].append(sc["dchange"][:, f, :, :h, :w])
+                if with_occ:
+                    st["gt_flow_occ"].append(sc["occ"][:, f, :, :h, :w])
+                st["pred_disp"].append(sc["pred"][:, f])
+                est.calc_metric(f, sc["pred"][:, f, :, :h, :w], st["gt_disp"][-1], sc["meta"], h, w,
+                                Ts=SE3Field(sc["Ts"][:, f]) if f > 0 else None)
+            res = collect_metric(st)
+            out[f"metric_{tag}_values"] = torch.stack([torch.as_tensor(res[k]).double().reshape(()) for k in names]).float()
         # ---- ablation plug-ins (GT / Kalman) ---------------------------------------------------------
         from model.fusion.others import GTFusion, KalmanFusion, NullFusion  # noqa: E402
         from model.motion.others import GTMotion  # noqa: E402

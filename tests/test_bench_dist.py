@@ -1,0 +1,71 @@
+"""bench.py's multi-rank control flow under gloo, world_size 2, with a stub runner (no GPU): barrier -> exactly K timed
+steps -> ONE metric all-reduce -> barrier -> MAX over ranks of the elapsed time; one video per rank (weak scaling)."""
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from codd_amd import metrics
+    dev = torch.device("cpu")
+    meta = dict(disp_range=(1, 210))
+    seqm = metrics.SequenceMetrics(meta, dev)
+    calls = dict(step=0, coll=0)
+    real_all_reduce = dist.all_reduce
+
+    def counting_all_reduce(t, *a, **k):
+        calls["coll"] += 1
+        return real_all_reduce(t, *a, **k)
+
+    dist.all_reduce = counting_all_reduce
+    gt = torch.full((1, 1, 8, 12), 20.0)
+
+    def step(l, r):  # stub runner: rank 1 is the slow one, its prediction is off by (1 + rank) px
+        calls["step"] += 1
+        time.sleep(0.01 * (1 + 3 * rank))
+        return gt + (1.0 + rank)
+
+    steps = 5
+    dt, red = bench.timed_region(step, lambda i: (None, None, gt), steps, lambda d, g: seqm.update(d, g), seqm.row,
+                                 dev, True)
+    out[rank] = dict(dt=dt, steps=calls["step"], coll=calls["coll"], epe=red["epe"])
+    dist.destroy_process_group()
+
+
+def test_bench_timed_region_world_size_2():
+    port = 29600 + os.getpid() % 300
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+        r0, r1 = out[0], out[1]
+    assert r0["steps"] == r1["steps"] == 5                      # exactly K steps on every rank
+    assert r0["coll"] == r1["coll"] == 2                        # the metric all-reduce + the MAX of dt, nothing else
+    assert r0["dt"] == r1["dt"] and r0["dt"] >= 5 * 0.04 * 0.9  # every rank reports the SLOWEST rank's time
+    mean, std, n = r0["epe"]
+    assert n == 2 and abs(mean - 1.5) < 1e-9 and abs(std - 0.5) < 1e-9 and r1["epe"] == r0["epe"]  # one video per rank
+
+
+def test_rank_core_pinning_partitions_the_host():
+    import bench
+    before = os.sched_getaffinity(0)
+    try:
+        if len(before) < 2:
+            return
+        a = bench.pin_rank_to_cores(0, 2)
+        os.sched_setaffinity(0, before)
+        b = bench.pin_rank_to_cores(1, 2)
+        assert a and b and not (set(a) & set(b)) and set(a) | set(b) <= set(before)
+    finally:
+        os.sched_setaffinity(0, before)
+        torch.set_num_threads(max(1, min(8, len(before))))

@@ -118,3 +118,35 @@ def test_headline_configuration_matches_oracle(name):
         print(f"{name}: worst per-frame mean |delta| over ALL pixels {worst:.3e} px")
     finally:
         ops.enable_autotune(False)
+
+
+def test_bf16_variant_tartanair_shape():
+    """BASELINE.json configs[4]: full CODD at the TartanAir shape with the bf16 conv path (every convolution on bf16
+    MFMA operands with fp32 accumulation -- reference hook: auto_fp16, model/codd.py:37,128; correlation, Gauss-Newton,
+    SE3 and splat stay fp32).  bf16 keeps 8 mantissa bits, so this is NOT the 1e-3 px path: the test reports the measured
+    deviation from the fp32 oracle and asserts the bound it meets -- median |delta| < 0.5 px, 90th percentile < 4 px
+    on ~52 px disparities (measured on MI355X: median 0.21 px, p90 1.8 px; HITNet's disparity-carrying channels are
+    bf16-quantised to 2^-8 relative = 0.2 px at 50 px) -- against 3e-6 / 3e-5 px for the split-bf16 default."""
+    from codd_amd import ops, synth
+    from codd_amd.runtime import FrameRunner
+    name = "cfg5_tartanair_640x512"
+    H, W, intr, img_shape, stereo_only, MF = CASES[name]
+    est, sd = _build(stereo_only)
+    ref = oracle_frames(name, sd)
+    est = est.to(DEV)
+    img, r_img, _ = synth.stereo_sequence(H, W, MF)
+    metas = synth.default_metas(H, W, img_shape=img_shape, intrinsics=intr)
+    prev = ops.set_conv_precision("bf16")
+    try:
+        runner = FrameRunner(est, metas[0], use_graph=True)
+        for f in range(MF):
+            d = runner.step(img[:, f].to(DEV).contiguous(), r_img[:, f].to(DEV).contiguous()).cpu()
+            diff = (d - ref[f]).abs().flatten()
+            med, p90, mean = diff.median().item(), diff.kthvalue(int(0.9 * diff.numel())).values.item(), diff.mean().item()
+            print(f"bf16 {name} frame {f}: median |d| {med:.3e}  p90 {p90:.3e}  mean {mean:.3e} px "
+                  f"(mean disparity {ref[f].abs().mean().item():.1f} px)")
+            assert torch.isfinite(d).all()
+            assert med < 0.5 and p90 < 4.0, (med, p90)
+        assert runner.graph is not None
+    finally:
+        ops.set_conv_precision(prev)

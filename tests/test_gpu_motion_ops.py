@@ -326,6 +326,56 @@ def test_tepe_metrics_kernel_matches_torch_reference():
         assert abs(rt[i].item() - rd[i].item()) < 1e-5 * max(1.0, abs(rt[i].item())), (metrics.COLUMNS[i], rt[i], rd[i])
 
 
+def test_sceneflow_metrics_kernel_matches_torch_restatement():
+    """HIP scene-flow accumulators vs codd_amd.metrics.scene_flow_sums (itself pinned to the reference's calc_metric by
+    tests/test_oracle_golden.py), on padded maps with a crop, zero predictions, invalid GT and occlusions."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import cases
+    from codd_amd import metrics
+    sc = cases.sceneflow_case()
+    h, w = sc["h"], sc["w"]
+    for with_occ in (False, True):
+        st, sd = metrics.SequenceMetrics(sc["meta"], torch.device("cpu")), metrics.SequenceMetrics(sc["meta"], torch.device(DEV))
+        for f in range(1, sc["pred"].shape[1]):
+            dc = sc["dchange"][:, f if with_occ else f - 1]
+            occ = sc["occ"][:, f - 1] if with_occ else None
+            crop = lambda t_: t_[..., :h, :w]
+            st.update_scene_flow(sc["Ts"][:, f, :h, :w], crop(sc["pred"][:, f - 1]), crop(sc["gt"][:, f - 1]),
+                                 crop(sc["flow"][:, f - 1]), crop(dc), None if occ is None else crop(occ))
+            sd.update_scene_flow_device(sc["Ts"][:, f].to(DEV), sc["pred"][:, f - 1].to(DEV), sc["gt"][:, f - 1].to(DEV),
+                                        sc["flow"][:, f - 1].contiguous().to(DEV), dc.to(DEV),
+                                        None if occ is None else occ.to(DEV), (h, w))
+        a, b = st.row()[7:], sd.row()[7:].cpu()
+        assert a[0].item() == b[0].item() and a[0].item() > 1000
+        for i in range(1, 5):
+            assert abs(a[i].item() - b[i].item()) <= 1e-4 * max(1.0, abs(a[i].item())) + (2.0 if i >= 3 else 0.0), (i, a[i], b[i])
+    with pytest.raises(ValueError):  # unpadded ground truth is refused instead of being read out of bounds
+        sd.update_scene_flow_device(sc["Ts"][:, 1].to(DEV), sc["pred"][:, 0].to(DEV), sc["gt"][:, 0, :, :h, :w].to(DEV),
+                                    sc["flow"][:, 0].contiguous().to(DEV), sc["dchange"][:, 0].to(DEV), None, (h, w))
+
+
+def test_motion_outputs_follow_the_reference_dict_contract():
+    """reference raft3d.py:267-274: motion writes outputs['Ts'], ['flow2d_est_induced'] and ['weight']; the induced
+    flow equals the oracle's induced_flow2d of the up-sampled field."""
+    from codd_amd import synth
+    from oracle import motion as om
+    est, _ = _model(2)
+    H, W = 128, 256
+    img, r_img, _ = synth.stereo_sequence(H, W, 2)
+    metas = synth.default_metas(H, W, intrinsics=(280.0, 280.0, 128.0, 64.0))[0]
+    state = {}
+    for f in range(2):
+        out = est.consistent_online_depth_estimation(img[:, f].to(DEV).contiguous(), r_img[:, f].to(DEV).contiguous(), metas, state)
+        if f == 0:
+            depth_prev = (210.0 / (out["pred_disp"][:, 0] + 1e-5)).clamp(0, 210.0).cpu()
+    assert out["Ts"].shape == (1, H, W, 7) and out["weight"].shape == (1, 3, H, W)
+    fl = out["flow2d_est_induced"]
+    assert fl.shape == (1, H, W, 3)
+    ref = om.induced_flow2d(out["Ts"].cpu(), depth_prev, torch.tensor([[280.0, 280.0, 128.0, 64.0]]))
+    assert (fl.cpu() - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())
+
+
 def test_preprocess_matches_numpy_restatement():
     import numpy as np
     from codd_amd import ops

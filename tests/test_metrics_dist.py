@@ -86,4 +86,4 @@ def test_sequence_metrics_epe_tepe():
     row = sm.row()
     assert abs(row[0].item() - 1.0) < 1e-9  # mean of per-frame EPEs 0.5 and 1.5
     assert abs(row[2].item() - 1.0) < 1e-9  # TEPE: |(1.5) - (0.5)| = 1
-    assert torch.isnan(row[8])
+    assert row[8].item() == 0.0  # scene-flow accumulators are sums: 0 without data (reference collect_metric)

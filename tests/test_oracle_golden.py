@@ -93,6 +93,28 @@ def test_metrics_restatement_matches_reference_calc_metric():
     assert float(ref[2]) > 0 and float(ref[6]) > 0  # the temporal columns were really exercised
 
 
+def test_scene_flow_columns_match_reference_calc_metric():
+    """The five scene-flow accumulators (count, epe2d_scene_flow, epe2d_optical_flow, 1px_*): codd_amd.metrics'
+    restatement against the reference's own calc_metric (model/codd.py:519-575) driven frame by frame with a dense
+    SE3 field (make_golden.py: only indexing and T * X come from a stand-in for lietorch.SE3), with and without
+    occlusion maps (the two branches pick the disparity change of different frames)."""
+    from codd_amd import metrics
+    sc = cases.sceneflow_case()
+    h, w = sc["h"], sc["w"]
+    assert tuple(str(n) for n in G["metric_names"]) == metrics.COLUMNS
+    for tag, with_occ in (("sf", False), ("sfocc", True)):
+        sm = metrics.SequenceMetrics(sc["meta"], torch.device("cpu"))
+        for f in range(1, sc["pred"].shape[1]):
+            crop = lambda t: t[..., :h, :w]
+            sm.update_scene_flow(sc["Ts"][:, f, :h, :w], crop(sc["pred"][:, f - 1]), crop(sc["gt"][:, f - 1]),
+                                 crop(sc["flow"][:, f - 1]), crop(sc["dchange"][:, f if with_occ else f - 1]),
+                                 crop(sc["occ"][:, f - 1]) if with_occ else None)
+        row, ref = sm.row(), G[f"metric_{tag}_values"]
+        for i in range(7, 12):
+            assert abs(row[i].item() - float(ref[i])) <= 2e-5 * max(1.0, abs(float(ref[i]))), (tag, metrics.COLUMNS[i], row[i].item(), ref[i])
+        assert float(ref[7]) > 1000 and float(ref[10]) > 0  # really exercised
+
+
 def test_ablation_plugins_match_reference():
     from oracle import ablation
     c = cases.ablation_case()
