@@ -28,6 +28,8 @@ class ConvParams(C.Structure):
         ("terms", C.c_int), ("pgw", C.c_int), ("cgw", C.c_int),
         ("xs", C.c_void_p), ("xs_c8", C.c_int), ("xs_hp", C.c_int), ("xs_wp", C.c_int),
         ("xs_bt", C.c_int), ("xs_bl", C.c_int), ("xs_o8", C.c_int),
+        ("xso", C.c_void_p), ("xso_c8", C.c_int), ("xso_hp", C.c_int), ("xso_wp", C.c_int), ("xso_bt", C.c_int),
+        ("xso_bl", C.c_int), ("xso_o8", C.c_int), ("xso_terms", C.c_int),
     ]
 
 
@@ -85,7 +87,7 @@ SIGNATURES = {
     "codd_fusion_blend": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 4  # CODD_ABI_VERSION of include/codd_hip.h
+ABI_VERSION = 5  # CODD_ABI_VERSION of include/codd_hip.h
 _lib = None
 MISSING = []
 

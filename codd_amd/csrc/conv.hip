@@ -175,7 +175,7 @@ extern "C" int codd_conv2d(const codd_conv_params* pp, void* stream) {
   if (!pp) return CODD_EINVAL;
   if (pp->layout == 2) {
     const codd_conv_params& q = *pp;
-    if (!q.xs || !q.out || !q.wpacked || q.C0 <= 0 || q.C1 < 0 || q.B < 1 || q.Cout < 1 || q.kh < 1 || q.kw < 1 ||
+    if (!q.xs || (!q.out && !q.xso) || !q.wpacked || q.C0 <= 0 || q.C1 < 0 || q.B < 1 || q.Cout < 1 || q.kh < 1 || q.kw < 1 ||
         q.pad_l < 0 || q.pad_t < 0)
       return CODD_EINVAL;
     if (q.store_mode && (q.kh != 1 || q.kw != 1 || q.res1.ptr || q.res2.ptr || q.post.ptr)) return CODD_EUNSUPPORTED;

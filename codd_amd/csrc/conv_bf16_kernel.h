@@ -113,6 +113,13 @@ static inline int convb_geometry(const codd_conv_params* pp, ConvB& k, size_t& l
                   p.xs_hp < p.xs_bt - p.pad_t + (k.tiles_y * k.th - 1) * p.sy + (p.kh - 1) * p.dil_y + 1 ||
                   p.xs_wp < p.xs_bl - p.pad_l + (k.tiles_x * k.tw - 1) * p.sx + (p.kw - 1) * p.dil_x + 1))
     return CODD_EINVAL;
+  if (need_xs && p.xso) {  // split-record output: plain conv only; the tensor must hold the image inside its borders
+    if (p.store_mode || p.res1.ptr || p.res2.ptr || p.post.ptr || p.act == CODD_ACT_RELU_CH0) return CODD_EUNSUPPORTED;
+    if (p.bias && ((uintptr_t)p.bias & 15)) return CODD_EINVAL;
+    if (!(p.xso_terms == 1 || p.xso_terms == 3) || p.xso_o8 < 0 || p.xso_bt < 0 || p.xso_bl < 0 ||
+        p.xso_c8 < p.xso_o8 + cdiv(k.cout_eff, 8) || p.xso_hp < p.xso_bt + p.Hout || p.xso_wp < p.xso_bl + p.Wout)
+      return CODD_EINVAL;
+  }
   grid = (long long)k.tiles_x * k.tiles_y * k.ncog * p.B;
   if (grid <= 0 || grid > 0x7fffffffLL) return CODD_EINVAL;
   return CODD_OK;
@@ -177,7 +184,7 @@ struct ConvbSched {
   }
 };
 
-template <int PGW, int CGW, int A, int B, int TERMS>
+template <int PGW, int CGW, int A, int B, int TERMS, int OUTF>
 __global__ __launch_bounds__((PGW * CGW + CONVB_NWP) * 64) void conv_bf16_kernel(const ConvB k) {
   constexpr int NWC = PGW * CGW;          // consumer waves
   constexpr int NTP = CONVB_NWP * 64;     // producer threads
@@ -331,12 +338,15 @@ __global__ __launch_bounds__((PGW * CGW + CONVB_NWP) * 64) void conv_bf16_kernel
   {                                                                                                       \
     if (TERMS == 3) {                                                                                     \
       _Pragma("unroll") for (int a = 0; a < A; ++a) _Pragma("unroll") for (int m = 0; m < B; ++m)         \
-        acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bh[a], F.al[m], acc[a][m], 0, 0, 0);        \
+        acc[a][m] = OUTF ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.al[m], F.bh[a], acc[a][m], 0, 0, 0)  \
+                         : __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bh[a], F.al[m], acc[a][m], 0, 0, 0); \
       _Pragma("unroll") for (int a = 0; a < A; ++a) _Pragma("unroll") for (int m = 0; m < B; ++m)         \
-        acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bl[a], F.ah[m], acc[a][m], 0, 0, 0);        \
+        acc[a][m] = OUTF ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.ah[m], F.bl[a], acc[a][m], 0, 0, 0)  \
+                         : __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bl[a], F.ah[m], acc[a][m], 0, 0, 0); \
     }                                                                                                     \
     _Pragma("unroll") for (int a = 0; a < A; ++a) _Pragma("unroll") for (int m = 0; m < B; ++m)           \
-      acc[a][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bh[a], F.ah[m], acc[a][m], 0, 0, 0);          \
+      acc[a][m] = OUTF ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.ah[m], F.bh[a], acc[a][m], 0, 0, 0)    \
+                       : __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bh[a], F.ah[m], acc[a][m], 0, 0, 0);   \
   }
 
   __syncthreads();  // chunk 0 and the entry table are in LDS
@@ -385,6 +395,54 @@ __global__ __launch_bounds__((PGW * CGW + CONVB_NWP) * 64) void conv_bf16_kernel
     return;
   }
 #endif
+  if constexpr (OUTF == 1) {
+    // Split-record epilogue (the output IS the next convolution's input, codd_split_bf16 layout): the MFMA was issued
+    // weights-first, D[m = co 4g + r][n = pixel j], so a lane holds 4 consecutive CHANNELS of one pixel; lanes g and
+    // g ^ 1 (16 apart) own the two halves of a channel octet.  After bias + activation each lane splits its 4 values
+    // into (hi, lo) bf16, the pair swaps one half through ds_bpermute, the even lane stores the 16-byte HI record and
+    // the odd lane the LO record: 16 pixels j -> 256 contiguous bytes per (octet, plane).  No fp32 tensor is written.
+    const int orec = p.xso_hp * p.xso_wp;
+    uint4* xo = (uint4*)p.xso + (size_t)b * (p.xso_terms == 3 ? 2 : 1) * p.xso_c8 * orec;
+    const bool odd = g & 1;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+      const int u = pgi * A + a;
+      const int prow = u / k.xb;
+      const int oy = ty * k.th + prow;
+      const int ox = tx * k.tw + (u - prow * k.xb) * 16 + j;
+      const bool inb = u < k.pu && oy < p.Hout && ox < p.Wout;
+#pragma unroll
+      for (int m = 0; m < B; ++m) {
+        const int co0 = (cog * CGW * B + cgi * B + m) * 16 + 4 * g;  // this lane's first channel
+        f32x4 v = acc[a][m];
+        if (p.bias) {
+          if (co0 + 3 < k.cout_eff) v += *(const f32x4*)(p.bias + co0);  // co0 is a multiple of 4: 16-byte aligned
+          else
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += co0 + r < k.cout_eff ? p.bias[co0 + r] : 0.f;
+        }
+        v = convb_act(v, p.act, 1);  // (CODD_ACT_RELU_CH0 is a per-channel activation of fp32 outputs only)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = co0 + r < k.cout_eff ? v[r] : 0.f;  // channel padding of the octet stays 0
+        unsigned hi2[2], lo2[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const __bf16 h0 = (__bf16)v[2 * q], h1 = (__bf16)v[2 * q + 1];
+          const __bf16 l0 = (__bf16)(v[2 * q] - (float)h0), l1 = (__bf16)(v[2 * q + 1] - (float)h1);
+          hi2[q] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+          lo2[q] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+        }
+        // even lane needs the partner's hi, odd lane the partner's lo
+        const unsigned s0 = odd ? hi2[0] : lo2[0], s1 = odd ? hi2[1] : lo2[1];
+        const unsigned r0 = __shfl_xor(s0, 16, 64), r1 = __shfl_xor(s1, 16, 64);
+        const uint4 rec = odd ? make_uint4(r0, r1, lo2[0], lo2[1]) : make_uint4(hi2[0], hi2[1], r0, r1);
+        const int oct = (co0 >> 3) + p.xso_o8;  // both lanes of the pair: same octet (co0 differs by 4)
+        if (inb && (co0 & ~7) < k.cout_eff && (!odd || p.xso_terms == 3))
+          xo[(size_t)(odd ? p.xso_c8 * orec : 0) + ((size_t)oct * p.xso_hp + oy + p.xso_bt) * p.xso_wp + ox + p.xso_bl] = rec;
+      }
+    }
+    return;
+  }
   // epilogue.  The MFMA is issued with the im2col fragment as its first operand, so D[m = pixel 4g + r][n = co j]:
   // a lane holds FOUR CONSECUTIVE PIXELS of one output channel -- bias is one value per tile, residual / output
   // accesses are 16-byte vectors (4x fewer memory instructions than a channel-major accumulator layout)
@@ -451,9 +509,13 @@ __global__ __launch_bounds__((PGW * CGW + CONVB_NWP) * 64) void conv_bf16_kernel
 #define CONVB_GROUP_D(X) X(4, 1, 4, 1) X(4, 1, 8, 1)
 #define CONVB_GROUP_E(X) X(4, 1, 2, 2) X(4, 1, 2, 1)
 #define CONVB_ALL(X) CONVB_GROUP_A(X) CONVB_GROUP_B(X) CONVB_GROUP_C(X) CONVB_GROUP_D(X) CONVB_GROUP_E(X)
-#define CONVB_DECLARE(PGW, CGW, A, B)                                                     \
-  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1>(const ConvB);      \
-  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3>(const ConvB);
-#define CONVB_DEFINE(PGW, CGW, A, B)                                                      \
-  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1>(const ConvB);             \
-  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3>(const ConvB);
+#define CONVB_DECLARE(PGW, CGW, A, B)                                                        \
+  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, 0>(const ConvB);      \
+  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 0>(const ConvB);      \
+  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, 1>(const ConvB);      \
+  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 1>(const ConvB);
+#define CONVB_DEFINE(PGW, CGW, A, B)                                                         \
+  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, 0>(const ConvB);             \
+  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 0>(const ConvB);             \
+  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, 1>(const ConvB);             \
+  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 1>(const ConvB);

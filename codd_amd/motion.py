@@ -143,13 +143,28 @@ class BasicUpdateBlock(nn.Module):
         g = self.gru
         fk, fkz = self._forks(net.device)
 
+        # conv -> conv links: the producer writes its result as split-bf16 records straight into the consumer's input
+        # tensor (persistent, zero-bordered: ops.split_buffer), so neither an fp32 tensor nor a re-layout pass exists
+        # between them (None outside the split / bf16 precision modes: plain fp32 tensors then)
+        def sb(name, C, border):
+            return ops.split_buffer((id(self), name), net.shape[0], C, net.shape[2], net.shape[3], border, net.device)
+
         def corr_chain():
-            c = cv(self.corr_enc[0], corr, act="relu")
-            c = cv(self.corr_enc[2], c, act="relu")
-            return cv(self.corr_enc[4], c)
+            s0, s2 = sb("corr_enc0", 256, 1), sb("corr_enc2", 256, 0)
+            if s0 is None:
+                c = cv(self.corr_enc[0], corr, act="relu")
+                c = cv(self.corr_enc[2], c, act="relu")
+                return cv(self.corr_enc[4], c)
+            cv(self.corr_enc[0], corr, act="relu", xs_out=s0)
+            cv(self.corr_enc[2], None, act="relu", xs=s0, xs_out=s2)
+            return cv(self.corr_enc[4], None, xs=s2)
 
         def flow_chain():
-            return cv(self.flow_enc[2], cv(self.flow_enc[0], minfo, act="relu"))
+            s0 = sb("flow_enc0", 128, 0)
+            if s0 is None:
+                return cv(self.flow_enc[2], cv(self.flow_enc[0], minfo, act="relu"))
+            cv(self.flow_enc[0], minfo, act="relu", xs_out=s0)
+            return cv(self.flow_enc[2], None, xs=s0)
 
         if zr is None:
             zr = self.zr_convs(net)
@@ -168,12 +183,17 @@ class BasicUpdateBlock(nn.Module):
         # the four 3x3 head convs share their input: one 768/1024-channel conv; the mask head (576
         # up-sampling weights) is only consumed after the last iteration (raft3d.py:267-273)
         heads = (self.ae[0], self.delta[0], self.weight[0]) + ((self.mask[0],) if need_mask else ())
-        hid = ops.conv2d(net, packed_cat(heads), pad=1, act="relu", xs=self._split(net))
-        hs = ops.split_input(hid)  # one re-layout of the 768 / 1024 channels for the four 1x1 heads
-        delta = fk.run(0, lambda: cv(self.delta[2], Slice(hid, 256, 256), xs=hs, xs_coff=256))
-        weight = fk.run(1, lambda: cv(self.weight[2], Slice(hid, 512, 256), act="sigmoid", xs=hs, xs_coff=512))
-        mask = fk.run(2, lambda: cv(self.mask[2], Slice(hid, 768, 256), xs=hs, xs_coff=768)) if need_mask else None
-        ae = cv(self.ae[2], Slice(hid, 0, 256), xs=hs, xs_coff=0)
+        hs = sb("hid", 256 * len(heads), 0)
+        if hs is None:
+            hid = ops.conv2d(net, packed_cat(heads), pad=1, act="relu")
+            sl = lambda i: Slice(hid, 256 * i, 256)
+        else:  # the 768 / 1024 hidden channels only ever exist as the four 1x1 heads' split-form input
+            ops.conv2d(net, packed_cat(heads), pad=1, act="relu", xs=self._split(net), xs_out=hs)
+            sl = lambda i: None
+        delta = fk.run(0, lambda: cv(self.delta[2], sl(1), xs=hs, xs_coff=256))
+        weight = fk.run(1, lambda: cv(self.weight[2], sl(2), act="sigmoid", xs=hs, xs_coff=512))
+        mask = fk.run(2, lambda: cv(self.mask[2], sl(3), xs=hs, xs_coff=768)) if need_mask else None
+        ae = cv(self.ae[2], sl(0), xs=hs, xs_coff=0)
         fk.join()
         return net, mask, ae, delta, weight, zr_next
 

@@ -292,15 +292,51 @@ def split_input(x, x2=None, border=0, c8=None, hp=None, wp=None):
     return SplitTensor(buf, B, C0 + C1, H, W, bt, bl, hp, wp, c8, terms)
 
 
+_SPLIT_BUFFERS = {}
+
+
+def split_buffer(key, B, C, H, W, border=0, device=None):
+    """A PERSISTENT, zero-initialised SplitTensor for activations that a convolution writes directly in split-bf16
+    form (conv2d(..., xs_out=...)): the producer only writes the image interior, so the zero border (and the zero
+    channel padding) made here once stays valid for every later frame.  One buffer per call site (``key``) and shape;
+    returns None outside the split / bf16 precision modes."""
+    terms = _TERMS.get(CONV_PRECISION, 0)
+    if not terms:
+        return None
+    lib = _abi.load()
+    bt, bl = (border, border) if isinstance(border, int) else border
+    k = (key, B, C, H, W, bt, bl, terms, str(device))
+    st = _SPLIT_BUFFERS.get(k)
+    if st is None:
+        c8 = -(-C // 32) * 4
+        hp, wp = 2 * bt + -(-H // 16) * 16, 2 * bl + -(-W // 32) * 32
+        buf = torch.zeros(lib.codd_split_bf16_bytes(B, c8, hp, wp, terms), device=device, dtype=torch.uint8)
+        st = _SPLIT_BUFFERS[k] = SplitTensor(buf, B, C, H, W, bt, bl, hp, wp, c8, terms)
+    return st
+
+
 def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=None, post=None,
-           out=None, pad_tl=None, out_hw=None, xs=None, xs_coff=0):
+           out=None, pad_tl=None, out_hw=None, xs=None, xs_coff=0, xs_out=None, xs_out_coff=0):
     """act(conv(cat[x, x2]) + bias + res1 + res2) + post  ->  out (tensor or Slice).
     ``xs``: a SplitTensor of the input made by split_input (channels [xs_coff, xs_coff + Cin) of it): used instead of
-    a private re-layout when this layer runs on the split-bf16 kernel and the tensor fits its tiles."""
+    a private re-layout when this layer runs on the split-bf16 kernel and the tensor fits its tiles.  ``x`` may be
+    None when the input only exists in split form (it was written by a producer's ``xs_out``).
+    ``xs_out``: write the result as split-bf16 records into this (persistent, zero-bordered: split_buffer) tensor at
+    channel offset ``xs_out_coff`` instead of an fp32 tensor, and return it -- the next convolution then needs no
+    re-layout pass.  Both options pin the layer to the split-bf16 kernel."""
     lib = _abi.load()
-    xsl = _as_slice(x)
-    _require_gpu(xsl.buf)
-    B, C0, Hin, Win = xsl.shape
+    force_split = (x is None) or (xs_out is not None)
+    if x is None:
+        assert xs is not None and x2 is None and xs_coff % 8 == 0
+        _require_gpu(xs.buf)
+        B, C0, Hin, Win = xs.B, pc.cin, xs.H, xs.W
+        xsl = None
+        dev_ = xs.buf.device
+    else:
+        xsl = _as_slice(x)
+        _require_gpu(xsl.buf)
+        B, C0, Hin, Win = xsl.shape
+        dev_ = xsl.buf.device
     C1 = 0
     if x2 is not None:
         x2s = _as_slice(x2)
@@ -322,19 +358,27 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
         Hout = (Hin + pt + pb_ - dy * (pc.kh - 1) - 1) // sy + 1
         Wout = (Win + pl + pr_ - dx * (pc.kw - 1) - 1) // sx + 1
     up = 2 if pc.deconv else 1
-    if out is None:
-        out = torch.empty(B, pc.cout, Hout * up, Wout * up, device=xsl.buf.device, dtype=torch.float32)
-    os_ = _as_slice(out)
-    assert os_.shape == (B, pc.cout, Hout * up, Wout * up), (os_.shape, (B, pc.cout, Hout * up, Wout * up))
     terms = _TERMS.get(CONV_PRECISION, 0)
-    key = (Hout, Wout, B, sy, sx, dy, dx, pl, C1 > 0, terms)
+    if force_split and not terms:
+        raise _abi.CoddHipError("split-form convolution inputs / outputs need the 'split' or 'bf16' conv precision")
+    if xs_out is None:
+        if out is None:
+            out = torch.empty(B, pc.cout, Hout * up, Wout * up, device=dev_, dtype=torch.float32)
+        os_ = _as_slice(out)
+        assert os_.shape == (B, pc.cout, Hout * up, Wout * up), (os_.shape, (B, pc.cout, Hout * up, Wout * up))
+    else:
+        assert (xs_out.B, xs_out.H, xs_out.W) == (B, Hout, Wout) and xs_out.terms == terms and xs_out_coff % 8 == 0
+        assert xs_out_coff + pc.cout <= 8 * xs_out.c8 and not pc.deconv and res1 is None and res2 is None and post is None
+        os_ = None
+    key = (Hout, Wout, B, sy, sx, dy, dx, pl, C1 > 0, terms) + (("split",) if force_split else ())
     p = ConvParams()
     p.in0 = _view(xsl)
     p.in1 = _view(x2)
     p.C0, p.C1, p.B, p.Hin, p.Win = C0, C1, B, Hin, Win
     p.bias = None if pc.bias is None else pc.bias.data_ptr()
     p.res1, p.res2, p.post = _view(res1), _view(res2), _view(post)
-    p.out, p.out_ctot, p.out_coff = os_.buf.data_ptr(), os_.buf.shape[1], os_.coff
+    if os_ is not None:
+        p.out, p.out_ctot, p.out_coff = os_.buf.data_ptr(), os_.buf.shape[1], os_.coff
     p.Cout, p.Hout, p.Wout = pc.cout, Hout, Wout
     p.kh, p.kw, p.sy, p.sx, p.pad_t, p.pad_l, p.dil_y, p.dil_x = pc.kh, pc.kw, sy, sx, pt, pl, dy, dx
     p.act = ACT[act]
@@ -344,10 +388,33 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
     cfg = pc.tuned.get(key)
     if cfg is None:
         sig = ("b%d|" % terms if terms else "") + "%d,%d,%d,%d,%d,%d|" % (
-            pc.cout_eff, pc.cin, pc.kh, pc.kw, pc.mb, int(pc.deconv)) + ",".join(str(int(v)) for v in key[:-1])
+            pc.cout_eff, pc.cin, pc.kh, pc.kw, pc.mb, int(pc.deconv)) + ",".join(str(int(v)) for v in key[:9]) + (
+                "|split" if force_split else "")
         capturing = torch.cuda.is_current_stream_capturing()
         if _AUTOTUNE and sig in TUNE_DB:  # same layer signature already timed (this process or a loaded file)
             cfg = pc.tuned[key] = tuple(TUNE_DB[sig])
+        elif force_split:
+            # pinned to the split-bf16 kernel: the configuration this layer was tuned to in its plain form if that is
+            # a split one, else the first candidate the library accepts
+            cands = [c for c in _bf16_candidates(pc, Hout, Wout, B, pc.kh * pc.kw, terms) if _cfg_ok(lib, p, c)]
+            if not cands:
+                raise _abi.CoddHipError("no split-bf16 launch configuration for conv %dx%d %d->%d" % (
+                    pc.kh, pc.kw, pc.cin, pc.cout))
+            if _AUTOTUNE and not capturing:  # time the candidates on the real split input / output tensors
+                if x is None:
+                    p.xs, p.xs_c8, p.xs_hp, p.xs_wp = xs.buf.data_ptr(), xs.c8, xs.hp, xs.wp
+                    p.xs_bt, p.xs_bl, p.xs_o8 = xs.bt, xs.bl, xs_coff // 8
+                else:
+                    keep = _make_split(lib, p, xsl, x2, cands)  # noqa: F841
+                if xs_out is not None:
+                    p.xso, p.xso_c8, p.xso_hp, p.xso_wp = xs_out.buf.data_ptr(), xs_out.c8, xs_out.hp, xs_out.wp
+                    p.xso_bt, p.xso_bl, p.xso_o8, p.xso_terms = xs_out.bt, xs_out.bl, xs_out_coff // 8, xs_out.terms
+                cfg, _ = _autotune_b(lib, p, pc, cands, None, None)
+                TUNE_DB[sig] = cfg
+            else:
+                plain = TUNE_DB.get(sig[:-6]) if _AUTOTUNE else None
+                cfg = tuple(plain) if plain is not None and len(plain) > 4 and plain[4] == 2 else cands[0]
+            pc.tuned[key] = cfg
         elif terms:
             cands = [c for c in _bf16_candidates(pc, Hout, Wout, B, pc.kh * pc.kw, terms) if _cfg_ok(lib, p, c)]
             if _AUTOTUNE and not capturing:
@@ -377,15 +444,19 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
 
     if len(cfg) > 4 and cfg[4] == 2:  # split-bf16 / bf16 kernel
         keep = None
+        if xs_out is not None:
+            p.xso, p.xso_c8, p.xso_hp, p.xso_wp = xs_out.buf.data_ptr(), xs_out.c8, xs_out.hp, xs_out.wp
+            p.xso_bt, p.xso_bl, p.xso_o8, p.xso_terms = xs_out.bt, xs_out.bl, xs_out_coff // 8, xs_out.terms
+            out = xs_out
         if (xs is not None and xs.terms == terms and (xs.B, xs.H, xs.W) == (B, Hin, Win) and xs_coff % 8 == 0 and
-                xs_coff + pc.cin <= xs.C):
+                xs_coff + pc.cin <= max(xs.C, 8 * xs.c8 if x is None else 0)):
             p.xs, p.xs_c8, p.xs_hp, p.xs_wp = xs.buf.data_ptr(), xs.c8, xs.hp, xs.wp
             p.xs_bt, p.xs_bl, p.xs_o8 = xs.bt, xs.bl, xs_coff // 8
             _set_cfg(p, pc, cfg)
             rc = _launch_conv(lib, p, _stream())
             if rc == 0:
                 return out
-            if rc != -1:  # -1: the shared tensor does not fit this configuration's tiles -> private re-layout below
+            if rc != -1 or x is None:  # -1: the shared tensor does not fit this configuration's tiles -> private re-layout below
                 _abi.check(rc, "codd_conv2d")
         keep = _make_split(lib, p, xsl, x2, [cfg])  # noqa: F841 (alive until the launch below is enqueued)
         _set_cfg(p, pc, cfg)
@@ -485,15 +556,17 @@ def _autotune_b(lib, p, pc, cands, xsl, x2):
     used = {pc._pack_key(c) for c in pc.tuned.values()} | {pc._pack_key(best)}
     for k in [k for k in pc._packs if k not in used]:
         del pc._packs[k]
-    # the re-layout pass of the winner (private tensor of exactly its size)
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    _make_split(lib, p, xsl, x2, [best])
-    s.record()
-    for _ in range(3):
-        keep = _make_split(lib, p, xsl, x2, [best])  # noqa: F841
-    e.record()
-    e.synchronize()
-    t_split = s.elapsed_time(e) / 3.0
+    # the re-layout pass of the winner (private tensor of exactly its size); none when the input exists in split form
+    t_split = 0.0
+    if xsl is not None:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        _make_split(lib, p, xsl, x2, [best])
+        s.record()
+        for _ in range(3):
+            keep = _make_split(lib, p, xsl, x2, [best])  # noqa: F841
+        e.record()
+        e.synchronize()
+        t_split = s.elapsed_time(e) / 3.0
     AUTOTUNE_LOG.append(("b%d %dx%d k%dx%d %d->%d out %dx%d" % (p.terms, p.sy, p.sx, pc.kh, pc.kw, pc.cin, pc.cout, p.Hout,
                                                                 p.Wout), first[0], first[1] * 1e3, best, best_t * 1e3))
     return best, best_t + t_split

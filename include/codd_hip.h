@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CODD_ABI_VERSION 4
+#define CODD_ABI_VERSION 5
 
 #define CODD_OK 0
 #define CODD_EINVAL (-1)
@@ -93,6 +93,12 @@ typedef struct {
   int xs_bt, xs_bl; /* borders the split tensor was made with (>= pad_t, pad_l: one split input can serve several
                        convolutions of the same activation, e.g. a 3x3 and a dilated 3x3) */
   int xs_o8;        /* first channel octet of this conv's input inside the split tensor (channel-slice views) */
+  /* layout 2, optional: write the result as split-bf16 records straight into the NEXT convolution's input tensor
+   * (same layout as xs, borders (xso_bt, xso_bl), first octet xso_o8, xso_terms = the consumer's terms) instead of
+   * fp32 NCHW `out` (then unused; plain convolutions only: no residual / post operand, no deconv).  The border and
+   * the octets past the output channels are NOT written: the caller keeps the tensor zero there. */
+  void* xso;
+  int xso_c8, xso_hp, xso_wp, xso_bt, xso_bl, xso_o8, xso_terms;
 } codd_conv_params;
 
 int codd_conv2d(const codd_conv_params* p, void* stream);

@@ -385,3 +385,34 @@ def test_tunable_configurations_with_views_and_two_inputs():
             assert outbuf[:, :8].abs().max().item() == 0 and outbuf[:, 56:].abs().max().item() == 0, cfg
     finally:
         ops.set_conv_precision(prev)
+
+
+@pytest.mark.parametrize("mode,tol", [("split", 2e-4), ("bf16", 4e-2)])
+def test_conv_chain_through_split_records(mode, tol):
+    """conv -> conv with the intermediate written by the first kernel's epilogue as split-bf16 records straight into
+    the second one's input tensor (ops.split_buffer / xs_out): no fp32 tensor, no re-layout pass.  Output channels that
+    are not a multiple of 8 (zero-padded octet), a 3x3 consumer (border 1), a 1x1 consumer reading a channel slice, and
+    a second frame through the same persistent buffers."""
+    from codd_amd import ops
+    B, H, W = 1, 36, 60
+    w0, b0 = rnd(44, 20, 3, 3, seed=1) / 13.0, rnd(44, seed=2) * 0.1
+    w1, b1 = rnd(32, 44, 3, 3, seed=3) / 20.0, rnd(32, seed=4) * 0.1
+    w2, b2 = rnd(24, 16, 1, 1, seed=5) / 4.0, rnd(24, seed=6) * 0.1
+    prev = ops.set_conv_precision(mode)
+    try:
+        p0, p1, p2 = (ops.PackedConv(w.to(dev()), b.to(dev())) for w, b in ((w0, b0), (w1, b1), (w2, b2)))
+        for frame in range(2):
+            x = rnd(B, 20, H, W, seed=10 + frame)
+            r0 = F.relu(F.conv2d(x, w0, b0, padding=1))
+            r1 = F.relu(F.conv2d(r0, w1, b1, padding=1))
+            r2 = F.conv2d(r1[:, 8:24], w2, b2)
+            s0 = ops.split_buffer("t0", B, 44, H, W, 1, dev())
+            s1 = ops.split_buffer("t1", B, 32, H, W, 0, dev())
+            assert ops.conv2d(x.to(dev()), p0, pad=1, act="relu", xs_out=s0) is s0
+            ops.conv2d(None, p1, pad=1, act="relu", xs=s0, xs_out=s1)
+            y1 = ops.conv2d(None, p1, pad=1, act="relu", xs=s0)          # the same layer with an fp32 result
+            y2 = ops.conv2d(None, p2, xs=s1, xs_coff=8)
+            assert (y1.cpu() - r1).abs().max().item() < tol * r1.abs().max().item(), frame
+            assert (y2.cpu() - r2).abs().max().item() < tol * max(1.0, r2.abs().max().item()), frame
+    finally:
+        ops.set_conv_precision(prev)

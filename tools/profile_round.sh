@@ -1,16 +1,17 @@
 #!/bin/bash
 # Run on the GPU box: rocprofv3 kernel statistics of bench.py (serial streams and default schedule) and the
-# PMC passes (HBM traffic, MFMA busy) -> gpurun_out/prof_final/.  tools/make_profile_md.py turns them into
+# PMC passes (HBM traffic, MFMA busy) -> gpurun_out/prof_r02/.  tools/make_profile_md.py turns them into
 # the committed summaries under profiles/.
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_final; mkdir -p $OUT
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_r02; mkdir -p $OUT
 cp $R/codd_amd/tuned/mi355x.json $OUT/tune_db.json   # the shipped launch configurations (what bench.py runs by default)
 python $R/bench.py --no-cpu-baseline --tune-db $OUT/tune_db.json > $OUT/bench_plain.log 2>&1   # un-profiled reference run
 for mode in serial default; do
   flag=""; [ $mode = serial ] && flag="--serial-streams"
   rm -rf /tmp/st_$mode
-  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$mode -o s -- python $R/bench.py --no-cpu-baseline --tune-db $OUT/tune_db.json $flag > $OUT/bench_$mode.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$mode -o s -- python $R/bench.py --steps 60 --no-cpu-baseline --tune-db $OUT/tune_db.json $flag > $OUT/bench_$mode.log 2>&1
   cp /tmp/st_$mode/s_kernel_stats.csv $OUT/${mode}_kernel_stats.csv
+  [ $mode = default ] && python3 $R/tools/timeline_gaps.py /tmp/st_$mode/s_kernel_trace.csv > $OUT/timeline_default.txt 2>&1
 done
 CMD="python $R/bench.py --no-cpu-baseline --tune-db $OUT/tune_db.json --serial-streams --steps 4 --prewarm 2 --warmup 1 --no-graph"
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do

@@ -6,7 +6,7 @@
 #include <vector>
 
 #ifndef CFG
-#define CFG 2, 2, 5, 2, 3
+#define CFG 2, 2, 5, 2, 3, 0
 #endif
 template __global__ void conv_bf16_kernel<CFG>(const ConvB);
 
