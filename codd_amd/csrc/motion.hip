@@ -284,26 +284,30 @@ extern "C" int codd_raft_geometry(const float* T, const float* depth1, const flo
 }
 
 // ------------------------------------------------------------------------------------------------
-// Dense SE3 Gauss-Newton step (reference se3_field.py:150-170).
-// Workgroup = 8 waves = one 8x8 tile of pixels i (lane = pixel).  The (8+2r)^2 neighbourhood of the
-// tile is streamed row by row through LDS: wave w stages rows w, w+8, ... (coalesced global reads,
-// 44 floats per neighbour j: ae/8 (32), X_j (3), target_j (3), weight_j (3), |ae_j|^2) and every
-// lane then walks the row with BROADCAST LDS reads, accumulating its 21 + 6 normal-equation sums in
-// registers.  The 8 partial sums per pixel are combined through LDS and 64 lanes damp, solve
-// (Cholesky, fp64) and retract their pixels in parallel.
-//   a_ij = sigmoid(-|ae_i - ae_j|^2), |.|^2 expanded as |a_i|^2 + |a_j|^2 - 2 <a_i, a_j>.
+// Dense SE3 Gauss-Newton step (reference se3_field.py:150-170):
+//   a_ij = sigmoid(-|ae_i - ae_j|^2), |.|^2 expanded as |a_i|^2 + |a_j|^2 - 2 <a_i, a_j>,
+//   H_i = sum_j a_ij J_ij^T W_j J_ij,  b_i = sum_j a_ij J_ij^T W_j r_ij  over the (2r+1)^2 window.
+// Three launches:
+//   prep   packs everything a neighbour j contributes -- ae_j/8 (32), X_j (3), target_j (3), weight_j (3),
+//          |ae_j/8|^2 -- into one 176-byte record.
+//   build  lane = pixel i of an 8x8 tile; all 64 lanes of a wave visit the same j, so the record is read with
+//          SCALAR loads (wave-uniform address -> s_load_dwordx16, SGPR pairs feed v_pk_fma_f32 directly): no LDS,
+//          no broadcast traffic.  The kernel is VALU-issue bound; its loop is written on float2 values so that the
+//          32-term dot product is 16 packed FMAs and the 49 + 13 normal-equation updates are 23 + 8 (measured on
+//          gfx950 at 4 waves/SIMD: v_fma_f32 4.2 cycles per wave instruction, v_pk_fma_f32 5.2 -- tools/ubench/
+//          valu_rate.hip; 111 VALU instructions per neighbour against 197 for the scalar form).
+//          Work decomposition: a tile's clipped neighbourhood (1600 ... 5184 neighbours at 72x120, r = 32) is a
+//          row-major list cut into G = nj / q4 equal pieces, one per workgroup, and each piece into 4, one per
+//          wave: every wave of the launch carries the same number of pairs, and the ~8000 waves are dispatched
+//          dynamically over the 4096 wave slots.  The 4 waves of a workgroup add their sums through LDS (fixed
+//          order) and write ONE [27][64] partial.
+//   solve  one workgroup per tile: 14 waves add the tile's G partials in index order (deterministic), wave 0
+//          damps, solves (Cholesky, fp64) and retracts its 64 pixels.
 // ------------------------------------------------------------------------------------------------
 #define GN_AE 32
-#define GN_JS 44  // floats per staged neighbour record (16-byte aligned)
+#define GN_JS 44  // floats per neighbour record (16-byte aligned)
 #define GN_WAVES 4
-// Work decomposition: (tile, row-group) tasks, one per WAVE (lane = pixel i of an 8x8 tile); R
-// row-groups per tile are chosen so that tiles*R fills the chip.  A pre-pass packs everything a
-// neighbour j contributes -- ae_j/8 (32), X_j (3), target_j (3), weight_j (3), |ae_j/8|^2 -- into one
-// 176-byte record; because all 64 lanes of a wave visit the same j, the main loop reads the record
-// with SCALAR loads (wave-uniform address -> s_load_dwordx*, SGPR operands feed the VALU directly):
-// no LDS, no broadcast traffic, and the loop body is branch-free so the loads pipeline.
-// Partial sums go to scratch [task][27][64]; se3_gn_solve_kernel adds the R partials of each pixel
-// in a fixed order (deterministic), damps, solves and retracts.
+#define GN_SOLVE_WAVES 14  // 27 sums over 14 waves: <= 2 each
 __global__ void se3_gn_prep_kernel(const float* __restrict__ ae, int ae_c, const float* __restrict__ xyz,
                                    const float* __restrict__ delta, const float* __restrict__ wgt,
                                    const float* __restrict__ d1, int h, int w, float fx, float fy, float cx, float cy,
@@ -334,125 +338,166 @@ __global__ void se3_gn_prep_kernel(const float* __restrict__ ae, int ae_c, const
   rp[41] = a2; rp[42] = 0.f; rp[43] = 0.f;
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ v2f GN_PK(v2f a, v2f b, v2f c) {  // -> v_pk_fma_f32: 2 fp32 FMAs per lane and issue slot
+  return __builtin_elementwise_fma(a, b, c);
+}
+
+// Workgroups a tile's nj neighbours are split into: ~q4 neighbours per workgroup (4 waves), so that every wave of
+// the launch carries the same number of (i, j) pairs whatever the clipping of its tile's neighbourhood.
+static __host__ __device__ __forceinline__ int gn_groups(int nj, int q4, int gmax) {
+  const int g = (nj + q4 / 2) / q4;
+  return g < 1 ? 1 : (g > gmax ? gmax : g);
+}
+
 __global__ __launch_bounds__(64 * GN_WAVES) void se3_gn_build_kernel(
     const float* __restrict__ T, const float* __restrict__ jd, int h, int w, float fx, float fy, float cx, float cy,
-    int radius, int tiles_x, int ntiles, int R, float* __restrict__ part) {
+    int radius, int tiles_x, int ntiles, int q4, int gmax, float* __restrict__ part) {
+  __shared__ float red[GN_WAVES][27][64];
   const int N = h * w;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = blockIdx.y;
-  const int task = blockIdx.x * GN_WAVES + wave;
-  if (task >= ntiles * R) return;
-  const int tile = task / R, rg = task - tile * R;
+  const int tile = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
   const int tx0 = (tile % tiles_x) * 8, ty0 = (tile / tiles_x) * 8;
-  const int xi = tx0 + (lane & 7), yi = ty0 + (lane >> 3);
-  const bool vi = xi < w && yi < h;
-  const int i = vi ? yi * w + xi : 0;
   // rows / columns of the tile's neighbourhood, clipped to the image (all wave-uniform)
   const int ylo = max(ty0 - radius, 0), yhi = min(ty0 + 7 + radius, h - 1);
   const int xlo = max(tx0 - radius, 0), xhi = min(tx0 + 7 + radius, w - 1);
-  const int nrows = yhi - ylo + 1;
-  const int r0 = ylo + (int)((long long)nrows * rg / R), r1 = ylo + (int)((long long)nrows * (rg + 1) / R);
+  const int ncols = xhi - xlo + 1, nj = (yhi - ylo + 1) * ncols;
+  const int G = gn_groups(nj, q4, gmax);
+  if (g >= G) return;  // (workgroup-uniform) this tile needs fewer groups than the grid provides
+  // this wave's share of the row-major neighbour list: [s0, s1)
+  const int slot = g * GN_WAVES + wave, nslots = G * GN_WAVES;
+  const int s0 = (int)((long long)nj * slot / nslots), s1 = (int)((long long)nj * (slot + 1) / nslots);
+  const int ys = ylo + s0 / ncols, xs = xlo + s0 % ncols;
+  const int ye = ylo + (s1 - 1) / ncols, xe = xlo + (s1 - 1) % ncols;
 
+  const int xi = tx0 + (lane & 7), yi = ty0 + (lane >> 3);
+  const bool vi = xi < w && yi < h;
+  const int i = vi ? yi * w + xi : 0;
+  const int xim = xi - radius, yim = yi - radius;
+  const unsigned twor = 2u * (unsigned)radius;
   const float* rec = jd + (size_t)b * N * GN_JS;
   const float* aip = rec + (size_t)i * GN_JS;
   const SE3T Ti = se3_load(T + ((size_t)b * N + i) * 7);
   // rotation matrix of T_i: Y = [c0 c1 c2] X + t
   const V3 c0 = qrot(Ti.q, V3{1.f, 0.f, 0.f}), c1 = qrot(Ti.q, V3{0.f, 1.f, 0.f}), c2 = qrot(Ti.q, V3{0.f, 0.f, 1.f});
-  float ai[GN_AE];
+  v2f ai[GN_AE / 2];
 #pragma unroll
-  for (int c = 0; c < GN_AE; ++c) ai[c] = aip[c];
+  for (int c = 0; c < GN_AE / 2; ++c) ai[c] = *(const v2f*)(aip + 2 * c);
   const float ai2 = aip[41];
-  float Hs[21], bs[6];
-#pragma unroll
-  for (int k = 0; k < 21; ++k) Hs[k] = 0.f;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) bs[k] = 0.f;
+  // normal-equation sums: the upper triangle of H as row pairs (H_p,q  H_p,q+1), q even -- rows 1, 3, 5 carry one
+  // redundant lower-triangle entry so that every update is one packed FMA; H01 is structurally 0
+  float H00 = 0.f, H11 = 0.f, b0 = 0.f, b1 = 0.f, b4z = 0.f;
+  v2f h02 = {0.f, 0.f}, h04 = h02, h12 = h02, h14 = h02, h22 = h02, h24 = h02, h32 = h02, h34 = h02, h44 = h02, h54 = h02;
+  v2f b23 = h02, b45 = h02;
+  const float nfy = -fy;
 
-  for (int yj = r0; yj < r1; ++yj) {
-    const bool rowin = vi && abs(yj - yi) <= radius;
+  if (s1 > s0)
+  for (int yj = ys; yj <= ye; ++yj) {
+    const bool rowin = vi && (unsigned)(yj - yim) <= twor;
     const float* rrow = rec + (size_t)yj * w * GN_JS;
-    for (int xj = xlo; xj <= xhi; ++xj) {
-      // wave-uniform address -> scalar loads; the whole 176-byte record is fetched up front (one
-      // batch of s_load_dwordx4/x8, one wait) instead of three dependent round trips
+    const int xa = yj == ys ? xs : xlo, xb = yj == ye ? xe : xhi;
+    for (int xj = xa; xj <= xb; ++xj) {
+      // wave-uniform address -> scalar loads; the whole 176-byte record is fetched up front (one batch of
+      // s_load_dwordx4/x8/x16, one wait); SGPR pairs feed the packed FMAs directly
       const float4* rp4 = (const float4*)(rrow + (size_t)xj * GN_JS);
-      float4 rec4[11];
+      float4 r[11];
 #pragma unroll
-      for (int q = 0; q < 11; ++q) rec4[q] = rp4[q];
-      const float Xx = rec4[8].x, Xy = rec4[8].y, Xz = rec4[8].z;
-      const float Yx = c0.x * Xx + c1.x * Xy + c2.x * Xz + Ti.t.x;
-      const float Yy = c0.y * Xx + c1.y * Xy + c2.y * Xz + Ti.t.y;
-      const float Yz = c0.z * Xx + c1.z * Xy + c2.z * Xz + Ti.t.z;
-      const bool in = rowin && abs(xj - xi) <= radius && Xz >= MIN_DEPTH && Yz >= MIN_DEPTH;
-      float dot = 0.f;
+      for (int q = 0; q < 11; ++q) r[q] = rp4[q];
+      const float Xx = r[8].x, Xy = r[8].y, Xz = r[8].z;
+      const float Yz = fmaf(c0.z, Xx, fmaf(c1.z, Xy, fmaf(c2.z, Xz, Ti.t.z)));
+      const bool in = rowin && (unsigned)(xj - xim) <= twor && Xz >= MIN_DEPTH && Yz >= MIN_DEPTH;
+      v2f acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
-        dot += ai[4 * q] * rec4[q].x + ai[4 * q + 1] * rec4[q].y + ai[4 * q + 2] * rec4[q].z + ai[4 * q + 3] * rec4[q].w;
-      const float d2 = fmaxf(ai2 + rec4[10].y - 2.f * dot, 0.f);
-      const float a = (in ? 1.f : 0.f) * __builtin_amdgcn_rcpf(1.f + __expf(d2));  // sigmoid(-d2), masked (branch-free)
-      // the affinity of most neighbours underflows against the accumulated sums: skip their geometry
-      // when every lane's weight is below 1e-9 (relative effect on H, b < 1e-9; wave-uniform branch)
+      for (int q = 0; q < 8; ++q) {
+        acc0 = GN_PK(ai[2 * q], (v2f){r[q].x, r[q].y}, acc0);
+        acc1 = GN_PK(ai[2 * q + 1], (v2f){r[q].z, r[q].w}, acc1);
+      }
+      acc0 += acc1;
+      const float dot = acc0.x + acc0.y;
+      const float d2 = fmaxf(fmaf(-2.f, dot, ai2 + r[10].y), 0.f);
+      const float a = in ? __builtin_amdgcn_rcpf(1.f + __expf(d2)) : 0.f;  // sigmoid(-d2), masked
+      // the affinity of far neighbours underflows against the accumulated sums: skip their geometry when every
+      // lane's weight is below 1e-9 (relative effect on H, b < 1e-9; wave-uniform branch)
       if (__ballot(a > 1e-9f) == 0ull) continue;
+      const float Yx = fmaf(c0.x, Xx, fmaf(c1.x, Xy, fmaf(c2.x, Xz, Ti.t.x)));
+      const float Yy = fmaf(c0.y, Xx, fmaf(c1.y, Xy, fmaf(c2.y, Xz, Ti.t.y)));
       const float d = __builtin_amdgcn_rcpf(fmaxf(Yz, MIN_DEPTH));
       const float xn = Yx * d, yn = Yy * d;
-      const float Jx[6] = {fx * d, 0.f, -fx * xn * d, -fx * xn * yn, fx * (1.f + xn * xn), -fx * yn};
-      const float Jy[6] = {0.f, fy * d, -fy * yn * d, -fy * (1.f + yn * yn), fy * xn * yn, fy * xn};
-      const float Jz[6] = {0.f, 0.f, -d * d, -yn * d, xn * d, 0.f};
-      const float rx = rec4[8].w - (fx * xn + cx);
-      const float ry_ = rec4[9].x - (fy * yn + cy);
-      const float rz = rec4[9].y - d;
-      const float wx = a * rec4[9].z, wy = a * rec4[9].w, wz = a * rec4[10].x;
-      float wJx[6], wJy[6], wJz[6];
-#pragma unroll
-      for (int p = 0; p < 6; ++p) { wJx[p] = wx * Jx[p]; wJy[p] = wy * Jy[p]; wJz[p] = wz * Jz[p]; }
-      // one fma chain per residual row straight into the accumulators: the structural zeros of J
-      // (Jx[1], Jy[0], Jz[0], Jz[1], Jz[5]) fold away -> 36 + 13 fma instead of 63 + 18 mul/add
-      int k = 0;
-#pragma unroll
-      for (int p = 0; p < 6; ++p) {
-#pragma unroll
-        for (int qq = p; qq < 6; ++qq) {
-          Hs[k] = fmaf(wJx[p], Jx[qq], Hs[k]);
-          Hs[k] = fmaf(wJy[p], Jy[qq], Hs[k]);
-          Hs[k] = fmaf(wJz[p], Jz[qq], Hs[k]);
-          ++k;
-        }
-        bs[p] = fmaf(wJx[p], rx, bs[p]);
-        bs[p] = fmaf(wJy[p], ry_, bs[p]);
-        bs[p] = fmaf(wJz[p], rz, bs[p]);
-      }
+      const float fxd = fx * d, fyd = fy * d, xy = xn * yn, fxx = fx * xn, fyy = fy * yn;
+      // J rows (d(u, v, 1/z) / d(tau, phi)); structural zeros: Jx1, Jy0, Jz0, Jz1, Jz5
+      const v2f Jx23 = {-fxd * xn, -fx * xy}, Jx45 = {fmaf(fxx, xn, fx), -fx * yn};
+      const v2f Jy23 = {-fyd * yn, fmaf(-fyy, yn, nfy)}, Jy45 = {fy * xy, fy * xn};
+      const v2f Jz23 = {-d * d, -yn * d}, Jz45 = {xn * d, 0.f};
+      const float rx = r[8].w - (fxx + cx), ry = r[9].x - (fyy + cy), rz = r[9].y - d;
+      const float wx = a * r[9].z, wy = a * r[9].w, wz = a * r[10].x;
+      const float wJx0 = wx * fxd, wJy1 = wy * fyd, wJz4 = wz * Jz45.x;
+      const v2f wJx23 = wx * Jx23, wJx45 = wx * Jx45, wJy23 = wy * Jy23, wJy45 = wy * Jy45, wJz23 = wz * Jz23;
+      H00 = fmaf(wJx0, fxd, H00);
+      h02 = GN_PK((v2f)(wJx0), Jx23, h02);
+      h04 = GN_PK((v2f)(wJx0), Jx45, h04);
+      H11 = fmaf(wJy1, fyd, H11);
+      h12 = GN_PK((v2f)(wJy1), Jy23, h12);
+      h14 = GN_PK((v2f)(wJy1), Jy45, h14);
+      h22 = GN_PK((v2f)(wJx23.x), Jx23, h22); h22 = GN_PK((v2f)(wJy23.x), Jy23, h22); h22 = GN_PK((v2f)(wJz23.x), Jz23, h22);
+      h24 = GN_PK((v2f)(wJx23.x), Jx45, h24); h24 = GN_PK((v2f)(wJy23.x), Jy45, h24); h24 = GN_PK((v2f)(wJz23.x), Jz45, h24);
+      h32 = GN_PK((v2f)(wJx23.y), Jx23, h32); h32 = GN_PK((v2f)(wJy23.y), Jy23, h32); h32 = GN_PK((v2f)(wJz23.y), Jz23, h32);
+      h34 = GN_PK((v2f)(wJx23.y), Jx45, h34); h34 = GN_PK((v2f)(wJy23.y), Jy45, h34); h34 = GN_PK((v2f)(wJz23.y), Jz45, h34);
+      h44 = GN_PK((v2f)(wJx45.x), Jx45, h44); h44 = GN_PK((v2f)(wJy45.x), Jy45, h44); h44 = GN_PK((v2f)(wJz4), Jz45, h44);
+      h54 = GN_PK((v2f)(wJx45.y), Jx45, h54); h54 = GN_PK((v2f)(wJy45.y), Jy45, h54);
+      b0 = fmaf(wJx0, rx, b0);
+      b1 = fmaf(wJy1, ry, b1);
+      b23 = GN_PK(wJx23, (v2f)(rx), b23); b23 = GN_PK(wJy23, (v2f)(ry), b23); b23 = GN_PK(wJz23, (v2f)(rz), b23);
+      b45 = GN_PK(wJx45, (v2f)(rx), b45); b45 = GN_PK(wJy45, (v2f)(ry), b45);
+      b4z = fmaf(wJz4, rz, b4z);
     }
   }
-  float* pp = part + ((size_t)b * ntiles * R + task) * 27 * 64 + lane;
+  // combine the workgroup's 4 partial sums in a fixed order, one [27][64] partial per workgroup
+  const float Hs[27] = {H00, 0.f, h02.x, h02.y, h04.x, h04.y, H11, h12.x, h12.y, h14.x, h14.y, h22.x, h22.y, h24.x,
+                        h24.y, h32.y, h34.x, h34.y, h44.x, h44.y, h54.y, b0, b1, b23.x, b23.y, b45.x + b4z, b45.y};
 #pragma unroll
-  for (int k = 0; k < 21; ++k) pp[k * 64] = Hs[k];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) pp[(21 + k) * 64] = bs[k];
+  for (int k = 0; k < 27; ++k) red[wave][k][lane] = Hs[k];
+  __syncthreads();
+  float* pp = part + (((size_t)b * ntiles + tile) * gmax + g) * 27 * 64 + lane;
+  for (int k = wave; k < 27; k += GN_WAVES)
+    pp[k * 64] = ((red[0][k][lane] + red[1][k][lane]) + red[2][k][lane]) + red[3][k][lane];
 }
 
-// Combine the R partials of a tile: one wave per (tile, k); consecutive lanes = pixels (coalesced),
-// 27*ntiles waves in flight hide the R dependent adds.  sums: [tile][27][64].
-__global__ __launch_bounds__(64) void se3_gn_reduce_kernel(const float* __restrict__ part, int ntiles, int R,
-                                                           float* __restrict__ sums) {
-  const int lane = threadIdx.x, k = blockIdx.x % 27, tile = blockIdx.x / 27, b = blockIdx.y;
-  const float* p = part + (((size_t)b * ntiles + tile) * R) * 27 * 64 + k * 64 + lane;
-  float s = 0.f;
-  for (int r = 0; r < R; ++r) s += p[(size_t)r * 27 * 64];
-  sums[(((size_t)b * ntiles + tile) * 27 + k) * 64 + lane] = s;
-}
-
-__global__ __launch_bounds__(64) void se3_gn_solve_kernel(float* __restrict__ T, const float* __restrict__ sums, int h,
-                                                          int w, int tiles_x, int ntiles, float lm, float ep) {
-  const int lane = threadIdx.x;
+// One workgroup per tile: 14 waves add the tile's G partials (fixed order -> deterministic), wave 0 damps, solves
+// (Cholesky, fp64) and retracts its 64 pixels.
+__global__ __launch_bounds__(64 * GN_SOLVE_WAVES) void se3_gn_solve_kernel(
+    float* __restrict__ T, const float* __restrict__ part, int h, int w, int radius, int tiles_x, int ntiles, int q4,
+    int gmax, float lm, float ep) {
+  __shared__ float sums[27][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = blockIdx.x, b = blockIdx.y;
-  const int xi = (tile % tiles_x) * 8 + (lane & 7), yi = (tile / tiles_x) * 8 + (lane >> 3);
+  const int tx0 = (tile % tiles_x) * 8, ty0 = (tile / tiles_x) * 8;
+  {
+    const int ylo = max(ty0 - radius, 0), yhi = min(ty0 + 7 + radius, h - 1);
+    const int xlo = max(tx0 - radius, 0), xhi = min(tx0 + 7 + radius, w - 1);
+    const int G = gn_groups((yhi - ylo + 1) * (xhi - xlo + 1), q4, gmax);
+    const float* p = part + (((size_t)b * ntiles + tile) * gmax) * 27 * 64 + lane;
+    for (int k = wave; k < 27; k += GN_SOLVE_WAVES) {
+      float s = 0.f;
+      int g = 0;
+      for (; g + 4 <= G; g += 4) {  // four loads in flight, added in index order
+        const float v0 = p[((size_t)g * 27 + k) * 64], v1 = p[((size_t)(g + 1) * 27 + k) * 64];
+        const float v2 = p[((size_t)(g + 2) * 27 + k) * 64], v3 = p[((size_t)(g + 3) * 27 + k) * 64];
+        s = (((s + v0) + v1) + v2) + v3;
+      }
+      for (; g < G; ++g) s += p[((size_t)g * 27 + k) * 64];
+      sums[k][lane] = s;
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  const int xi = tx0 + (lane & 7), yi = ty0 + (lane >> 3);
   if (xi >= w || yi >= h) return;
   const int N = h * w, i = yi * w + xi;
   float Hf[21], bf[6];
-  const float* sp = sums + (((size_t)b * ntiles + tile) * 27) * 64 + lane;
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
-    const float s = sp[k * 64];
+    const float s = sums[k][lane];
     if (k < 21) Hf[k] = s; else bf[k - 21] = s;
   }
   // damping H_pp += lm*H_pp + ep (fp32, as the reference), then Cholesky solve in fp64
@@ -503,17 +548,21 @@ __global__ __launch_bounds__(64) void se3_gn_solve_kernel(float* __restrict__ T,
   }
 }
 
-static inline int gn_rowgroups(int ntiles, int NC) {
-  static const int tasks = getenv("CODD_GN_TASKS") ? atoi(getenv("CODD_GN_TASKS")) : 4096;  // dev override; 4096: 190 us, 3072: 216 us, 2048: 243 us
-  int R = tasks / (ntiles > 0 ? ntiles : 1);  // ~4 waves per SIMD on 256 CUs
-  if (R < 1) R = 1;
-  if (R > NC) R = NC;
-  return R;
+// Neighbours per workgroup (4 waves): small enough that the launch is several dispatch rounds of equal-sized
+// waves (dynamic balance over the 256 CUs), large enough that a wave's set-up (its 32 + 12 per-pixel registers) and
+// the per-workgroup partial (6.9 KB) stay in the noise.
+static inline int gn_q4() {
+  static const int q = getenv("CODD_GN_Q4") ? atoi(getenv("CODD_GN_Q4")) : 128;  // dev override
+  return q < 16 ? 16 : q;
+}
+static inline int gn_gmax(int radius) {
+  const int NC = 8 + 2 * radius;
+  return gn_groups(NC * NC, gn_q4(), 1 << 20);
 }
 
 extern "C" long long codd_se3_gn_scratch(int B, int h, int w, int radius) {
   const int ntiles = cdiv(w, 8) * cdiv(h, 8);
-  return (long long)B * ntiles * (gn_rowgroups(ntiles, 8 + 2 * radius) + 1) * 27 * 64 + (long long)B * h * w * GN_JS;
+  return (long long)B * ntiles * gn_gmax(radius) * 27 * 64 + (long long)B * h * w * GN_JS;
 }
 
 extern "C" int codd_se3_gn_step(float* T, const float* ae, int ae_c, const float* xyz, const float* delta,
@@ -521,22 +570,18 @@ extern "C" int codd_se3_gn_step(float* T, const float* ae, int ae_c, const float
                                 float cx, float cy, int radius, float lm, float ep, float* Hb, void* stream) {
   if (!T || !ae || !xyz || !delta || !weight || !depth1 || !Hb || ae_c < 1 || ae_c > GN_AE || radius < 0)
     return CODD_EINVAL;
-  const int NC = 8 + 2 * radius;
   const int tiles_x = cdiv(w, 8), ntiles = tiles_x * cdiv(h, 8);
-  const int R = gn_rowgroups(ntiles, NC);
+  const int q4 = gn_q4(), gmax = gn_gmax(radius);
   float* part = Hb;
-  float* sums = Hb + (size_t)B * ntiles * R * 27 * 64;
-  float* jd = sums + (size_t)B * ntiles * 27 * 64;
+  float* jd = Hb + (size_t)B * ntiles * gmax * 27 * 64;
   hipStream_t s = (hipStream_t)stream;
   se3_gn_prep_kernel<<<dim3(cdiv(h * w, 128), B), 128, 0, s>>>(ae, ae_c, xyz, delta, weight, depth1, h, w, fx, fy, cx,
                                                              cy, jd);
   CODD_LAUNCH_CHECK();
-  dim3 grid(cdiv(ntiles * R, GN_WAVES), B);
-  se3_gn_build_kernel<<<grid, 64 * GN_WAVES, 0, s>>>(T, jd, h, w, fx, fy, cx, cy, radius, tiles_x, ntiles, R, part);
+  se3_gn_build_kernel<<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, s>>>(T, jd, h, w, fx, fy, cx, cy, radius, tiles_x,
+                                                                      ntiles, q4, gmax, part);
   CODD_LAUNCH_CHECK();
-  se3_gn_reduce_kernel<<<dim3(ntiles * 27, B), 64, 0, s>>>(part, ntiles, R, sums);
-  CODD_LAUNCH_CHECK();
-  se3_gn_solve_kernel<<<dim3(ntiles, B), 64, 0, s>>>(T, sums, h, w, tiles_x, ntiles, lm, ep);
+  se3_gn_solve_kernel<<<dim3(ntiles, B), 64 * GN_SOLVE_WAVES, 0, s>>>(T, part, h, w, radius, tiles_x, ntiles, q4, gmax, lm, ep);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }
@@ -707,25 +752,44 @@ __global__ void splat_count_kernel(const SplatP p) {
   splat_cover(p, b, u, v, [&](size_t pix) { atomicAdd(&p.cnt[pix], 1); });
 }
 
-__global__ void splat_reserve_kernel(const SplatP p, long long npix) {
-  // one atomic per WAVE (a per-thread atomicAdd on the single cursor serialised 552 960 requests: 56 us):
-  // wave-inclusive scan of the counts by shuffles, the last lane claims the wave's total, base broadcast back
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  const int c = e < npix ? p.cnt[e] : 0;
-  int incl = c;
+__global__ __launch_bounds__(1024) void splat_reserve_kernel(const SplatP p, long long npix) {
+  // one atomic per 4096 pixels: requests to the single cursor serialise in L2 at ~6 ns each (one per thread: 56 us
+  // at 960x576, one per wave: 55 us) -- so a workgroup scans 4 counts per thread (shuffles inside a wave, LDS across
+  // its 16 waves) and thread 0 claims the workgroup's total
+  __shared__ int wsum[16];
+  __shared__ int sbase;
+  const long long e0 = ((long long)blockIdx.x * 1024 + threadIdx.x) * 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int c[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) c[k] = e0 + k < npix ? p.cnt[e0 + k] : 0;
+  const int t = (c[0] + c[1]) + (c[2] + c[3]);
+  int incl = t;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += t;
+    const int u = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += u;
   }
-  int base = 0;
-  if (lane == 63 && incl > 0) base = atomicAdd(p.cursor, incl);
-  base = __shfl(base, 63, 64);
-  if (e < npix) {
-    p.off[e] = base + incl - c;
-    p.cur[e] = 0;
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int q = 0; q < 16; ++q) {
+      const int v = wsum[q];
+      wsum[q] = tot;
+      tot += v;
+    }
+    sbase = tot > 0 ? atomicAdd(p.cursor, tot) : 0;
   }
+  __syncthreads();
+  int o = sbase + wsum[wave] + incl - t;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (e0 + k < npix) {
+      p.off[e0 + k] = o;
+      p.cur[e0 + k] = 0;
+      o += c[k];
+    }
 }
 
 __global__ void splat_fill_kernel(const SplatP p) {
@@ -863,7 +927,7 @@ extern "C" int codd_splat(const float* T, const float* depth, int HT, int WT, in
   dim3 grid(cdiv(H * W, 256), B);
   splat_count_kernel<<<grid, 256, 0, s>>>(p);
   CODD_LAUNCH_CHECK();
-  splat_reserve_kernel<<<cdiv(n, 256), 256, 0, s>>>(p, n);
+  splat_reserve_kernel<<<cdiv(n, 4096), 1024, 0, s>>>(p, n);
   CODD_LAUNCH_CHECK();
   splat_fill_kernel<<<grid, 256, 0, s>>>(p);
   CODD_LAUNCH_CHECK();

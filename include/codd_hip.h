@@ -207,8 +207,8 @@ int codd_raft_geometry(const float* T, const float* depth1, const float* depth2,
 /* Dense SE3 Gauss-Newton step (se3_field.step_inplace, se3_field.py:150-170 =
  * lietorch_extras.se3_build_inplace + damping + cholesky6x6_forward + SE3.exp(dx) * Ts).
  * ae [B,32,h,w] (raw head output; /8 applied inside), delta/weight [B,3,h,w]; target = xyz + delta.
- * T is updated in place.  Hb: scratch of codd_se3_gn_scratch(B,h,w,radius) floats (per-task partial
- * normal equations; combined in a fixed order -> deterministic). */
+ * T is updated in place.  Hb: scratch of codd_se3_gn_scratch(B,h,w,radius) floats (per-workgroup partial
+ * normal equations, combined in a fixed order -> deterministic, + the packed neighbour records). */
 long long codd_se3_gn_scratch(int B, int h, int w, int radius);
 int codd_se3_gn_step(float* T, const float* ae, int ae_c, const float* xyz, const float* delta,
                      const float* weight, const float* depth1, int B, int h, int w,

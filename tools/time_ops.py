@@ -15,7 +15,7 @@ def timeit(fn, n=10):
 
 which = sys.argv[1:] or ["gn", "conv"]
 h, w = 72, 120
-if "gn" in which:
+if any(a.startswith("gn") for a in which):
     T = ops.se3_identity(1, h, w, dev)
     ae = torch.randn(1, 32, h, w, device=dev)
     xyz = torch.rand(1, h, w, 3, device=dev) * 50
@@ -23,7 +23,7 @@ if "gn" in which:
     wgt = torch.rand(1, 3, h, w, device=dev)
     d1 = torch.rand(1, h, w, device=dev) * 50 + 1
     K8 = [131.0, 131.0, 60.0, 36.0]
-    for r in (32, 8):
+    for r in ([int(a[2:]) for a in which if a.startswith('gn') and a[2:]] or (32, 8)):
         print(f"gn radius {r}: {timeit(lambda: ops.se3_gn_step(T, ae, xyz, delta, wgt, d1, K8, radius=r)):.1f} us")
 if "conv" in which:
     def conv_case(cin, cout, k, H, W, dil=1, stride=1, n=10):
