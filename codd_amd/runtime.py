@@ -8,6 +8,8 @@ dominate at 30 fps, so the whole frame is recorded with HIP stream capture
 pool).  Recurrent state (reference model/codd.py:322-366: memory, raft_feat, raft_netinp) lives
 in static buffers that the graph reads at its head and overwrites at its tail.
 """
+import os
+
 import torch
 
 from . import ops
@@ -16,10 +18,13 @@ from . import ops
 class FrameRunner:
     """Runs ConsistentOnlineDynamicDepth frame by frame on one GPU, eagerly or by graph replay."""
 
-    def __init__(self, estimator, img_metas, use_graph=True):
+    def __init__(self, estimator, img_metas, use_graph=True, split=None):
         self.est = estimator
         self.metas = img_metas
         self.use_graph = use_graph
+        # split = True: the frame is FOUR graphs on three HIP streams (see _capture_split) instead of one graph with
+        # parallel branches; default on (CODD_SPLIT_GRAPHS=0 selects the single graph)
+        self.split = (os.environ.get("CODD_SPLIT_GRAPHS", "0") == "1") if split is None else split
         self.state = {}
         self.graph = None
         self._static = None
@@ -80,6 +85,92 @@ class FrameRunner:
             dst.copy_(src)
         self.graph, self._static = g, st
 
+    # ---- split graphs -----------------------------------------------------------------------
+    # One captured graph with parallel branches is replayed by the HIP runtime almost in capture order: the image-only
+    # branches (RAFT3D feature encoder ~100 launches, context network ~200) and the stereo network share the device
+    # only at their seams (rocprofv3: 11.2 of 14.3 busy ms with exactly one kernel resident, the stereo network's first
+    # launch 1.0 ms after the frame starts).  Separate graphs launched on separate streams land on separate hardware
+    # queues and run side by side:
+    #     s1: [fnet]            -> fmap
+    #     s2: [cnet]            -> netinp (only the NEXT frame reads it: reference raft3d.py:278)
+    #     s0: [stereo] , wait s1, [motion + fusion + state write-back] , wait s2, netinp -> state
+    # Same kernels, same arguments, same per-chain order as the single graph: results are identical.
+    def _capture_split(self, left, right):
+        dev = left.device
+        raft = self.est.motion.raft3d
+        st = dict(l=torch.empty_like(left), r=torch.empty_like(right), primed=True, split=True)
+        st["state"] = [torch.empty_like(t).contiguous() for t in self._state_tensors(self.state)]
+        for dst, src in zip(st["state"], self._state_tensors(self.state)):
+            dst.copy_(src)
+        st["l"].copy_(left)
+        st["r"].copy_(right)
+        saved = [t.clone() for t in st["state"]]
+        s0, s1, s2 = (torch.cuda.Stream(device=dev) for _ in range(3))
+        st["streams"] = (s0, s1, s2)
+        cur = torch.cuda.current_stream(dev)
+        for s in (s0, s1, s2):
+            s.wait_stream(cur)
+
+        def stage_b():
+            s = st["state"]
+            state = dict(memory=[s[0], s[1], s[2]], raft_feat=s[3], raft_netinp=s[4])
+            outputs = dict(st["stereo"])
+            raft._pending, raft._nowait = dict(fmap=st["fmap"], netinp=st["netinp"]), True
+            try:
+                self.est.motion(state, outputs, img_metas=self.metas, train_mode=False)
+                self.est.fusion.memory_query(outputs, state, img_metas=self.metas)
+                self.est.fusion.memory_update(outputs, state, img_metas=self.metas)
+            finally:
+                raft._pending, raft._nowait = None, False
+            # state write-back with kernels (see _capture); netinp is written by step() once s2 has finished
+            for dst, src in zip(s[:4], self._state_tensors(state)[:4]):
+                ops.add_relu(src.contiguous(), None, relu=False, out=dst)
+            return outputs["pred_disp"]
+
+        def capture(stream, fn):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(stream):
+                out = fn()  # warm-up on the capture stream (weight packing, allocator)
+                torch.cuda.synchronize(dev)
+                with torch.cuda.graph(g, stream=stream):
+                    out = fn()
+            return g, out
+
+        with torch.no_grad():
+            st["g_f"], st["fmap"] = capture(s1, lambda: raft.fnet(st["l"]))
+            st["g_c"], st["netinp"] = capture(s2, lambda: raft.context(st["l"]))
+            st["g_s"], st["stereo"] = capture(s0, lambda: self.est.stereo.stereo_matching(st["l"], st["r"], self.metas, {}))
+            # (capture does not execute: run the three once so that stage B's warm-up reads real tensors)
+            for g in (st["g_f"], st["g_c"], st["g_s"]):
+                g.replay()
+            torch.cuda.synchronize(dev)
+            st["g_m"], st["out"] = capture(s0, stage_b)
+        torch.cuda.synchronize(dev)
+        for dst, src in zip(st["state"], saved):  # the warm-up advanced the state: restore, step() replays this frame
+            dst.copy_(src)
+        cur.wait_stream(s0)
+        self.graph, self._static = st["g_m"], st
+
+    def _replay_split(self):
+        st = self._static
+        dev = st["l"].device
+        s0, s1, s2 = st["streams"]
+        cur = torch.cuda.current_stream(dev)
+        for s in (s0, s1, s2):
+            s.wait_stream(cur)  # the input copies
+        with torch.cuda.stream(s0):
+            st["g_s"].replay()
+        with torch.cuda.stream(s1):
+            st["g_f"].replay()
+        with torch.cuda.stream(s2):
+            st["g_c"].replay()
+        with torch.cuda.stream(s0):
+            s0.wait_stream(s1)
+            st["g_m"].replay()
+            s0.wait_stream(s2)
+            ops.add_relu(st["netinp"], None, relu=False, out=st["state"][4])
+        cur.wait_stream(s0)
+
     def eager_frame_on_static_state(self, left, right):
         """One eager (un-captured) steady-state frame on the current recurrent state -- used by
         bench.py to bracket individual launches with events.  Advances the state."""
@@ -124,7 +215,10 @@ class FrameRunner:
             d = self._eager(left, right)
             return d
         if self.graph is None:
-            self._capture(left, right)
+            if self.split and not ops.Fork.serial:
+                self._capture_split(left, right)
+            else:
+                self._capture(left, right)
         elif not self._static["primed"]:
             for dst, src in zip(self._static["state"], self._state_tensors(self.state)):
                 dst.copy_(src)
@@ -132,7 +226,10 @@ class FrameRunner:
         st = self._static
         st["l"].copy_(left, non_blocking=True)
         st["r"].copy_(right, non_blocking=True)
-        self.graph.replay()
+        if st.get("split"):
+            self._replay_split()
+        else:
+            self.graph.replay()
         self.state = {"memory": True}  # state now lives in the static buffers
         return st["out"]
 

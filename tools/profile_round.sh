@@ -11,7 +11,7 @@ for mode in serial default; do
   rm -rf /tmp/st_$mode
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$mode -o s -- python $R/bench.py --steps 60 --no-cpu-baseline --tune-db $OUT/tune_db.json $flag > $OUT/bench_$mode.log 2>&1
   cp /tmp/st_$mode/s_kernel_stats.csv $OUT/${mode}_kernel_stats.csv
-  [ $mode = default ] && python3 $R/tools/timeline_gaps.py /tmp/st_$mode/s_kernel_trace.csv > $OUT/timeline_default.txt 2>&1
+  [ $mode = default ] && python3 $R/tools/timeline_gaps.py /tmp/st_$mode/s_kernel_trace.csv --dump $OUT/frame_sequence.txt > $OUT/timeline_default.txt 2>&1
 done
 CMD="python $R/bench.py --no-cpu-baseline --tune-db $OUT/tune_db.json --serial-streams --steps 4 --prewarm 2 --warmup 1 --no-graph"
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do

@@ -1,7 +1,8 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from codd_amd import configs, synth
+from codd_amd import configs, synth, ops
+ops.enable_autotune(True, shipped=True)
 from codd_amd.registry import build_estimator
 from codd_amd.runtime import FrameRunner
 H, W = 576, 960

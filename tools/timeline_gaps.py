@@ -2,10 +2,17 @@
 disp_metrics_finish kernels) and report busy time, idle gaps and concurrency."""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows), key=lambda t: t[0])
+ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
+              "%sx%sx%s/%s" % (r.get("Grid_Size_X", "?"), r.get("Grid_Size_Y", "?"), r.get("Grid_Size_Z", "?"), r.get("Workgroup_Size_X", "?")),
+              r.get("Stream_Id", r.get("Queue_Id", "?"))) for r in rows), key=lambda t: t[0])
 marks = [i for i, e in enumerate(ev) if "disp_metrics_finish" in e[2]]
 a, b = marks[-3], marks[-2]
 fr = ev[a + 1:b + 1]
+if len(sys.argv) > 3 and sys.argv[2] == "--dump":  # the frame's launches in start order: offset, duration, queue, name, grid
+    with open(sys.argv[3], "w") as f:
+        for s_, e_, n_, g_, q_ in fr:
+            f.write("%9.1f us  %7.1f us  q%-4s %-70s %s\n" % ((s_ - fr[0][0]) / 1e3, (e_ - s_) / 1e3, q_, n_[:70], g_))
+fr = [e[:3] for e in fr]
 t0, t1 = fr[0][0], max(e[1] for e in fr)
 print("frame: %d kernels, wall %.2f ms, sum of kernel time %.2f ms" % (len(fr), (t1 - t0) / 1e6, sum(e[1] - e[0] for e in fr) / 1e6))
 # union coverage and gaps
