@@ -14,6 +14,11 @@ class View(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("ctot", C.c_int), ("coff", C.c_int)]
 
 
+class XsView(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("c8", C.c_int), ("hp", C.c_int), ("wp", C.c_int), ("bt", C.c_int),
+                ("bl", C.c_int), ("o8", C.c_int), ("terms", C.c_int)]
+
+
 class ConvParams(C.Structure):
     _fields_ = [
         ("in0", View), ("in1", View), ("C0", C.c_int), ("C1", C.c_int),
@@ -69,6 +74,8 @@ SIGNATURES = {
     "codd_add_relu": (_i, [_p, _p, _ll, _i, _p, _p]),
     "codd_gru_gate_zr": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "codd_gru_gate_q": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p]),
+    "codd_gru_gate_zr_xs": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, XsView, _p]),
+    "codd_gru_gate_q_xs": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, XsView, _p]),
     "codd_fusion_cues_lr": (_i, [_p] * 6 + [_i] * 5 + [_p, _p, _i, _i, _p]),
     "codd_fusion_cues_fr": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "codd_disp_metrics": (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p]),

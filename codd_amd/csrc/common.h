@@ -30,6 +30,28 @@ __device__ __forceinline__ float act_apply(float v, int act, int co) {
   }
 }
 
+// 8 consecutive channels of one pixel -> the split-bf16 record(s) of a codd_xs_view (same rounding as
+// split_bf16_kernel: hi = RNE(v), lo = RNE(v - hi))
+typedef __bf16 codd_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void xs_store8(const codd_xs_view& d, int b, int oct, int y, int x, const float* v) {
+  const size_t per = (size_t)d.c8 * d.hp * d.wp;
+  const int planes = d.terms == 3 ? 2 : 1;
+  codd_bf16x8 h, l;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 hh = (__bf16)v[i];
+    h[i] = hh;
+    l[i] = (__bf16)(v[i] - (float)hh);
+  }
+  uint4* dst = (uint4*)d.ptr + (size_t)b * planes * per + ((size_t)(d.o8 + oct) * d.hp + (y + d.bt)) * d.wp + (x + d.bl);
+  dst[0] = __builtin_bit_cast(uint4, h);
+  if (planes == 2) dst[per] = __builtin_bit_cast(uint4, l);
+}
+static inline bool xs_view_ok(const codd_xs_view& d, int C, int H, int W) {
+  return d.ptr && !((uintptr_t)d.ptr & 15) && (d.terms == 1 || d.terms == 3) && d.o8 >= 0 && 8 * (d.c8 - d.o8) >= C &&
+         d.bt >= 0 && d.bl >= 0 && d.hp >= d.bt + H && d.wp >= d.bl + W;
+}
+
 // wave64 butterfly helpers
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -1067,6 +1067,70 @@ extern "C" int codd_gru_gate_q(const float* t1, const float* t2, const float* in
   return CODD_OK;
 }
 
+// The gates writing split-bf16 records: one thread = 8 consecutive channels of one pixel (16-byte record stores;
+// the fp32 loads of a wave are 8 coalesced rows of 64 pixels).  Arithmetic identical to the kernels above.
+__global__ void gru_gate_zr_xs_kernel(const float* __restrict__ t1, const float* __restrict__ t2,
+                                      const float* __restrict__ inp, const float* __restrict__ cor,
+                                      const float* __restrict__ mot, const float* __restrict__ h, int B, int H, int W,
+                                      float* __restrict__ z, const codd_xs_view rh) {
+  const int hw = H * W;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long long)B * 16 * hw) return;
+  const int pix = (int)(e % hw), oct = (int)((e / hw) % 16), b = (int)(e / (16LL * hw));
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = oct * 8 + i;
+    const size_t ez = ((size_t)b * 256 + c) * hw + pix, er = ez + (size_t)128 * hw;
+    const size_t iz = ((size_t)b * 384 + c) * hw + pix, ir = iz + (size_t)128 * hw;
+    const size_t ih = ((size_t)b * 128 + c) * hw + pix;
+    z[ih] = 1.f / (1.f + expf(-((t1[ez] + t2[ez]) + ((inp[iz] + cor[iz]) + mot[iz]))));
+    const float r = 1.f / (1.f + expf(-((t1[er] + t2[er]) + ((inp[ir] + cor[ir]) + mot[ir]))));
+    v[i] = r * h[ih];
+  }
+  xs_store8(rh, b, oct, pix / W, pix % W, v);
+}
+__global__ void gru_gate_q_xs_kernel(const float* __restrict__ t1, const float* __restrict__ t2,
+                                     const float* __restrict__ inp, const float* __restrict__ cor,
+                                     const float* __restrict__ mot, const float* __restrict__ z,
+                                     const float* __restrict__ h, int B, int H, int W, float* __restrict__ ho,
+                                     const codd_xs_view hx) {
+  const int hw = H * W;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long long)B * 16 * hw) return;
+  const int pix = (int)(e % hw), oct = (int)((e / hw) % 16), b = (int)(e / (16LL * hw));
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = oct * 8 + i;
+    const size_t ih = ((size_t)b * 128 + c) * hw + pix;
+    const size_t i3 = ((size_t)b * 384 + 256 + c) * hw + pix;
+    const float q = tanhf((t1[ih] + t2[ih]) + ((inp[i3] + cor[i3]) + mot[i3]));
+    const float zz = z[ih];
+    v[i] = (1.f - zz) * h[ih] + zz * q;
+    ho[ih] = v[i];
+  }
+  xs_store8(hx, b, oct, pix / W, pix % W, v);
+}
+extern "C" int codd_gru_gate_zr_xs(const float* t1, const float* t2, const float* inp, const float* cor,
+                                   const float* mot, const float* h, int B, int H, int W, float* z, codd_xs_view rh_xs,
+                                   void* stream) {
+  if (!t1 || !t2 || !inp || !cor || !mot || !h || !z || !xs_view_ok(rh_xs, 128, H, W)) return CODD_EINVAL;
+  const long long total = (long long)B * 16 * H * W;
+  gru_gate_zr_xs_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(t1, t2, inp, cor, mot, h, B, H, W, z, rh_xs);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+extern "C" int codd_gru_gate_q_xs(const float* t1, const float* t2, const float* inp, const float* cor, const float* mot,
+                                  const float* z, const float* h, int B, int H, int W, float* hout, codd_xs_view h_xs,
+                                  void* stream) {
+  if (!t1 || !t2 || !inp || !cor || !mot || !z || !h || !hout || !xs_view_ok(h_xs, 128, H, W)) return CODD_EINVAL;
+  const long long total = (long long)B * 16 * H * W;
+  gru_gate_q_xs_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(t1, t2, inp, cor, mot, z, h, B, H, W, hout, h_xs);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
 // net = tanh(x[:, :128]), inp = relu(x[:, 128:512])  (reference raft3d.py:183-186)
 __global__ void context_split_kernel(const float* __restrict__ x, int hw, float* __restrict__ net,
                                      float* __restrict__ inp, long long total) {

@@ -119,12 +119,14 @@ class BasicUpdateBlock(nn.Module):
         return t1, t2
 
     def _split(self, t):
-        """One split-bf16 re-layout (border 4: serves the 3x3 and the dilated 3x3 convolutions) of a hidden-state
-        sized tensor, shared by all of its consumers; cached per tensor so that the forked z|r convolutions of the
-        next update and this update's head convolution use the same one."""
+        """The split-bf16 form (border 4: serves the 3x3 and the dilated 3x3 convolutions) of the hidden state, shared
+        by all of its consumers -- the forked z|r convolutions of the next update and this update's head convolution.
+        gru_gate_q_xs writes it together with the fp32 state (``_xs`` = (tensor, its split form)); only the initial
+        state (context network output) needs a re-layout pass, into the same persistent tensor."""
         c = getattr(self, "_xs", None)
         if c is None or c[0] is not t:
-            c = self._xs = (t, ops.split_input(t, border=4))
+            hb = ops.split_buffer((id(self), "net"), t.shape[0], 128, t.shape[2], t.shape[3], 4, t.device)
+            c = self._xs = (t, ops.split_input(t, border=4, out=hb) if hb is not None else None)
         return c[1]
 
     def _forks(self, dev):
@@ -173,12 +175,20 @@ class BasicUpdateBlock(nn.Module):
         cor = corr_chain()
         fk.join()
         fkz.join()
-        zr_g, rh = ops.gru_gate_zr(t1, t2, inp, cor, mot, net)
-        rs = ops.split_input(rh, border=4)  # one re-layout for both q convolutions
-        q2 = fk.run(0, lambda: cv(g.convq2, rh, xs=rs))
-        q1 = cv(g.convq1, rh, xs=rs)
-        fk.join()
-        net = ops.gru_gate_q(q1, q2, inp, cor, mot, zr_g, net)
+        rs, hb = sb("rh", 128, 4), sb("net", 128, 4)
+        if rs is None:
+            zr_g, rh = ops.gru_gate_zr(t1, t2, inp, cor, mot, net)
+            q2 = fk.run(0, lambda: cv(g.convq2, rh))
+            q1 = cv(g.convq1, rh)
+            fk.join()
+            net = ops.gru_gate_q(q1, q2, inp, cor, mot, zr_g, net)
+        else:  # the gates write r*h / the new state directly in the following convolutions' input form
+            z = ops.gru_gate_zr_xs(t1, t2, inp, cor, mot, net, rs)
+            q2 = fk.run(0, lambda: cv(g.convq2, None, xs=rs))
+            q1 = cv(g.convq1, None, xs=rs)
+            fk.join()
+            net = ops.gru_gate_q_xs(q1, q2, inp, cor, mot, z, net, hb)
+            self._xs = (net, hb)
         zr_next = self.zr_convs(net) if prefetch_next else None
         # the four 3x3 head convs share their input: one 768/1024-channel conv; the mask head (576
         # up-sampling weights) is only consumed after the last iteration (raft3d.py:267-273)

@@ -270,7 +270,7 @@ class SplitTensor:
         self.bt, self.bl, self.hp, self.wp, self.c8, self.terms = bt, bl, hp, wp, c8, terms
 
 
-def split_input(x, x2=None, border=0, c8=None, hp=None, wp=None):
+def split_input(x, x2=None, border=0, c8=None, hp=None, wp=None, out=None):
     """codd_split_bf16 of (x | x2) with a zero border of ``border`` pixels (int or (top, left)); hp / wp default to
     the size that serves every instantiated tile (rows up to 16, 32-pixel columns) of a stride-1 'same' convolution
     whose padding does not exceed the border.  Returns None outside the split / bf16 precision modes."""
@@ -282,6 +282,10 @@ def split_input(x, x2=None, border=0, c8=None, hp=None, wp=None):
     _require_gpu(xs.buf)
     B, C0, H, W = xs.shape
     C1 = 0 if x2 is None else _as_slice(x2).c
+    if out is not None:  # re-layout into an existing (persistent) tensor of the same geometry
+        _abi.check(lib.codd_split_bf16(_view(xs), C0, _view(x2), C1, B, H, W, out.bt, out.bl, out.c8, out.hp, out.wp,
+                                       out.terms, out.buf.data_ptr(), _stream()), "codd_split_bf16")
+        return out
     bt, bl = (border, border) if isinstance(border, int) else border
     c8 = -(-(C0 + C1) // 32) * 4 if c8 is None else c8  # whole 32-channel chunks
     hp = 2 * bt + -(-H // 16) * 16 if hp is None else hp
@@ -883,6 +887,34 @@ def gru_gate_zr(t1, t2, inp, cor, mot, h):
     _abi.check(lib.codd_gru_gate_zr(t1.data_ptr(), t2.data_ptr(), inp.data_ptr(), cor.data_ptr(), mot.data_ptr(),
                                     h.data_ptr(), B, hh * ww, zr.data_ptr(), rh.data_ptr(), _stream()), "gru_gate_zr")
     return zr, rh
+
+
+def _xs_view(st, coff=0):
+    return _abi.XsView(st.buf.data_ptr(), st.c8, st.hp, st.wp, st.bt, st.bl, coff // 8, st.terms)
+
+
+def gru_gate_zr_xs(t1, t2, inp, cor, mot, h, rh_xs):
+    """gru_gate_zr writing r*h straight into the q convolutions' split-bf16 input (``rh_xs``: split_buffer) and only
+    z as fp32: no fp32 r*h tensor, no re-layout launch.  Returns z [B,128,h,w]."""
+    lib = _abi.load()
+    B, _, hh, ww = h.shape
+    z = torch.empty_like(h)
+    _abi.check(lib.codd_gru_gate_zr_xs(t1.data_ptr(), t2.data_ptr(), inp.data_ptr(), cor.data_ptr(), mot.data_ptr(),
+                                       h.data_ptr(), B, hh, ww, z.data_ptr(), _xs_view(rh_xs), _stream()),
+               "gru_gate_zr_xs")
+    return z
+
+
+def gru_gate_q_xs(t1, t2, inp, cor, mot, z, h, h_xs):
+    """gru_gate_q with ``z`` as returned by gru_gate_zr_xs; the new hidden state is returned as fp32 AND written as
+    split records into ``h_xs`` (the input of the head convolution and of the next update's z|r convolutions)."""
+    lib = _abi.load()
+    B, _, hh, ww = h.shape
+    ho = torch.empty_like(h)
+    _abi.check(lib.codd_gru_gate_q_xs(t1.data_ptr(), t2.data_ptr(), inp.data_ptr(), cor.data_ptr(), mot.data_ptr(),
+                                      z.data_ptr(), h.data_ptr(), B, hh, ww, ho.data_ptr(), _xs_view(h_xs), _stream()),
+               "gru_gate_q_xs")
+    return ho
 
 
 def gru_gate_q(t1, t2, inp, cor, mot, zr, h):

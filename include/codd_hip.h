@@ -269,6 +269,25 @@ int codd_gru_gate_q(const float* t1, const float* t2, const float* inp, const fl
                     const float* mot, const float* zr, const float* h, int B, int hw, float* hout,
                     void* stream);
 
+/* A split-bf16 activation tensor (codd_split_bf16 layout: [b][plane hi|lo][octet][hp][wp][8 bf16], image pixel
+ * (y, x) at (y + bt, x + bl), planes = 2 for terms 3 / 1 for terms 1) as the DESTINATION of a producer kernel: the
+ * producer writes the image interior of channels [8*o8, ...) only; border and padding channels stay as they are
+ * (zero in a persistent buffer). */
+typedef struct codd_xs_view {
+  void* ptr;
+  int c8, hp, wp, bt, bl, o8, terms;
+} codd_xs_view;
+
+/* The same gates, writing what the following convolutions read directly in their input form (no fp32 tensor, no
+ * re-layout pass between gate and convolution):
+ *   zr_xs: z [B,128,hw] fp32 (only z is read again) and r*h as split records into rh_xs (128 channels);
+ *   q_xs:  z as written by zr_xs; the new hidden state as fp32 hout AND as split records into h_xs. */
+int codd_gru_gate_zr_xs(const float* t1, const float* t2, const float* inp, const float* cor, const float* mot,
+                        const float* h, int B, int H, int W, float* z, codd_xs_view rh_xs, void* stream);
+int codd_gru_gate_q_xs(const float* t1, const float* t2, const float* inp, const float* cor, const float* mot,
+                       const float* z, const float* h, int B, int H, int W, float* hout, codd_xs_view h_xs,
+                       void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fusion
  * --------------------------------------------------------------------------------------------- */

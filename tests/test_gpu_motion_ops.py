@@ -558,6 +558,28 @@ def test_fused_geometry_lookup_equals_separate_kernels():
     assert (corr - corr2).abs().max().item() < 1e-5 * max(1.0, corr.abs().max().item())
 
 
+def test_gru_gates_writing_split_records_equal_gate_plus_relayout():
+    """codd_gru_gate_zr_xs / codd_gru_gate_q_xs (gate fused with the re-layout of its result into the next
+    convolution's split-bf16 input) == the plain gate kernels followed by codd_split_bf16, bit for bit."""
+    from codd_amd import ops
+    B, h, w = 1, 23, 37
+    t1, t2 = rnd(B, 256, h, w, seed=1).to(DEV), rnd(B, 256, h, w, seed=2).to(DEV)
+    inp, cor, mot = (rnd(B, 384, h, w, seed=s).to(DEV) for s in (3, 4, 5))
+    net = torch.tanh(rnd(B, 128, h, w, seed=6)).to(DEV)
+    zr, rh = ops.gru_gate_zr(t1, t2, inp, cor, mot, net)
+    rs = ops.split_buffer(("test", "rh"), B, 128, h, w, 4, DEV)
+    z = ops.gru_gate_zr_xs(t1, t2, inp, cor, mot, net, rs)
+    assert torch.equal(z, zr[:, :128])
+    ref = ops.split_input(rh, border=4)
+    assert (ref.c8, ref.hp, ref.wp) == (rs.c8, rs.hp, rs.wp) and torch.equal(ref.buf, rs.buf)
+    q1, q2 = rnd(B, 128, h, w, seed=7).to(DEV), rnd(B, 128, h, w, seed=8).to(DEV)
+    h_ref = ops.gru_gate_q(q1, q2, inp, cor, mot, zr, net)
+    hb = ops.split_buffer(("test", "net"), B, 128, h, w, 4, DEV)
+    h_new = ops.gru_gate_q_xs(q1, q2, inp, cor, mot, z, net, hb)
+    assert torch.equal(h_new, h_ref)
+    assert torch.equal(ops.split_input(h_ref, border=4).buf, hb.buf)
+
+
 def test_full_codd_parity_with_autotuned_launch_configurations():
     """The configurations the tuner picks (quad-layout kernel, 2/8/9-wave workgroups, ...) in the whole pipeline:
     HIP vs oracle on a 3-frame sequence, same bound as the un-tuned parity tests."""
