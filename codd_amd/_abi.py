@@ -65,6 +65,7 @@ SIGNATURES = {
     "codd_raft_geometry": (_i, [_p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p]),
     "codd_se3_gn_step": (_i, [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f, _p, _p]),
     "codd_se3_gn_scratch": (_ll, [_i, _i, _i, _i]),
+    "codd_se3_gn_step_heads": (_i, [_p, XsView, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f, _p, _p, _p]),
     "codd_cvx_upsample": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "codd_disp_to_depth": (_i, [_p, _ll, _f, _p, _p]),
     "codd_splat": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f,

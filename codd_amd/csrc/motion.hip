@@ -338,6 +338,117 @@ __global__ void se3_gn_prep_kernel(const float* __restrict__ ae, int ae_c, const
   rp[41] = a2; rp[42] = 0.f; rp[43] = 0.f;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The three 1x1 heads (ae 256->32, delta 256->3, weight 256->3 + sigmoid; reference raft3d.py:59-61,100-104) fused
+// with the record packing above: the 768 hidden channels arrive as split-bf16 records (written by the 3x3 head
+// convolution), x = hi + lo is rebuilt in fp32 and multiplied with the fp32 weights -- the heads' outputs never
+// exist as tensors (except weight, which the caller up-samples after the last update).
+// ------------------------------------------------------------------------------------------------
+// One wave = 16 pixels, three 16-row MFMA tiles (v_mfma_f32_16x16x32_bf16, rows = head outputs, columns = pixels):
+// tiles 0/1 = the 32 ae rows over hidden channels 0..255 (8 k-steps), tile 2 = [delta 3 rows | weight 3 rows | 0]
+// over channels 256..767 (16 k-steps, zero weights where a row does not read a channel).  A 16-byte record (8 channels
+// of one pixel) IS the B operand of lane (pixel = lane % 16, k-group = lane / 16), so the hidden channels go from
+// global memory straight into the MFMA; the weights are pre-packed on the host as A operands
+// [32 (tile, k-step) blocks][plane hi|lo][lane][8 bf16] (64 KB, L2-resident).  Same 3-term split arithmetic as the
+// convolution kernel (conv_bf16_kernel.h).  Lane (g = lane / 16) ends up with rows 4g..4g+3 of every tile for its
+// pixel = 4 consecutive floats of the record.
+__global__ __launch_bounds__(64) void gn_heads_prep_kernel(const codd_xs_view hs, const uint4* __restrict__ Wp,
+                                                          const float* __restrict__ bias,
+                                                          const float* __restrict__ xyz, const float* __restrict__ d1,
+                                                          int h, int w, float fx, float fy, float cx, float cy,
+                                                          float* __restrict__ jd, float* __restrict__ wout) {
+  const int N = h * w;
+  const int lane = threadIdx.x, px = lane & 15, g = lane >> 4, b = blockIdx.y;
+  const int n = blockIdx.x * 16 + px;
+  const bool ok = n < N;
+  const int j = ok ? n : N - 1;
+  const int yj = j / w, xj = j - yj * w;
+  const size_t per = (size_t)hs.c8 * hs.hp * hs.wp, ostride = (size_t)hs.hp * hs.wp;
+  const bool three = hs.terms == 3;
+  const uint4* src = (const uint4*)hs.ptr + (size_t)b * (three ? 2 : 1) * per +
+                     ((size_t)(hs.o8 + g) * hs.hp + (yj + hs.bt)) * hs.wp + (xj + hs.bl);
+  const uint4* wl = Wp + lane;
+  f32x4 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // k-steps 0..7: channels 0..255 -> tiles 0, 1;  k-steps 8..23: channels 256..767 -> tile 2.  Three phases of 8
+  // k-steps; the loads of a phase are all in flight before the MFMAs of the previous one are issued (the compiler's
+  // own order is load-wait-MFMA per k-step, 24 exposed latencies) -- sched_barriers pin the phases.
+  uint4 xh[2][8], xl[2][8], wh[2][16], wlo[2][16];
+#define HEADS_LOAD(P, BUF)                                                                              \
+  {                                                                                                     \
+    _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                                     \
+      xh[BUF][s] = src[(size_t)4 * (8 * (P) + s) * ostride];                                            \
+      if (three) xl[BUF][s] = src[per + (size_t)4 * (8 * (P) + s) * ostride];                           \
+    }                                                                                                   \
+    _Pragma("unroll") for (int q = 0; q < ((P) == 0 ? 16 : 8); ++q) {                                   \
+      const uint4* wb = wl + (size_t)((P) == 0 ? q : 8 + 8 * (P) + q) * 128;                            \
+      wh[BUF][q] = wb[0];                                                                               \
+      if (three) wlo[BUF][q] = wb[64];                                                                  \
+    }                                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+  }
+#define HEADS_MMA(T, WQ, BUF, S)                                                                        \
+  {                                                                                                     \
+    const codd_bf16x8 ah = __builtin_bit_cast(codd_bf16x8, wh[BUF][WQ]);                                \
+    const codd_bf16x8 bh = __builtin_bit_cast(codd_bf16x8, xh[BUF][S]);                                 \
+    if (three) {                                                                                        \
+      const codd_bf16x8 al = __builtin_bit_cast(codd_bf16x8, wlo[BUF][WQ]);                             \
+      const codd_bf16x8 bl = __builtin_bit_cast(codd_bf16x8, xl[BUF][S]);                               \
+      acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[T], 0, 0, 0);                        \
+      acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[T], 0, 0, 0);                        \
+    }                                                                                                   \
+    acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[T], 0, 0, 0);                          \
+  }
+  HEADS_LOAD(0, 0)
+  HEADS_LOAD(1, 1)
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    HEADS_MMA(0, s, 0, s)
+    HEADS_MMA(1, 8 + s, 0, s)
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  HEADS_LOAD(2, 0)
+#pragma unroll
+  for (int s = 0; s < 8; ++s) HEADS_MMA(2, s, 1, s)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) HEADS_MMA(2, s, 0, s)
+#undef HEADS_LOAD
+#undef HEADS_MMA
+  float* rp = jd + ((size_t)b * N + j) * GN_JS;
+  // ae rows 16 t + 4 g + r -> record floats [16 t + 4 g, +4)
+  float a2 = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] = (acc[t][r] + bias[16 * t + 4 * g + r]) * 0.125f;
+      a2 += v[r] * v[r];
+    }
+    if (ok) *(f32x4*)(rp + 16 * t + 4 * g) = v;
+  }
+  a2 += __shfl_xor(a2, 16, 64);
+  a2 += __shfl_xor(a2, 32, 64);
+  // tile 2: g = 0 holds (delta0, delta1, delta2, weight0), g = 1 holds (weight1, weight2, 0, 0)
+  const float w1 = __shfl_down(acc[2][0], 16, 64), w2 = __shfl_down(acc[2][1], 16, 64);
+  if (g == 0 && ok) {
+    const V3 X = inv_project(d1[(size_t)b * N + j], xj, yj, fx, fy, cx, cy);
+    const float* xb = xyz + ((size_t)b * N + j) * 3;
+    const float dl0 = acc[2][0] + bias[32], dl1 = acc[2][1] + bias[33], dl2 = acc[2][2] + bias[34];
+    float wv[3] = {acc[2][3] + bias[35], w1 + bias[36], w2 + bias[37]};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      wv[r] = 1.f / (1.f + expf(-wv[r]));
+      wout[((size_t)b * 3 + r) * N + j] = wv[r];
+    }
+    *(f32x4*)(rp + 32) = f32x4{X.x, X.y, X.z, xb[0] + dl0};
+    *(f32x4*)(rp + 36) = f32x4{xb[1] + dl1, xb[2] + dl2, wv[0], wv[1]};
+    *(f32x4*)(rp + 40) = f32x4{wv[2], a2, 0.f, 0.f};
+  }
+}
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ v2f GN_PK(v2f a, v2f b, v2f c) {  // -> v_pk_fma_f32: 2 fp32 FMAs per lane and issue slot
   return __builtin_elementwise_fma(a, b, c);
@@ -565,25 +676,48 @@ extern "C" long long codd_se3_gn_scratch(int B, int h, int w, int radius) {
   return (long long)B * ntiles * gn_gmax(radius) * 27 * 64 + (long long)B * h * w * GN_JS;
 }
 
-extern "C" int codd_se3_gn_step(float* T, const float* ae, int ae_c, const float* xyz, const float* delta,
-                                const float* weight, const float* depth1, int B, int h, int w, float fx, float fy,
-                                float cx, float cy, int radius, float lm, float ep, float* Hb, void* stream) {
-  if (!T || !ae || !xyz || !delta || !weight || !depth1 || !Hb || ae_c < 1 || ae_c > GN_AE || radius < 0)
-    return CODD_EINVAL;
+static int gn_build_solve(float* T, int B, int h, int w, float fx, float fy, float cx, float cy, int radius, float lm,
+                          float ep, float* Hb, hipStream_t s) {
   const int tiles_x = cdiv(w, 8), ntiles = tiles_x * cdiv(h, 8);
   const int q4 = gn_q4(), gmax = gn_gmax(radius);
   float* part = Hb;
-  float* jd = Hb + (size_t)B * ntiles * gmax * 27 * 64;
-  hipStream_t s = (hipStream_t)stream;
-  se3_gn_prep_kernel<<<dim3(cdiv(h * w, 128), B), 128, 0, s>>>(ae, ae_c, xyz, delta, weight, depth1, h, w, fx, fy, cx,
-                                                             cy, jd);
-  CODD_LAUNCH_CHECK();
+  const float* jd = Hb + (size_t)B * ntiles * gmax * 27 * 64;
   se3_gn_build_kernel<<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, s>>>(T, jd, h, w, fx, fy, cx, cy, radius, tiles_x,
                                                                       ntiles, q4, gmax, part);
   CODD_LAUNCH_CHECK();
   se3_gn_solve_kernel<<<dim3(ntiles, B), 64 * GN_SOLVE_WAVES, 0, s>>>(T, part, h, w, radius, tiles_x, ntiles, q4, gmax, lm, ep);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
+}
+
+extern "C" int codd_se3_gn_step(float* T, const float* ae, int ae_c, const float* xyz, const float* delta,
+                                const float* weight, const float* depth1, int B, int h, int w, float fx, float fy,
+                                float cx, float cy, int radius, float lm, float ep, float* Hb, void* stream) {
+  if (!T || !ae || !xyz || !delta || !weight || !depth1 || !Hb || ae_c < 1 || ae_c > GN_AE || radius < 0)
+    return CODD_EINVAL;
+  const int ntiles = cdiv(w, 8) * cdiv(h, 8);
+  float* jd = Hb + (size_t)B * ntiles * gn_gmax(radius) * 27 * 64;
+  hipStream_t s = (hipStream_t)stream;
+  se3_gn_prep_kernel<<<dim3(cdiv(h * w, 128), B), 128, 0, s>>>(ae, ae_c, xyz, delta, weight, depth1, h, w, fx, fy, cx,
+                                                             cy, jd);
+  CODD_LAUNCH_CHECK();
+  return gn_build_solve(T, B, h, w, fx, fy, cx, cy, radius, lm, ep, Hb, s);
+}
+
+extern "C" int codd_se3_gn_step_heads(float* T, codd_xs_view hidden, const void* head_w, const float* head_b,
+                                      const float* xyz, const float* depth1, int B, int h, int w, float fx, float fy,
+                                      float cx, float cy, int radius, float lm, float ep, float* weight_out, float* Hb,
+                                      void* stream) {
+  if (!T || !head_w || ((uintptr_t)head_w & 15) || !head_b || !xyz || !depth1 || !weight_out || !Hb || radius < 0 ||
+      !xs_view_ok(hidden, 768, h, w))
+    return CODD_EINVAL;
+  const int ntiles = cdiv(w, 8) * cdiv(h, 8);
+  float* jd = Hb + (size_t)B * ntiles * gn_gmax(radius) * 27 * 64;
+  hipStream_t s = (hipStream_t)stream;
+  gn_heads_prep_kernel<<<dim3(cdiv(h * w, 16), B), 64, 0, s>>>(hidden, (const uint4*)head_w, head_b, xyz, depth1, h, w, fx, fy, cx, cy,
+                                                               jd, weight_out);
+  CODD_LAUNCH_CHECK();
+  return gn_build_solve(T, B, h, w, fx, fy, cx, cy, radius, lm, ep, Hb, s);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -134,7 +134,7 @@ class BasicUpdateBlock(nn.Module):
             self._fk = (ops.Fork(dev, 3), ops.Fork(dev, 2))
         return self._fk
 
-    def run(self, net, inp, corr, minfo, need_mask, zr=None, prefetch_next=False):
+    def run(self, net, inp, corr, minfo, need_mask, zr=None, prefetch_next=False, fuse_heads=False):
         """One update (reference raft3d.py:92-106).  Launch schedule: the correlation encoder chain,
         the flow encoder chain and the two z|r gate convolutions only depend on data available at
         the start of the update, so they are forked onto side streams; likewise the two q
@@ -200,12 +200,52 @@ class BasicUpdateBlock(nn.Module):
         else:  # the 768 / 1024 hidden channels only ever exist as the four 1x1 heads' split-form input
             ops.conv2d(net, packed_cat(heads), pad=1, act="relu", xs=self._split(net), xs_out=hs)
             sl = lambda i: None
+        if hs is not None and fuse_heads:
+            # the ae / delta / weight 1x1 heads run inside the Gauss-Newton record packing (ops.se3_gn_step_heads)
+            mask = cv(self.mask[2], None, xs=hs, xs_coff=768) if need_mask else None
+            return net, mask, None, None, None, zr_next, hs
         delta = fk.run(0, lambda: cv(self.delta[2], sl(1), xs=hs, xs_coff=256))
         weight = fk.run(1, lambda: cv(self.weight[2], sl(2), act="sigmoid", xs=hs, xs_coff=512))
         mask = fk.run(2, lambda: cv(self.mask[2], sl(3), xs=hs, xs_coff=768)) if need_mask else None
         ae = cv(self.ae[2], sl(0), xs=hs, xs_coff=0)
         fk.join()
-        return net, mask, ae, delta, weight, zr_next
+        return net, mask, ae, delta, weight, zr_next, None
+
+    def head_matrix(self):
+        """The three 1x1 heads (ae 32, delta 3, weight 3 rows x 256) packed as the MFMA A operands of
+        codd_se3_gn_step_heads (include/codd_hip.h) + their 38 biases; cached on the module per parameter version."""
+        mods = (self.ae[2], self.delta[2], self.weight[2])
+        ver = tuple((m.weight.data_ptr(), m.weight._version, m.bias._version) for m in mods)
+        c = self.__dict__.get("_codd_head_matrix")
+        if c is None or c[0] != ver:
+            Wm = torch.cat([m.weight.detach().reshape(m.weight.shape[0], 256) for m in mods], 0).float()
+            bm = torch.cat([m.bias.detach() for m in mods], 0).float().contiguous()
+            c = self.__dict__["_codd_head_matrix"] = (ver, pack_head_matrix(Wm), bm)
+        return c[1], c[2]
+
+
+def pack_head_matrix(Wm):
+    """[38, 256] fp32 (ae rows 0..31, delta 32..34, weight 35..37) -> [32, 2, 64, 8] bf16 A-operand blocks."""
+    dev = Wm.device
+    full = torch.zeros(48, 768, device=dev)  # rows: 32 ae | delta 3 | weight 3 | 10 zero; columns: hidden channel
+    full[:32, :256] = Wm[:32]
+    full[32:35, 256:512] = Wm[32:35]
+    full[35:38, 512:768] = Wm[35:38]
+    lane = torch.arange(64, device=dev)
+    row, kg = lane % 16, lane // 16
+    k8 = torch.arange(8, device=dev)
+    blocks = []
+    for t in range(2):
+        for s_ in range(8):
+            cols = (32 * s_ + 8 * kg)[:, None] + k8[None]
+            blocks.append(full[(16 * t + row)[:, None], cols])
+    for s_ in range(16):
+        cols = (256 + 32 * s_ + 8 * kg)[:, None] + k8[None]
+        blocks.append(full[(32 + row)[:, None], cols])
+    v = torch.stack(blocks, 0)  # [32, 64, 8] fp32
+    hi = v.bfloat16()
+    lo = (v - hi.float()).bfloat16()
+    return torch.stack([hi, lo], 1).contiguous()  # [32, 2, 64, 8]
 
 
 @register
@@ -280,9 +320,12 @@ class RAFT3D(nn.Module):
         mask = weight = zr = None
         for it in range(iters):
             xyz, minfo, corr = ops.raft_geometry_lookup(T, d1, d2, K8, pyr)  # projection + pyramid lookup, one launch
-            net, mask, ae, delta, weight, zr = self.update_block.run(net, inp, corr, minfo, need_mask=it == iters - 1,
-                                                                     zr=zr, prefetch_next=it < iters - 1)
-            ops.se3_gn_step(T, ae, xyz, delta, weight, d1, K8, radius=32)
+            net, mask, ae, delta, weight, zr, hid = self.update_block.run(
+                net, inp, corr, minfo, need_mask=it == iters - 1, zr=zr, prefetch_next=it < iters - 1, fuse_heads=True)
+            if hid is not None:  # split-bf16 path: heads + record packing in one launch
+                weight = ops.se3_gn_step_heads(T, hid, *self.update_block.head_matrix(), xyz, d1, K8, radius=32)
+            else:
+                ops.se3_gn_step(T, ae, xyz, delta, weight, d1, K8, radius=32)
         T_up = ops.cvx_upsample(T, mask, 1)
         outputs["Ts"] = T_up
         # reference raft3d.py:268-270: the induced 2-D flow + inverse-depth change of the up-sampled field

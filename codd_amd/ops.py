@@ -793,6 +793,19 @@ def se3_gn_step(T, ae, xyz, delta, weight, d1, K8, radius=32, lm=1e-4, ep=10.0):
     return T
 
 
+def se3_gn_step_heads(T, hidden_xs, head_w, head_b, xyz, d1, K8, radius=32, lm=1e-4, ep=10.0):
+    """se3_gn_step with the ae / delta / weight 1x1 heads computed inside the record-packing kernel from the hidden
+    channels in split form (``hidden_xs``: 768 channels); returns the confidence weights [B,3,h,w]."""
+    lib = _abi.load()
+    B, h, w, _ = T.shape
+    scratch = _f32(lib.codd_se3_gn_scratch(B, h, w, radius), like=T)
+    wout = _f32(B, 3, h, w, like=T)
+    _abi.check(lib.codd_se3_gn_step_heads(T.data_ptr(), _xs_view(hidden_xs), head_w.data_ptr(), head_b.data_ptr(),
+                                          xyz.data_ptr(), d1.data_ptr(), B, h, w, *K8, radius, lm, ep, wout.data_ptr(),
+                                          scratch.data_ptr(), _stream()), "se3_gn_step_heads")
+    return wout
+
+
 def cvx_upsample(data, mask, mode):
     """mode 0: [B,h,w,D] -> [B,8h,8w,D]; 1: SE3 field [B,h,w,7]; 2: [B,D,h,w] -> [B,D,8h,8w]."""
     lib = _abi.load()

@@ -41,6 +41,15 @@ typedef struct {
   int coff; /* first channel of the view */
 } codd_view;
 
+/* A split-bf16 activation tensor (codd_split_bf16 layout: [b][plane hi|lo][octet][hp][wp][8 bf16], image pixel
+ * (y, x) at (y + bt, x + bl), planes = 2 for terms 3 / 1 for terms 1) as the DESTINATION of a producer kernel: the
+ * producer writes the image interior of channels [8*o8, ...) only; border and padding channels stay as they are
+ * (zero in a persistent buffer). */
+typedef struct codd_xs_view {
+  void* ptr;
+  int c8, hp, wp, bt, bl, o8, terms;
+} codd_xs_view;
+
 /* ---------------------------------------------------------------------------------------------
  * Convolution family (MFMA implicit GEMM).  Three kernel families behind one entry point, selected by `layout`:
  *   0 / 1  v_mfma_f32_16x16x4_f32 (exact fp32 k-ordered fma chain);
@@ -215,6 +224,20 @@ int codd_se3_gn_step(float* T, const float* ae, int ae_c, const float* xyz, cons
                      float fx, float fy, float cx, float cy, int radius, float lm, float ep,
                      float* Hb, void* stream);
 
+/* The same step with the three 1x1 heads of the update block folded into the record packing (raft3d.py:59-61,
+ * 100-104: ae = conv1x1(256->32), delta = conv1x1(256->3), weight = sigmoid(conv1x1(256->3))).
+ * hidden: the 768 post-ReLU hidden channels [ae | delta | weight groups of 256] in split-bf16 form (written by the
+ * fused 3x3 head convolution).  head_w: the 38 x 256 head weights as MFMA A operands,
+ *   [32 blocks][plane hi|lo][lane 0..63][8 bf16]  (64 KB, 16-byte aligned): block t*8+s (t = 0, 1; s = 0..7) holds ae
+ *   rows 16t + lane%16, channels 32s + 8*(lane/16) .. +8; block 16+s (s = 0..15) holds row lane%16 of
+ *   [delta0..2 | weight0..2 | zeros] at hidden channel 256 + 32s + 8*(lane/16) .. +8 (zero where the row's head does
+ *   not read that channel group); hi = bf16_rne(w), lo = bf16_rne(w - hi).  head_b [38] fp32 (ae, delta, weight).
+ * weight_out [B,3,h,w] receives the confidence weights (up-sampled by the caller after the last update). */
+int codd_se3_gn_step_heads(float* T, codd_xs_view hidden, const void* head_w, const float* head_b,
+                           const float* xyz, const float* depth1, int B, int h, int w, float fx, float fy,
+                           float cx, float cy, int radius, float lm, float ep, float* weight_out, float* Hb,
+                           void* stream);
+
 /* Convex 8x up-sampling (se3_field.cvx_upsample, se3_field.py:173-186) of `dim` channels.
  * mode 0: data [B,h,w,dim] -> out [B,8h,8w,dim]             (generic)
  * mode 1: data = SE3 field [B,h,w,7]: out = exp(cvx(log(T)))  (upsample_se3, :189-192)
@@ -269,14 +292,6 @@ int codd_gru_gate_q(const float* t1, const float* t2, const float* inp, const fl
                     const float* mot, const float* zr, const float* h, int B, int hw, float* hout,
                     void* stream);
 
-/* A split-bf16 activation tensor (codd_split_bf16 layout: [b][plane hi|lo][octet][hp][wp][8 bf16], image pixel
- * (y, x) at (y + bt, x + bl), planes = 2 for terms 3 / 1 for terms 1) as the DESTINATION of a producer kernel: the
- * producer writes the image interior of channels [8*o8, ...) only; border and padding channels stay as they are
- * (zero in a persistent buffer). */
-typedef struct codd_xs_view {
-  void* ptr;
-  int c8, hp, wp, bt, bl, o8, terms;
-} codd_xs_view;
 
 /* The same gates, writing what the following convolutions read directly in their input form (no fp32 tensor, no
  * re-layout pass between gate and convolution):

@@ -580,6 +580,37 @@ def test_gru_gates_writing_split_records_equal_gate_plus_relayout():
     assert torch.equal(ops.split_input(h_ref, border=4).buf, hb.buf)
 
 
+def test_gn_step_with_fused_heads_equals_heads_then_step():
+    """codd_se3_gn_step_heads (1x1 heads inside the record packing, hidden channels read in split-bf16 form) against
+    fp32 1x1 convolutions (torch) followed by codd_se3_gn_step."""
+    from codd_amd import ops
+    B, h, w = 1, 20, 44
+    T = _se3_field(B, h, w, 0.03).to(DEV)
+    g = torch.Generator().manual_seed(11)
+    d1 = (torch.rand(B, h, w, generator=g) * 30 + 3).to(DEV)
+    K8 = [40.0, 42.0, w / 2.0, h / 2.0]
+    xyz = (torch.rand(B, h, w, 3, generator=g) * 20).to(DEV)
+    hidden = torch.relu(rnd(B, 768, h, w, seed=12)).to(DEV)
+    Wm = (rnd(38, 256, seed=13) / 16).to(DEV)
+    bm = (rnd(38, seed=14) * 0.1).to(DEV)
+    hs = ops.split_input(hidden, border=0)
+    assert hs is not None, "needs the split / bf16 conv precision (the default)"
+    grp = lambda i: hidden[:, 256 * i:256 * (i + 1)]
+    ae = F.conv2d(grp(0), Wm[:32, :, None, None], bm[:32])
+    delta = F.conv2d(grp(1), Wm[32:35, :, None, None], bm[32:35])
+    weight = torch.sigmoid(F.conv2d(grp(2), Wm[35:38, :, None, None], bm[35:38]))
+    T_ref = T.clone()
+    ops.se3_gn_step(T_ref, ae.contiguous(), xyz, delta.contiguous(), weight.contiguous(), d1, K8, radius=6)
+    T_new = T.clone()
+    from codd_amd.motion import pack_head_matrix
+    w_out = ops.se3_gn_step_heads(T_new, hs, pack_head_matrix(Wm), bm, xyz, d1, K8, radius=6)
+    step = (T_ref - T).abs().max().item()
+    err = (T_new - T_ref).abs().max().item()
+    print("gn step", step, "fused-heads deviation", err, "weight dev", (w_out - weight).abs().max().item())
+    assert (w_out - weight).abs().max().item() < 1e-4
+    assert err < 2e-3 * step
+
+
 def test_full_codd_parity_with_autotuned_launch_configurations():
     """The configurations the tuner picks (quad-layout kernel, 2/8/9-wave workgroups, ...) in the whole pipeline:
     HIP vs oracle on a 3-frame sequence, same bound as the un-tuned parity tests."""

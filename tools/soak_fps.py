@@ -21,3 +21,12 @@ for blk in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"t={time.perf_counter()-t00:6.1f}s  block {blk}: {50/dt:.2f} fps", flush=True)
+# host-side cost of one step (input copies + graph launch), GPU idle at the start of each measurement
+ts = []
+for i in range(20):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    runner.step(img[:, i % 6], r_img[:, i % 6])
+    ts.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+print("host time of step() with an idle GPU: min %.2f ms  median %.2f ms" % (min(ts) * 1e3, sorted(ts)[10] * 1e3))
