@@ -81,6 +81,7 @@ SIGNATURES = {
     "codd_fusion_cues_fr": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p]),
     "codd_disp_metrics": (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p]),
     "codd_raft_geometry_lookup": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p]),
+    "codd_raft_geometry_lookup_xs": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _p, XsView, XsView, _p]),
     "codd_conv2d_packed_size_quad": (C.c_longlong, [_i, _i, _i, _i, _i, _i]),
     "codd_conv2d_pack_weights_quad": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "codd_split_bf16_bytes": (_ll, [_i] * 5),

@@ -134,14 +134,16 @@ struct LookupGeom {  // coords == NULL: the projected coordinates are computed h
   const float *T, *d1, *d2;
   float fx, fy, cx, cy;
   float *xyz, *minfo;
+  codd_xs_view cxs, mxs;  // XS mode: correlation features / motion info written as split-bf16 records instead
 };
 __device__ __forceinline__ V3 inv_project(float depth, int x, int y, float fx, float fy, float cx, float cy);
 __device__ __forceinline__ V3 project(V3 X, float fx, float fy, float cx, float cy);
 __device__ __forceinline__ void raft_geometry_pixel(const float* __restrict__ T, const float* __restrict__ d1,
                                                     const float* __restrict__ d2, int b, int pix, int h, int w,
                                                     float fx, float fy, float cx, float cy, float* __restrict__ xyz,
-                                                    float* __restrict__ minfo);
+                                                    float* __restrict__ minfo, const codd_xs_view* mxs = nullptr);
 
+template <bool XS>
 __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restrict__ l0, const float* __restrict__ l1,
                                                           const float* __restrict__ l2, const float* __restrict__ l3,
                                                           const float* __restrict__ coords, int cstride, int h, int w,
@@ -187,8 +189,25 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
   }
   // fused geometry: the level-0 workgroups also publish xyz and the motion-info channels of their 16 pixels
   if (!coords && lvl == 0 && tid < 16 && n0 + tid < N)
-    raft_geometry_pixel(gm.T, gm.d1, gm.d2, b, n0 + tid, h, w, gm.fx, gm.fy, gm.cx, gm.cy, gm.xyz, gm.minfo);
+    raft_geometry_pixel(gm.T, gm.d1, gm.d2, b, n0 + tid, h, w, gm.fx, gm.fy, gm.cx, gm.cy, gm.xyz, gm.minfo,
+                        XS ? &gm.mxs : nullptr);
   __syncthreads();
+  if (XS) {  // channel c = lvl*49 + ch -> slot c & 7 of record octet c >> 3 (2-byte stores: octets straddle the levels)
+    const codd_xs_view& d = gm.cxs;
+    const size_t per = (size_t)d.c8 * d.hp * d.wp;
+    unsigned short* base = (unsigned short*)d.ptr + (size_t)b * (d.terms == 3 ? 2 : 1) * per * 8;
+    for (int e = tid; e < 49 * 16; e += 256) {
+      const int ch = e >> 4, pi = e & 15, n = n0 + pi;
+      if (n >= N) continue;
+      const int c = lvl * 49 + ch, y = n / w, x = n - y * w;
+      const float v = tile[ch][pi];
+      const __bf16 hi = (__bf16)v;
+      const size_t at = (((size_t)(d.o8 + (c >> 3)) * d.hp + (y + d.bt)) * d.wp + (x + d.bl)) * 8 + (c & 7);
+      base[at] = __builtin_bit_cast(unsigned short, hi);
+      if (d.terms == 3) base[per * 8 + at] = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)hi));
+    }
+    return;
+  }
   for (int e = tid; e < 49 * 16; e += 256) {
     const int ch = e >> 4, pi = e & 15, n = n0 + pi;
     if (n < N) out[((size_t)b * 196 + lvl * 49 + ch) * N + n] = tile[ch][pi];
@@ -201,7 +220,7 @@ extern "C" int codd_corr_lookup(const float* lvl0, const float* lvl1, const floa
   dim3 grid(cdiv(h * w, 16), 4, B);
   LookupGeom gm;
   memset(&gm, 0, sizeof(gm));
-  corr_lookup_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(lvl0, lvl1, lvl2, lvl3, coords, cstride, h, w, out, gm);
+  corr_lookup_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(lvl0, lvl1, lvl2, lvl3, coords, cstride, h, w, out, gm);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }
@@ -211,9 +230,23 @@ extern "C" int codd_raft_geometry_lookup(const float* T, const float* depth1, co
                                          float fx, float fy, float cx, float cy, float* xyz, float* minfo, float* out,
                                          void* stream) {
   if (!T || !depth1 || !depth2 || !lvl0 || !lvl1 || !lvl2 || !lvl3 || !xyz || !minfo || !out) return CODD_EINVAL;
-  LookupGeom gm = {T, depth1, depth2, fx, fy, cx, cy, xyz, minfo};
+  LookupGeom gm = {T, depth1, depth2, fx, fy, cx, cy, xyz, minfo, {}, {}};
   dim3 grid(cdiv(h * w, 16), 4, B);
-  corr_lookup_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(lvl0, lvl1, lvl2, lvl3, nullptr, 0, h, w, out, gm);
+  corr_lookup_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(lvl0, lvl1, lvl2, lvl3, nullptr, 0, h, w, out, gm);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+extern "C" int codd_raft_geometry_lookup_xs(const float* T, const float* depth1, const float* depth2, const float* lvl0,
+                                            const float* lvl1, const float* lvl2, const float* lvl3, int B, int h, int w,
+                                            float fx, float fy, float cx, float cy, float* xyz, codd_xs_view minfo_xs,
+                                            codd_xs_view corr_xs, void* stream) {
+  if (!T || !depth1 || !depth2 || !lvl0 || !lvl1 || !lvl2 || !lvl3 || !xyz || !xs_view_ok(minfo_xs, 9, h, w) ||
+      !xs_view_ok(corr_xs, 196, h, w))
+    return CODD_EINVAL;
+  LookupGeom gm = {T, depth1, depth2, fx, fy, cx, cy, xyz, nullptr, corr_xs, minfo_xs};
+  dim3 grid(cdiv(h * w, 16), 4, B);
+  corr_lookup_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(lvl0, lvl1, lvl2, lvl3, nullptr, 0, h, w, nullptr, gm);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }
@@ -233,7 +266,7 @@ __device__ __forceinline__ V3 project(V3 X, float fx, float fy, float cx, float 
 __device__ __forceinline__ void raft_geometry_pixel(const float* __restrict__ T, const float* __restrict__ d1,
                                                     const float* __restrict__ d2, int b, int pix, int h, int w,
                                                     float fx, float fy, float cx, float cy, float* __restrict__ xyz,
-                                                    float* __restrict__ minfo) {
+                                                    float* __restrict__ minfo, const codd_xs_view* mxs) {
   const int N = h * w, n = b * N + pix, y = pix / w, x = pix - y * w;
   const SE3T Ti = se3_load(T + (size_t)n * 7);
   const V3 X1 = se3_act(Ti, inv_project(d1[n], x, y, fx, fy, cx, cy));
@@ -260,6 +293,15 @@ __device__ __forceinline__ void raft_geometry_pixel(const float* __restrict__ T,
   se3_log(Ti, &tau, &phi);
   const float vals[9] = {p.x - (float)x, p.y - (float)y, 10.f * tau.x, 10.f * tau.y, 10.f * tau.z,
                          10.f * phi.x, 10.f * phi.y, 10.f * phi.z, 10.f * (zinv - p.z)};
+  if (mxs) {  // the 9 channels as split-bf16 records: octet 0 and slot 0 of octet 1 (the other 7 slots stay zero)
+    float v0[8], v1[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { v0[c] = fminf(fmaxf(vals[c], -50.f), 50.f); v1[c] = 0.f; }
+    v1[0] = fminf(fmaxf(vals[8], -50.f), 50.f);
+    xs_store8(*mxs, b, 0, y, x, v0);
+    xs_store8(*mxs, b, 1, y, x, v1);
+    return;
+  }
   float* mp = minfo + (size_t)b * 9 * N + pix;
 #pragma unroll
   for (int c = 0; c < 9; ++c) mp[(size_t)c * N] = fminf(fmaxf(vals[c], -50.f), 50.f);

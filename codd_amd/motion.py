@@ -129,6 +129,14 @@ class BasicUpdateBlock(nn.Module):
             c = self._xs = (t, ops.split_input(t, border=4, out=hb) if hb is not None else None)
         return c[1]
 
+    def input_buffers(self, like):
+        """(corr, minfo) split-bf16 input tensors of the two encoder chains (persistent, zero-bordered; borders 1 and
+        3 for the 3x3 / 7x7 first convolutions) that ops.raft_geometry_lookup writes directly; (None, None) outside the
+        split / bf16 precision modes."""
+        B, _, h, w = like.shape
+        return (ops.split_buffer((id(self), "corr_in"), B, 196, h, w, 1, like.device),
+                ops.split_buffer((id(self), "minfo_in"), B, 9, h, w, 3, like.device))
+
     def _forks(self, dev):
         if getattr(self, "_fk", None) is None or self._fk[0].dev != dev:
             self._fk = (ops.Fork(dev, 3), ops.Fork(dev, 2))
@@ -151,13 +159,15 @@ class BasicUpdateBlock(nn.Module):
         def sb(name, C, border):
             return ops.split_buffer((id(self), name), net.shape[0], C, net.shape[2], net.shape[3], border, net.device)
 
+        cin, min_ = self.input_buffers(net) if corr is None else (None, None)
+
         def corr_chain():
             s0, s2 = sb("corr_enc0", 256, 1), sb("corr_enc2", 256, 0)
             if s0 is None:
                 c = cv(self.corr_enc[0], corr, act="relu")
                 c = cv(self.corr_enc[2], c, act="relu")
                 return cv(self.corr_enc[4], c)
-            cv(self.corr_enc[0], corr, act="relu", xs_out=s0)
+            cv(self.corr_enc[0], corr, act="relu", xs=cin, xs_out=s0)
             cv(self.corr_enc[2], None, act="relu", xs=s0, xs_out=s2)
             return cv(self.corr_enc[4], None, xs=s2)
 
@@ -165,7 +175,7 @@ class BasicUpdateBlock(nn.Module):
             s0 = sb("flow_enc0", 128, 0)
             if s0 is None:
                 return cv(self.flow_enc[2], cv(self.flow_enc[0], minfo, act="relu"))
-            cv(self.flow_enc[0], minfo, act="relu", xs_out=s0)
+            cv(self.flow_enc[0], minfo, act="relu", xs=min_, xs_out=s0)
             return cv(self.flow_enc[2], None, xs=s0)
 
         if zr is None:
@@ -318,8 +328,11 @@ class RAFT3D(nn.Module):
         d1 = depth_prev[:, 3::8, 3::8].contiguous()
         d2 = depth_curr[:, 3::8, 3::8].contiguous()
         mask = weight = zr = None
+        cxs, mxs = self.update_block.input_buffers(net)
         for it in range(iters):
-            xyz, minfo, corr = ops.raft_geometry_lookup(T, d1, d2, K8, pyr)  # projection + pyramid lookup, one launch
+            # projection + pyramid lookup, one launch; in the split-bf16 modes its results are written straight into
+            # the encoder convolutions' input tensors (corr = minfo = None then)
+            xyz, minfo, corr = ops.raft_geometry_lookup(T, d1, d2, K8, pyr, minfo_xs=mxs, corr_xs=cxs)
             net, mask, ae, delta, weight, zr, hid = self.update_block.run(
                 net, inp, corr, minfo, need_mask=it == iters - 1, zr=zr, prefetch_next=it < iters - 1, fuse_heads=True)
             if hid is not None:  # split-bf16 path: heads + record packing in one launch

@@ -770,10 +770,19 @@ def raft_geometry(T, d1, d2, K8):
     return xyz, minfo
 
 
-def raft_geometry_lookup(T, d1, d2, K8, pyr):
-    """raft_geometry + corr_lookup in one launch -> (xyz [B,h,w,3], minfo [B,9,h,w], corr [B,196,h,w])."""
+def raft_geometry_lookup(T, d1, d2, K8, pyr, minfo_xs=None, corr_xs=None):
+    """raft_geometry + corr_lookup in one launch -> (xyz [B,h,w,3], minfo [B,9,h,w], corr [B,196,h,w]).
+    With ``minfo_xs`` / ``corr_xs`` (split_buffer tensors of 9 / 196 channels) the two tensor results are written
+    directly as split-bf16 records -- the encoder convolutions' input form -- and (xyz, None, None) is returned."""
     lib = _abi.load()
     B, h, w, _ = T.shape
+    if corr_xs is not None:
+        xyz = _f32(B, h, w, 3, like=T)
+        _abi.check(lib.codd_raft_geometry_lookup_xs(T.data_ptr(), d1.data_ptr(), d2.data_ptr(), pyr[0].data_ptr(),
+                                                    pyr[1].data_ptr(), pyr[2].data_ptr(), pyr[3].data_ptr(), B, h, w,
+                                                    *K8, xyz.data_ptr(), _xs_view(minfo_xs), _xs_view(corr_xs),
+                                                    _stream()), "raft_geometry_lookup_xs")
+        return xyz, None, None
     xyz, minfo, out = _f32(B, h, w, 3, like=T), _f32(B, 9, h, w, like=T), _f32(B, 196, h, w, like=T)
     _abi.check(lib.codd_raft_geometry_lookup(T.data_ptr(), d1.data_ptr(), d2.data_ptr(), pyr[0].data_ptr(),
                                              pyr[1].data_ptr(), pyr[2].data_ptr(), pyr[3].data_ptr(), B, h, w, *K8,

@@ -379,6 +379,12 @@ int codd_raft_geometry_lookup(const float* T, const float* depth1, const float* 
                               const float* lvl1, const float* lvl2, const float* lvl3, int B, int h, int w,
                               float fx, float fy, float cx, float cy, float* xyz, float* minfo, float* out,
                               void* stream);
+/* The same launch writing its two tensor results -- the 9 motion-info channels and the 196 correlation features --
+ * directly as split-bf16 records (the inputs of the flow / correlation encoder convolutions); xyz stays fp32. */
+int codd_raft_geometry_lookup_xs(const float* T, const float* depth1, const float* depth2, const float* lvl0,
+                                 const float* lvl1, const float* lvl2, const float* lvl3, int B, int h, int w,
+                                 float fx, float fy, float cx, float cy, float* xyz, codd_xs_view minfo_xs,
+                                 codd_xs_view corr_xs, void* stream);
 
 int codd_abi_version(void);
 

@@ -611,6 +611,27 @@ def test_gn_step_with_fused_heads_equals_heads_then_step():
     assert err < 2e-3 * step
 
 
+def test_geometry_lookup_writing_split_records_equals_lookup_plus_relayout():
+    from codd_amd import ops
+    h, w = 24, 40
+    T = ops.se3_identity(1, h, w, DEV)
+    T[..., :3] = rnd(1, h, w, 3, seed=3).to(DEV) * 0.05
+    q = rnd(1, h, w, 4, seed=4).to(DEV) * 0.05
+    q[..., 3] = 1.0
+    T[..., 3:] = q / q.norm(dim=-1, keepdim=True)
+    d1 = (rnd(1, h, w, seed=5).abs() * 5 + 2).to(DEV)
+    d2 = (rnd(1, h, w, seed=6).abs() * 5 + 2).to(DEV)
+    pyr = ops.allpairs_corr(rnd(1, 128, h, w, seed=7).to(DEV), rnd(1, 128, h, w, seed=8).to(DEV))
+    K8 = [30.0, 32.0, 20.0, 12.0]
+    xyz, minfo, corr = ops.raft_geometry_lookup(T, d1, d2, K8, pyr)
+    cxs = ops.split_buffer(("test", "corr_in"), 1, 196, h, w, 1, DEV)
+    mxs = ops.split_buffer(("test", "minfo_in"), 1, 9, h, w, 3, DEV)
+    xyz2, m2, c2 = ops.raft_geometry_lookup(T, d1, d2, K8, pyr, minfo_xs=mxs, corr_xs=cxs)
+    assert m2 is None and c2 is None and torch.equal(xyz, xyz2)
+    assert torch.equal(ops.split_input(corr, border=1).buf, cxs.buf)
+    assert torch.equal(ops.split_input(minfo, border=3).buf, mxs.buf)
+
+
 def test_full_codd_parity_with_autotuned_launch_configurations():
     """The configurations the tuner picks (quad-layout kernel, 2/8/9-wave workgroups, ...) in the whole pipeline:
     HIP vs oracle on a 3-frame sequence, same bound as the un-tuned parity tests."""
