@@ -73,6 +73,7 @@ SIGNATURES = {
     "codd_splat_scratch": (_ll, [_i, _i, _i, _f]),
     "codd_resize_bilinear": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p]),
     "codd_add_relu": (_i, [_p, _p, _ll, _i, _p, _p]),
+    "codd_copy_many": (_i, [_p, _p, _p, _i, _p]),
     "codd_gru_gate_zr": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "codd_gru_gate_q": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p]),
     "codd_gru_gate_zr_xs": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, XsView, _p]),

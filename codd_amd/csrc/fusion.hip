@@ -8,34 +8,41 @@
 //   25..27 cost_curr(k=-1,0,1) = sum_c |fea_l - warp(fea_r, pc/4 + k)|,  28..30 cost_warp
 // and the sub-sampled disparities pc, pw (pred[.., 1::4, 1::4]).
 // ------------------------------------------------------------------------------------------------
-__global__ void fusion_cues_lr_kernel(const float* __restrict__ pred_curr, const float* __restrict__ pred_warp,
-                                      const float* __restrict__ feat_curr, const float* __restrict__ feat_warp,
-                                      const float* __restrict__ fea_l, const float* __restrict__ fea_r, int H, int W,
-                                      int CF, int CS, float* __restrict__ corr, float* __restrict__ dsub, int dsub_ctot,
-                                      int dsub_coff) {
+#define CUES_NS 8  // channel slices (waves) per 64-pixel group
+__global__ __launch_bounds__(64 * CUES_NS) void fusion_cues_lr_kernel(
+    const float* __restrict__ pred_curr, const float* __restrict__ pred_warp, const float* __restrict__ feat_curr,
+    const float* __restrict__ feat_warp, const float* __restrict__ fea_l, const float* __restrict__ fea_r, int H, int W,
+    int CF, int CS, float* __restrict__ corr, float* __restrict__ dsub, int dsub_ctot, int dsub_coff) {
+  // One thread per low-res pixel would be 540 waves at 960x576, each walking CF + CS channels of dependent gathers
+  // (104 us, latency bound): the channels are dealt over CUES_NS waves per pixel group instead and the 33 partial
+  // sums combined through LDS in slice order.
+  __shared__ float red[CUES_NS][33][64];
   const int h = H / 4, w = W / 4, N = h * w;
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
-  if (x >= w) return;
-  const int pix = y * w + x;
-  const size_t fr_idx = (size_t)b * H * W + (size_t)(4 * y + 1) * W + (4 * x + 1);
+  const int lane = threadIdx.x, slice = threadIdx.y;
+  const int x = blockIdx.x * 64 + lane, y = blockIdx.y, b = blockIdx.z;
+  const bool ok = x < w;
+  const int xc = ok ? x : w - 1;
+  const int pix = y * w + xc;
+  const size_t fr_idx = (size_t)b * H * W + (size_t)(4 * y + 1) * W + (4 * xc + 1);
   const float pc = pred_curr[fr_idx], pw = pred_warp[fr_idx];
-  dsub[((size_t)b * dsub_ctot + dsub_coff) * N + pix] = pc;
-  dsub[((size_t)b * dsub_ctot + dsub_coff + 1) * N + pix] = pw;
-
-  float* out = corr + (size_t)b * 31 * N + pix;
+  float acc[33];
+#pragma unroll
+  for (int k = 0; k < 33; ++k) acc[k] = 0.f;
   // stereo matching costs: 4 taps serve the three offsets (xs_k = xs_0 - k)
   const float disp[2] = {pc * 0.25f, pw * 0.25f};
   const float* flb = fea_l + (size_t)b * CS * N + pix;
   const float* frb = fea_r + (size_t)b * CS * N + (size_t)y * w;
+  float xsv[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const float xs = (float)x - disp[s];
+    const float xs = (float)xc - disp[s];
+    xsv[s] = xs;
     float f0 = floorf(xs);
     const float a = xs - f0;
     f0 = fminf(fmaxf(f0, -4.f), (float)w + 4.f);
     const int i0 = (int)f0;
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-    for (int c = 0; c < CS; ++c) {
+    for (int c = slice; c < CS; c += CUES_NS) {
       const float lv = flb[(size_t)c * N];
       const float* rr = frb + (size_t)c * N;
       float t[4];
@@ -46,40 +53,48 @@ __global__ void fusion_cues_lr_kernel(const float* __restrict__ pred_curr, const
       c1 += fabsf(lv - (w0 * t[1] + w1 * t[2]));  // k = 0
       c2 += fabsf(lv - (w0 * t[0] + w1 * t[1]));  // k = +1
     }
-    const float sc = 1.f / ((float)CS / 24.f);
-    if (xs != xs) { c0 = c1 = c2 = xs; }
-    out[(size_t)(25 + 3 * s) * N] = c0 * sc;
-    out[(size_t)(26 + 3 * s) * N] = c1 * sc;
-    out[(size_t)(27 + 3 * s) * N] = c2 * sc;
+    acc[27 + 3 * s] = c0; acc[28 + 3 * s] = c1; acc[29 + 3 * s] = c2;
   }
-  // pixel-to-patch feature correlations, 3x3 taps with dilation 2, zero padding
-  float cross[9], selfc[9], selfw[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) cross[k] = selfc[k] = selfw[k] = 0.f;
+  // pixel-to-patch feature correlations, 3x3 taps with dilation 2, zero padding: acc[0..8] cross, [9..17] self(curr),
+  // [18..26] self(warp)
   const float* fc = feat_curr + (size_t)b * CF * N;
   const float* fw = feat_warp + (size_t)b * CF * N;
-  for (int c = 0; c < CF; ++c) {
+  for (int c = slice; c < CF; c += CUES_NS) {
     const float kc = fc[(size_t)c * N + pix], kw_ = fw[(size_t)c * N + pix];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-      const int yy = y + 2 * (k / 3 - 1), xx = x + 2 * (k % 3 - 1);
+      const int yy = y + 2 * (k / 3 - 1), xx = xc + 2 * (k % 3 - 1);
       if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) {
         const float mc = fc[(size_t)c * N + yy * w + xx], mw = fw[(size_t)c * N + yy * w + xx];
-        cross[k] += kc * mw;
-        selfc[k] += kc * mc;
-        selfw[k] += kw_ * mw;
+        acc[k] += kc * mw;
+        acc[9 + k] += kc * mc;
+        acc[18 + k] += kw_ * mw;
       }
     }
   }
-  const float nrm = 1.f / sqrtf((float)CF);
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    out[(size_t)k * N] = cross[k] * nrm;
-    if (k != 4) {
-      const int kk = k < 4 ? k : k - 1;
-      out[(size_t)(9 + kk) * N] = selfc[k] * nrm;
-      out[(size_t)(17 + kk) * N] = selfw[k] * nrm;
+  for (int k = 0; k < 33; ++k) red[slice][k][lane] = acc[k];
+  __syncthreads();
+  if (!ok) return;
+  // every wave finalises its share of the 33 sums (slice order: deterministic)
+  float* out = corr + (size_t)b * 31 * N + pix;
+  const float nrm = 1.f / sqrtf((float)CF), sc = 1.f / ((float)CS / 24.f);
+  for (int k = slice; k < 33; k += CUES_NS) {
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < CUES_NS; ++q) v += red[q][k][lane];
+    if (k < 9) out[(size_t)k * N] = v * nrm;
+    else if (k < 18) { if (k != 13) out[(size_t)(9 + (k - 9 < 4 ? k - 9 : k - 10)) * N] = v * nrm; }
+    else if (k < 27) { if (k != 22) out[(size_t)(17 + (k - 18 < 4 ? k - 18 : k - 19)) * N] = v * nrm; }
+    else {
+      const int s_ = (k - 27) / 3;
+      const float xs = xsv[s_];
+      out[(size_t)(25 + (k - 27)) * N] = (xs != xs) ? xs : v * sc;
     }
+  }
+  if (slice == 0) {
+    dsub[((size_t)b * dsub_ctot + dsub_coff) * N + pix] = pc;
+    dsub[((size_t)b * dsub_ctot + dsub_coff + 1) * N + pix] = pw;
   }
 }
 
@@ -90,8 +105,9 @@ extern "C" int codd_fusion_cues_lr(const float* pred_curr, const float* pred_war
   if (!pred_curr || !pred_warp || !feat_curr || !feat_warp || !fea_l || !fea_r || !corr_feat || !dsub) return CODD_EINVAL;
   if ((H & 3) || (W & 3)) return CODD_EINVAL;
   dim3 grid(cdiv(W / 4, 64), H / 4, B);
-  fusion_cues_lr_kernel<<<grid, 64, 0, (hipStream_t)stream>>>(pred_curr, pred_warp, feat_curr, feat_warp, fea_l, fea_r, H,
-                                                             W, CF, CS, corr_feat, dsub, dsub_ctot, dsub_coff);
+  fusion_cues_lr_kernel<<<grid, dim3(64, CUES_NS), 0, (hipStream_t)stream>>>(pred_curr, pred_warp, feat_curr, feat_warp,
+                                                                           fea_l, fea_r, H, W, CF, CS, corr_feat, dsub,
+                                                                           dsub_ctot, dsub_coff);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }

@@ -1193,6 +1193,44 @@ extern "C" int codd_add_relu(const float* a, const float* b, long long n, int re
   return CODD_OK;
 }
 
+// Up to 8 tensor copies in one launch (the recurrent-state write-back at the end of the captured frame: five
+// dependent 8-us launches otherwise).  Element counts and addresses must be multiples of 4 floats / 16 bytes.
+struct CopyMany {
+  const float4* src[8];
+  float4* dst[8];
+  long long end[8];  // exclusive prefix ends, in float4 units
+  int count;
+};
+__global__ void copy_many_kernel(const CopyMany c) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= c.end[c.count - 1]) return;
+  int k = 0;
+  long long base = 0;
+#pragma unroll
+  for (int q = 0; q < 7; ++q)
+    if (q < c.count - 1 && e >= c.end[q]) { k = q + 1; base = c.end[q]; }
+  c.dst[k][e - base] = c.src[k][e - base];
+}
+extern "C" int codd_copy_many(const float* const* src, float* const* dst, const long long* n, int count, void* stream) {
+  if (!src || !dst || !n || count < 1 || count > 8) return CODD_EINVAL;
+  CopyMany c;
+  long long tot = 0;
+  for (int k = 0; k < count; ++k) {
+    if (!src[k] || !dst[k] || n[k] < 0 || (n[k] & 3) || ((uintptr_t)src[k] & 15) || ((uintptr_t)dst[k] & 15))
+      return CODD_EINVAL;
+    c.src[k] = (const float4*)src[k];
+    c.dst[k] = (float4*)dst[k];
+    tot += n[k] / 4;
+    c.end[k] = tot;
+  }
+  for (int k = count; k < 8; ++k) { c.src[k] = nullptr; c.dst[k] = nullptr; c.end[k] = tot; }
+  c.count = count;
+  if (tot == 0) return CODD_OK;
+  copy_many_kernel<<<cdiv(tot, 256), 256, 0, (hipStream_t)stream>>>(c);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // ConvGRU gate fusions (reference blocks/gru.py:17-34).  The six gate convolutions run as
 // independent launches (concurrently, on forked streams); these two kernels apply

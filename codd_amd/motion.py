@@ -9,6 +9,8 @@ Per-iteration schedule (16x per frame): geometry -> pyramid lookup -> flow/corr 
 ConvGRU (z|r as one 256-channel conv pair, q) -> one 1024-channel head conv + four 1x1 heads ->
 Gauss-Newton step.  Attribute names equal the reference's, so checkpoints load by key.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -199,7 +201,7 @@ class BasicUpdateBlock(nn.Module):
             fk.join()
             net = ops.gru_gate_q_xs(q1, q2, inp, cor, mot, z, net, hb)
             self._xs = (net, hb)
-        zr_next = self.zr_convs(net) if prefetch_next else None
+        zr_next = None
         # the four 3x3 head convs share their input: one 768/1024-channel conv; the mask head (576
         # up-sampling weights) is only consumed after the last iteration (raft3d.py:267-273)
         heads = (self.ae[0], self.delta[0], self.weight[0]) + ((self.mask[0],) if need_mask else ())
@@ -210,6 +212,11 @@ class BasicUpdateBlock(nn.Module):
         else:  # the 768 / 1024 hidden channels only ever exist as the four 1x1 heads' split-form input
             ops.conv2d(net, packed_cat(heads), pad=1, act="relu", xs=self._split(net), xs_out=hs)
             sl = lambda i: None
+        if prefetch_next:
+            # forked AFTER the head convolution is enqueued: the side streams wait for it, so the next update's z|r
+            # convolutions (MFMA + LDS) run beside the Gauss-Newton builder (VALU only, 27 KB LDS: both fit a CU)
+            # instead of sharing the matrix pipes with the head convolution
+            zr_next = self.zr_convs(net)
         if hs is not None and fuse_heads:
             # the ae / delta / weight 1x1 heads run inside the Gauss-Newton record packing (ops.se3_gn_step_heads)
             mask = cv(self.mask[2], None, xs=hs, xs_coff=768) if need_mask else None
@@ -380,10 +387,16 @@ class Motion(nn.Module):
         self.raft3d(img_curr, depth_prev, depth_curr, intr, state, outputs, iters=self.iters, train_mode=train_mode)
         T_up = outputs["Ts"]
         B, H, W = depth_prev.shape
-        # full-resolution warp of [img_prev | induced flow | confidence]; depth -> disparity fused
-        warped, disp_warp = ops.splat(T_up, depth_prev, img_prev, outputs["weight"], True, H, W, 0, 0, 1, K, 2.0, bf=bf)
-        # 1/ds-resolution feature warp with T, depth sampled at [o::ds, o::ds] and K / ds
+        # 1/ds-resolution feature warp with T, depth sampled at [o::ds, o::ds] and K / ds -- independent of the
+        # full-resolution warp below: forked onto a side stream (two ~95-us launch chains side by side)
         ds, o = self.ds_scale, self.ds_scale // 2 - 1
         Kd = [float(v / np.float32(ds)) for v in intr]
-        feat_warp, _ = ops.splat(T_up, depth_prev, feat_prev, None, False, H // ds, W // ds, o, o, ds, Kd, 4.0)
+        fk = self.__dict__.get("_fk")
+        if fk is None or fk.dev != T_up.device:
+            fk = self.__dict__["_fk"] = ops.Fork(T_up.device, 1)
+        feat_warp, _ = fk.run(0, lambda: ops.splat(T_up, depth_prev, feat_prev, None, False, H // ds, W // ds, o, o, ds,
+                                                   Kd, 4.0))
+        # full-resolution warp of [img_prev | induced flow | confidence]; depth -> disparity fused
+        warped, disp_warp = ops.splat(T_up, depth_prev, img_prev, outputs["weight"], True, H, W, 0, 0, 1, K, 2.0, bf=bf)
+        fk.join()
         state["memory"] = [warped[:, :3], feat_warp, warped[:, 6:], disp_warp, warped[:, 3:6]]

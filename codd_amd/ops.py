@@ -902,6 +902,28 @@ def add_relu(a, b=None, relu=True, out=None):
     return out
 
 
+def copy_many(pairs):
+    """dst.copy_(src) for up to 8 (dst, src) pairs of contiguous fp32 tensors in one kernel launch (a kernel node under
+    graph capture: see runtime.FrameRunner._capture); pairs that do not meet the 16-byte rules fall back to one
+    launch each."""
+    import ctypes as C
+    lib = _abi.load()
+    fast = []
+    for d, s in pairs:
+        assert d.numel() == s.numel() and d.is_contiguous() and s.is_contiguous()
+        if s.numel() % 4 == 0 and s.data_ptr() % 16 == 0 and d.data_ptr() % 16 == 0:
+            fast.append((d, s))
+        else:
+            add_relu(s, None, relu=False, out=d)
+    for i in range(0, len(fast), 8):
+        chunk = fast[i:i + 8]
+        n = len(chunk)
+        srcs = (C.c_void_p * n)(*[s.data_ptr() for _, s in chunk])
+        dsts = (C.c_void_p * n)(*[d.data_ptr() for d, _ in chunk])
+        cnt = (C.c_longlong * n)(*[s.numel() for _, s in chunk])
+        _abi.check(lib.codd_copy_many(srcs, dsts, cnt, n, _stream()), "copy_many")
+
+
 def gru_gate_zr(t1, t2, inp, cor, mot, h):
     lib = _abi.load()
     B, _, hh, ww = h.shape

@@ -67,8 +67,7 @@ class FrameRunner:
             # memcpy/memset graph nodes, and on ROCm 7.2 a captured hipMemsetAsync node was observed
             # to race with the neighbouring kernel nodes (GPU page faults after ~45 replays when
             # eager work ran between replays).  Only kernel nodes are used inside the frame graph.
-            for dst, src in zip(s, self._state_tensors(state)):
-                ops.add_relu(src.contiguous(), None, relu=False, out=dst)
+            ops.copy_many([(dst, src.contiguous()) for dst, src in zip(s, self._state_tensors(state))])
             return out["pred_disp"]
 
         saved = [t.clone() for t in st["state"]]

@@ -282,6 +282,10 @@ int codd_resize_bilinear(const float* in, int B, int C, int Hi, int Wi, int Ho, 
 /* y = relu?(a + b) elementwise (HRNet fuse sums), n floats. */
 int codd_add_relu(const float* a, const float* b, long long n, int relu, float* y, void* stream);
 
+/* dst[k][0..n[k]) = src[k][0..n[k]) for k < count <= 8 in ONE launch (the recurrent-state write-back at the end of a
+ * captured frame); every n[k] a multiple of 4, every pointer 16-byte aligned. */
+int codd_copy_many(const float* const* src, float* const* dst, const long long* n, int count, void* stream);
+
 /* ConvGRU gate fusions (blocks/gru.py:17-34).  t1, t2: the two gate convolutions of a gate pair
  * (3x3 and dilated 3x3, bias included); inp / cor / mot [B,384,hw]: the three input streams.
  *   zr [B,256,hw] = sigmoid(t1 + t2 + (inp+cor+mot)[:, :256]);  rh [B,128,hw] = r * h
