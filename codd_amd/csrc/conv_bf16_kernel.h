@@ -508,7 +508,12 @@ __global__ __launch_bounds__((PGW * CGW + CONVB_NWP) * 64) void conv_bf16_kernel
 #define CONVB_GROUP_C(X) X(4, 1, 4, 2)
 #define CONVB_GROUP_D(X) X(4, 1, 4, 1) X(4, 1, 8, 1)
 #define CONVB_GROUP_E(X) X(4, 1, 2, 2) X(4, 1, 2, 1)
-#define CONVB_ALL(X) CONVB_GROUP_A(X) CONVB_GROUP_B(X) CONVB_GROUP_C(X) CONVB_GROUP_D(X) CONVB_GROUP_E(X)
+//   (4,1,3,4) / (4,1,3,2): 12-unit tiles (12 x 16 or 6 x 32 px) x 64 / 32 channels: 192 workgroups = ONE dispatch
+//   round on a 72x120 map with 256 / 128 output channels (the 16-unit tiles give 136-160, the 10-unit ones 216-256
+//   with a worse LDS-read : MFMA ratio)
+#define CONVB_GROUP_F(X) X(4, 1, 3, 4) X(4, 1, 3, 2)
+#define CONVB_ALL(X) \
+  CONVB_GROUP_A(X) CONVB_GROUP_B(X) CONVB_GROUP_C(X) CONVB_GROUP_D(X) CONVB_GROUP_E(X) CONVB_GROUP_F(X)
 #define CONVB_DECLARE(PGW, CGW, A, B)                                                        \
   extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, 0>(const ConvB);      \
   extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 0>(const ConvB);      \

@@ -229,8 +229,9 @@ class stage:
 
 
 # split-bf16 kernel instantiations (conv_bf16_kernel.h): (pgw, cgw, A, B) and the tiles (rows, units per row) tried
-_B_INST = ((2, 2, 5, 2), (4, 1, 4, 4), (4, 1, 4, 2), (4, 1, 4, 1), (4, 1, 8, 1), (4, 1, 2, 2), (4, 1, 2, 1))
-_B_TILES = {5: ((9, 1), (10, 1), (5, 2)), 4: ((8, 2), (16, 1)), 8: ((16, 2),), 2: ((4, 2), (8, 1))}
+_B_INST = ((2, 2, 5, 2), (4, 1, 4, 4), (4, 1, 4, 2), (4, 1, 4, 1), (4, 1, 8, 1), (4, 1, 2, 2), (4, 1, 2, 1),
+           (4, 1, 3, 4), (4, 1, 3, 2))
+_B_TILES = {5: ((9, 1), (10, 1), (5, 2)), 4: ((8, 2), (16, 1)), 8: ((16, 2),), 2: ((4, 2), (8, 1)), 3: ((12, 1), (6, 2))}
 
 
 def _bf16_candidates(pc, Hout, Wout, B, taps, terms):
