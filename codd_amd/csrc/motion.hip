@@ -143,22 +143,28 @@ __device__ __forceinline__ void raft_geometry_pixel(const float* __restrict__ T,
                                                     float fx, float fy, float cx, float cy, float* __restrict__ xyz,
                                                     float* __restrict__ minfo, const codd_xs_view* mxs = nullptr);
 
+// pixels per wave of the lookup: each pixel is a chain of dependent gathers (project -> 4 corner loads -> blend), so
+// fewer pixels per wave would mean shorter chains and more workgroups -- measured: 1 per wave 18.6 us, 4 per wave 17.6 us
+#ifndef LOOKUP_PPW
+#define LOOKUP_PPW 4
+#endif
 template <bool XS>
 __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restrict__ l0, const float* __restrict__ l1,
                                                           const float* __restrict__ l2, const float* __restrict__ l3,
                                                           const float* __restrict__ coords, int cstride, int h, int w,
                                                           float* __restrict__ out, const LookupGeom gm) {
-  __shared__ float tile[49][17];
+  constexpr int PPW = LOOKUP_PPW, NPX = 4 * PPW;  // pixels per wave / per workgroup
+  __shared__ float tile[49][NPX + 1];
   const int lvl = blockIdx.y, b = blockIdx.z;
   const int N = h * w;
-  const int n0 = blockIdx.x * 16;
+  const int n0 = blockIdx.x * NPX;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h2 = h >> lvl, w2 = w >> lvl;
   const float* vol = (lvl == 0 ? l0 : lvl == 1 ? l1 : lvl == 2 ? l2 : l3) + (size_t)b * N * h2 * w2;
   const float inv = 1.f / (float)(1 << lvl);
   const int tx = lane & 7, ty = lane >> 3;
-  for (int q = 0; q < 4; ++q) {
-    const int pi = wave * 4 + q, n = n0 + pi;
+  for (int q = 0; q < PPW; ++q) {
+    const int pi = wave * PPW + q, n = n0 + pi;
     if (n >= N) break;
     float px, py;
     if (coords) {
@@ -187,20 +193,32 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
       tile[tx * 7 + ty][pi] = r;  // channel = i*7 + j, i = x offset, j = y offset
     }
   }
-  // fused geometry: the level-0 workgroups also publish xyz and the motion-info channels of their 16 pixels
-  if (!coords && lvl == 0 && tid < 16 && n0 + tid < N)
+  // fused geometry: the level-0 workgroups also publish xyz and the motion-info channels of their pixels
+  if (!coords && lvl == 0 && tid < NPX && n0 + tid < N)
     raft_geometry_pixel(gm.T, gm.d1, gm.d2, b, n0 + tid, h, w, gm.fx, gm.fy, gm.cx, gm.cy, gm.xyz, gm.minfo,
                         XS ? &gm.mxs : nullptr);
   __syncthreads();
-  if (XS) {  // channel c = lvl*49 + ch -> slot c & 7 of record octet c >> 3 (2-byte stores: octets straddle the levels)
+  if (XS) {  // channel c = lvl*49 + ch -> slot c & 7 of record octet c >> 3
     const codd_xs_view& d = gm.cxs;
+    const int c0 = lvl * 49, c1 = c0 + 49;
+    const int of = (c0 + 7) >> 3, ol = c1 >> 3;  // octets [of, ol) lie inside this level: whole 16-byte records
+    for (int e = tid; e < (ol - of) * NPX; e += 256) {
+      const int o = of + e / NPX, pi = e % NPX, n = n0 + pi;
+      if (n >= N) continue;
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = tile[o * 8 + i - c0][pi];
+      xs_store8(d, b, o, n / w, n % w, v);
+    }
+    // the octets shared with the neighbouring levels: 2-byte stores of this level's slots
     const size_t per = (size_t)d.c8 * d.hp * d.wp;
     unsigned short* base = (unsigned short*)d.ptr + (size_t)b * (d.terms == 3 ? 2 : 1) * per * 8;
-    for (int e = tid; e < 49 * 16; e += 256) {
-      const int ch = e >> 4, pi = e & 15, n = n0 + pi;
+    const int nhead = of * 8 - c0, ntail = c1 - ol * 8;
+    for (int e = tid; e < (nhead + ntail) * NPX; e += 256) {
+      const int q = e / NPX, pi = e % NPX, n = n0 + pi;
       if (n >= N) continue;
-      const int c = lvl * 49 + ch, y = n / w, x = n - y * w;
-      const float v = tile[ch][pi];
+      const int c = q < nhead ? c0 + q : ol * 8 + (q - nhead), y = n / w, x = n - y * w;
+      const float v = tile[c - c0][pi];
       const __bf16 hi = (__bf16)v;
       const size_t at = (((size_t)(d.o8 + (c >> 3)) * d.hp + (y + d.bt)) * d.wp + (x + d.bl)) * 8 + (c & 7);
       base[at] = __builtin_bit_cast(unsigned short, hi);
@@ -208,8 +226,8 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
     }
     return;
   }
-  for (int e = tid; e < 49 * 16; e += 256) {
-    const int ch = e >> 4, pi = e & 15, n = n0 + pi;
+  for (int e = tid; e < 49 * NPX; e += 256) {
+    const int ch = e / NPX, pi = e % NPX, n = n0 + pi;
     if (n < N) out[((size_t)b * 196 + lvl * 49 + ch) * N + n] = tile[ch][pi];
   }
 }
@@ -217,7 +235,7 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
 extern "C" int codd_corr_lookup(const float* lvl0, const float* lvl1, const float* lvl2, const float* lvl3,
                                 const float* coords, int cstride, int B, int h, int w, float* out, void* stream) {
   if (!lvl0 || !lvl1 || !lvl2 || !lvl3 || !coords || !out || cstride < 2) return CODD_EINVAL;
-  dim3 grid(cdiv(h * w, 16), 4, B);
+  dim3 grid(cdiv(h * w, 4 * LOOKUP_PPW), 4, B);
   LookupGeom gm;
   memset(&gm, 0, sizeof(gm));
   corr_lookup_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(lvl0, lvl1, lvl2, lvl3, coords, cstride, h, w, out, gm);
@@ -231,7 +249,7 @@ extern "C" int codd_raft_geometry_lookup(const float* T, const float* depth1, co
                                          void* stream) {
   if (!T || !depth1 || !depth2 || !lvl0 || !lvl1 || !lvl2 || !lvl3 || !xyz || !minfo || !out) return CODD_EINVAL;
   LookupGeom gm = {T, depth1, depth2, fx, fy, cx, cy, xyz, minfo, {}, {}};
-  dim3 grid(cdiv(h * w, 16), 4, B);
+  dim3 grid(cdiv(h * w, 4 * LOOKUP_PPW), 4, B);
   corr_lookup_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(lvl0, lvl1, lvl2, lvl3, nullptr, 0, h, w, out, gm);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
@@ -245,7 +263,7 @@ extern "C" int codd_raft_geometry_lookup_xs(const float* T, const float* depth1,
       !xs_view_ok(corr_xs, 196, h, w))
     return CODD_EINVAL;
   LookupGeom gm = {T, depth1, depth2, fx, fy, cx, cy, xyz, nullptr, corr_xs, minfo_xs};
-  dim3 grid(cdiv(h * w, 16), 4, B);
+  dim3 grid(cdiv(h * w, 4 * LOOKUP_PPW), 4, B);
   corr_lookup_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(lvl0, lvl1, lvl2, lvl3, nullptr, 0, h, w, nullptr, gm);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
@@ -771,9 +789,12 @@ template <int MODE, int DIM>
 __global__ __launch_bounds__(256) void cvx_upsample_kernel(const float* __restrict__ data,
                                                            const float* __restrict__ mask, int h, int w,
                                                            float* __restrict__ out) {
+  // workgroup = 64 coarse pixels of one row x a quarter of the 64 sub-pixels (4 per wave): 4x the workgroups of a
+  // one-row-segment-per-workgroup grid (144 at 72x120: 39 us for the 19.9 MB mask), the 9 neighbours' data (for the
+  // SE3 mode their logarithms) are recomputed per quarter
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int wave = threadIdx.x >> 6;
-  const int y = blockIdx.y, b = blockIdx.z;
+  const int wave = (threadIdx.x >> 6) + 4 * (blockIdx.z & 3);
+  const int y = blockIdx.y, b = blockIdx.z >> 2;
   if (x >= w) return;
   const int N = h * w;
   constexpr int D = (MODE == 1) ? 6 : DIM;
@@ -796,7 +817,7 @@ __global__ __launch_bounds__(256) void cvx_upsample_kernel(const float* __restri
   }
   const float* mb = mask + (size_t)b * 576 * N + (size_t)y * w + x;
   const int H8 = 8 * h, W8 = 8 * w;
-  for (int s = wave * 16; s < wave * 16 + 16; ++s) {
+  for (int s = wave * 4; s < wave * 4 + 4; ++s) {
     float m[9], mx = -INFINITY;
 #pragma unroll
     for (int k = 0; k < 9; ++k) { m[k] = mb[(size_t)(k * 64 + s) * N]; mx = fmaxf(mx, m[k]); }
@@ -829,7 +850,7 @@ __global__ __launch_bounds__(256) void cvx_upsample_kernel(const float* __restri
 extern "C" int codd_cvx_upsample(const float* data, const float* mask, int B, int h, int w, int dim, int mode,
                                  float* out, void* stream) {
   if (!data || !mask || !out) return CODD_EINVAL;
-  dim3 grid(cdiv(w, 64), h, B);
+  dim3 grid(cdiv(w, 64), h, 4 * B);
   hipStream_t s = (hipStream_t)stream;
   if (mode == 1) cvx_upsample_kernel<1, 6><<<grid, 256, 0, s>>>(data, mask, h, w, out);
   else if (mode == 0 && dim == 6) cvx_upsample_kernel<0, 6><<<grid, 256, 0, s>>>(data, mask, h, w, out);
