@@ -8,28 +8,36 @@
 //   25..27 cost_curr(k=-1,0,1) = sum_c |fea_l - warp(fea_r, pc/4 + k)|,  28..30 cost_warp
 // and the sub-sampled disparities pc, pw (pred[.., 1::4, 1::4]).
 // ------------------------------------------------------------------------------------------------
-#define CUES_NS 8  // channel slices (waves) per 64-pixel group
-__global__ __launch_bounds__(64 * CUES_NS) void fusion_cues_lr_kernel(
+// channel slices (waves) per 64-pixel group: 8, or 4 when the 3 P^2 + 6 partial sums of 8 slices would not fit the LDS
+#define CUES_NS (P >= 5 ? 4 : 8)
+// P = corr_cfg.patch_size (nn.Unfold(kernel P, padding P-1, dilation 2): tap (ky, kx) looks at (y + 2ky - (P-1),
+// x + 2kx - (P-1)); the self correlations drop tap P*P/2); ds = Fusion.ds_scale.  Channels of corr_feat:
+//   [0, P2) cross | [P2, 2P2-1) self(curr) | [2P2-1, 3P2-2) self(warp) | 3 cost_curr | 3 cost_warp      (P2 = P*P)
+template <int P>
+__global__ __launch_bounds__(512) void fusion_cues_lr_kernel(
     const float* __restrict__ pred_curr, const float* __restrict__ pred_warp, const float* __restrict__ feat_curr,
     const float* __restrict__ feat_warp, const float* __restrict__ fea_l, const float* __restrict__ fea_r, int H, int W,
-    int CF, int CS, float* __restrict__ corr, float* __restrict__ dsub, int dsub_ctot, int dsub_coff) {
+    int ds, int CF, int CS, float* __restrict__ corr, float* __restrict__ dsub, int dsub_ctot, int dsub_coff) {
   // One thread per low-res pixel would be 540 waves at 960x576, each walking CF + CS channels of dependent gathers
-  // (104 us, latency bound): the channels are dealt over CUES_NS waves per pixel group instead and the 33 partial
+  // (104 us, latency bound): the channels are dealt over CUES_NS waves per pixel group instead and the partial
   // sums combined through LDS in slice order.
-  __shared__ float red[CUES_NS][33][64];
-  const int h = H / 4, w = W / 4, N = h * w;
+  constexpr int P2 = P * P, NA = 3 * P2 + 6;
+  extern __shared__ float red_[];  // [CUES_NS][NA][64]
+  float(*red)[NA][64] = (float(*)[NA][64])red_;
+  const int h = H / ds, w = W / ds, N = h * w, so = ds / 2 - 1;
   const int lane = threadIdx.x, slice = threadIdx.y;
   const int x = blockIdx.x * 64 + lane, y = blockIdx.y, b = blockIdx.z;
   const bool ok = x < w;
   const int xc = ok ? x : w - 1;
   const int pix = y * w + xc;
-  const size_t fr_idx = (size_t)b * H * W + (size_t)(4 * y + 1) * W + (4 * xc + 1);
+  const size_t fr_idx = (size_t)b * H * W + (size_t)(ds * y + so) * W + (ds * xc + so);
   const float pc = pred_curr[fr_idx], pw = pred_warp[fr_idx];
-  float acc[33];
+  float acc[NA];
 #pragma unroll
-  for (int k = 0; k < 33; ++k) acc[k] = 0.f;
+  for (int k = 0; k < NA; ++k) acc[k] = 0.f;
   // stereo matching costs: 4 taps serve the three offsets (xs_k = xs_0 - k)
-  const float disp[2] = {pc * 0.25f, pw * 0.25f};
+  const float inv_ds = 1.f / (float)ds;
+  const float disp[2] = {pc * inv_ds, pw * inv_ds};
   const float* flb = fea_l + (size_t)b * CS * N + pix;
   const float* frb = fea_r + (size_t)b * CS * N + (size_t)y * w;
   float xsv[2];
@@ -53,43 +61,41 @@ __global__ __launch_bounds__(64 * CUES_NS) void fusion_cues_lr_kernel(
       c1 += fabsf(lv - (w0 * t[1] + w1 * t[2]));  // k = 0
       c2 += fabsf(lv - (w0 * t[0] + w1 * t[1]));  // k = +1
     }
-    acc[27 + 3 * s] = c0; acc[28 + 3 * s] = c1; acc[29 + 3 * s] = c2;
+    acc[3 * P2 + 3 * s] = c0; acc[3 * P2 + 1 + 3 * s] = c1; acc[3 * P2 + 2 + 3 * s] = c2;
   }
-  // pixel-to-patch feature correlations, 3x3 taps with dilation 2, zero padding: acc[0..8] cross, [9..17] self(curr),
-  // [18..26] self(warp)
+  // pixel-to-patch feature correlations: acc[0..P2) cross, [P2..2P2) self(curr), [2P2..3P2) self(warp)
   const float* fc = feat_curr + (size_t)b * CF * N;
   const float* fw = feat_warp + (size_t)b * CF * N;
   for (int c = slice; c < CF; c += CUES_NS) {
     const float kc = fc[(size_t)c * N + pix], kw_ = fw[(size_t)c * N + pix];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const int yy = y + 2 * (k / 3 - 1), xx = xc + 2 * (k % 3 - 1);
+    for (int k = 0; k < P2; ++k) {
+      const int yy = y + 2 * (k / P) - (P - 1), xx = xc + 2 * (k % P) - (P - 1);
       if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) {
         const float mc = fc[(size_t)c * N + yy * w + xx], mw = fw[(size_t)c * N + yy * w + xx];
         acc[k] += kc * mw;
-        acc[9 + k] += kc * mc;
-        acc[18 + k] += kw_ * mw;
+        acc[P2 + k] += kc * mc;
+        acc[2 * P2 + k] += kw_ * mw;
       }
     }
   }
 #pragma unroll
-  for (int k = 0; k < 33; ++k) red[slice][k][lane] = acc[k];
+  for (int k = 0; k < NA; ++k) red[slice][k][lane] = acc[k];
   __syncthreads();
   if (!ok) return;
-  // every wave finalises its share of the 33 sums (slice order: deterministic)
-  float* out = corr + (size_t)b * 31 * N + pix;
+  // every wave finalises its share of the sums (slice order: deterministic)
+  float* out = corr + (size_t)b * (3 * P2 + 4) * N + pix;
   const float nrm = 1.f / sqrtf((float)CF), sc = 1.f / ((float)CS / 24.f);
-  for (int k = slice; k < 33; k += CUES_NS) {
+  for (int k = slice; k < NA; k += CUES_NS) {
     float v = 0.f;
 #pragma unroll
     for (int q = 0; q < CUES_NS; ++q) v += red[q][k][lane];
-    if (k < 9) out[(size_t)k * N] = v * nrm;
-    else if (k < 18) { if (k != 13) out[(size_t)(9 + (k - 9 < 4 ? k - 9 : k - 10)) * N] = v * nrm; }
-    else if (k < 27) { if (k != 22) out[(size_t)(17 + (k - 18 < 4 ? k - 18 : k - 19)) * N] = v * nrm; }
+    if (k < P2) out[(size_t)k * N] = v * nrm;
+    else if (k < 2 * P2) { const int t = k - P2; if (t != P2 / 2) out[(size_t)(P2 + (t < P2 / 2 ? t : t - 1)) * N] = v * nrm; }
+    else if (k < 3 * P2) { const int t = k - 2 * P2; if (t != P2 / 2) out[(size_t)(2 * P2 - 1 + (t < P2 / 2 ? t : t - 1)) * N] = v * nrm; }
     else {
-      const int s_ = (k - 27) / 3;
-      const float xs = xsv[s_];
-      out[(size_t)(25 + (k - 27)) * N] = (xs != xs) ? xs : v * sc;
+      const float xs = xsv[(k - 3 * P2) / 3];
+      out[(size_t)(3 * P2 - 2 + (k - 3 * P2)) * N] = (xs != xs) ? xs : v * sc;
     }
   }
   if (slice == 0) {
@@ -98,60 +104,83 @@ __global__ __launch_bounds__(64 * CUES_NS) void fusion_cues_lr_kernel(
   }
 }
 
-extern "C" int codd_fusion_cues_lr(const float* pred_curr, const float* pred_warp, const float* feat_curr,
-                                   const float* feat_warp, const float* fea_l, const float* fea_r, int B, int H, int W,
-                                   int CF, int CS, float* corr_feat, float* dsub, int dsub_ctot, int dsub_coff,
-                                   void* stream) {
-  if (!pred_curr || !pred_warp || !feat_curr || !feat_warp || !fea_l || !fea_r || !corr_feat || !dsub) return CODD_EINVAL;
-  if ((H & 3) || (W & 3)) return CODD_EINVAL;
-  dim3 grid(cdiv(W / 4, 64), H / 4, B);
-  fusion_cues_lr_kernel<<<grid, dim3(64, CUES_NS), 0, (hipStream_t)stream>>>(pred_curr, pred_warp, feat_curr, feat_warp,
-                                                                           fea_l, fea_r, H, W, CF, CS, corr_feat, dsub,
-                                                                           dsub_ctot, dsub_coff);
+template <int P>
+static int launch_cues_lr(const float* pred_curr, const float* pred_warp, const float* feat_curr, const float* feat_warp,
+                          const float* fea_l, const float* fea_r, int B, int H, int W, int ds, int CF, int CS,
+                          float* corr_feat, float* dsub, int dsub_ctot, int dsub_coff, hipStream_t s) {
+  const size_t lds = (size_t)CUES_NS * (3 * P * P + 6) * 64 * sizeof(float);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)fusion_cues_lr_kernel<P>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  dim3 grid(cdiv(W / ds, 64), H / ds, B);
+  fusion_cues_lr_kernel<P><<<grid, dim3(64, CUES_NS), lds, s>>>(pred_curr, pred_warp, feat_curr, feat_warp, fea_l, fea_r, H,
+                                                               W, ds, CF, CS, corr_feat, dsub, dsub_ctot, dsub_coff);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }
 
+extern "C" int codd_fusion_cues_lr(const float* pred_curr, const float* pred_warp, const float* feat_curr,
+                                   const float* feat_warp, const float* fea_l, const float* fea_r, int B, int H, int W,
+                                   int patch, int ds, int CF, int CS, float* corr_feat, float* dsub, int dsub_ctot,
+                                   int dsub_coff, void* stream) {
+  if (!pred_curr || !pred_warp || !feat_curr || !feat_warp || !fea_l || !fea_r || !corr_feat || !dsub) return CODD_EINVAL;
+  if (ds < 2 || (ds & 1) || (H % ds) || (W % ds)) return CODD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+#define X(P)                                                                                                       \
+  if (patch == P)                                                                                                  \
+    return launch_cues_lr<P>(pred_curr, pred_warp, feat_curr, feat_warp, fea_l, fea_r, B, H, W, ds, CF, CS, corr_feat, \
+                             dsub, dsub_ctot, dsub_coff, s);
+  X(3) X(5)
+#undef X
+  return CODD_EUNSUPPORTED;  // patch sizes 3 and 5 are instantiated
+}
+
 // ------------------------------------------------------------------------------------------------
-// Full-resolution cues: corr_feat_fr [B,32,H,W] =
-//   0..8 |pc - pw~(nb)|, 9..16 |pc - pc~(nb)| (centre dropped), 17..24 |pw - pw~(nb)|,
-//   25..27 flow_warp, 28 (pw > 0), 29..31 confidence_warp      (nb = 3x3 taps, dilation 2, zero pad)
+// Full-resolution cues: corr_feat_fr [B,3P2+5,H,W] =
+//   [0,P2) |pc - pw~(nb)|, [P2,2P2-1) |pc - pc~(nb)| (tap P2/2 dropped), [2P2-1,3P2-2) |pw - pw~(nb)|,
+//   3 flow_warp, 1 (pw > 0), 3 confidence_warp      (nb = P x P taps, dilation 2, zero pad)
 // ------------------------------------------------------------------------------------------------
+template <int P>
 __global__ void fusion_cues_fr_kernel(const float* __restrict__ pc_, const float* __restrict__ pw_,
                                       const float* __restrict__ flow_warp, const float* __restrict__ conf_warp, int H,
                                       int W, float* __restrict__ out) {
+  constexpr int P2 = P * P;
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
   if (x >= W) return;
   const size_t N = (size_t)H * W, pix = (size_t)y * W + x;
   const float* pcb = pc_ + (size_t)b * N;
   const float* pwb = pw_ + (size_t)b * N;
   const float pc = pcb[pix], pw = pwb[pix];
-  float* o = out + (size_t)b * 32 * N + pix;
+  float* o = out + (size_t)b * (3 * P2 + 5) * N + pix;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    const int yy = y + 2 * (k / 3 - 1), xx = x + 2 * (k % 3 - 1);
+  for (int k = 0; k < P2; ++k) {
+    const int yy = y + 2 * (k / P) - (P - 1), xx = x + 2 * (k % P) - (P - 1);
     const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
     const float mc = in ? pcb[(size_t)yy * W + xx] : 0.f, mw = in ? pwb[(size_t)yy * W + xx] : 0.f;
     o[(size_t)k * N] = fabsf(pc - mw);
-    if (k != 4) {
-      const int kk = k < 4 ? k : k - 1;
-      o[(size_t)(9 + kk) * N] = fabsf(pc - mc);
-      o[(size_t)(17 + kk) * N] = fabsf(pw - mw);
+    if (k != P2 / 2) {
+      const int kk = k < P2 / 2 ? k : k - 1;
+      o[(size_t)(P2 + kk) * N] = fabsf(pc - mc);
+      o[(size_t)(2 * P2 - 1 + kk) * N] = fabsf(pw - mw);
     }
   }
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    o[(size_t)(25 + c) * N] = flow_warp[((size_t)b * 3 + c) * N + pix];
-    o[(size_t)(29 + c) * N] = conf_warp[((size_t)b * 3 + c) * N + pix];
+    o[(size_t)(3 * P2 - 2 + c) * N] = flow_warp[((size_t)b * 3 + c) * N + pix];
+    o[(size_t)(3 * P2 + 2 + c) * N] = conf_warp[((size_t)b * 3 + c) * N + pix];
   }
-  o[(size_t)28 * N] = pw > 0.f ? 1.f : 0.f;
+  o[(size_t)(3 * P2 + 1) * N] = pw > 0.f ? 1.f : 0.f;
 }
 
 extern "C" int codd_fusion_cues_fr(const float* pred_curr, const float* pred_warp, const float* flow_warp,
-                                   const float* conf_warp, int B, int H, int W, float* out, void* stream) {
+                                   const float* conf_warp, int B, int H, int W, int patch, float* out, void* stream) {
   if (!pred_curr || !pred_warp || !flow_warp || !conf_warp || !out) return CODD_EINVAL;
   dim3 grid(cdiv(W, 256), H, B);
-  fusion_cues_fr_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(pred_curr, pred_warp, flow_warp, conf_warp, H, W, out);
+  hipStream_t s = (hipStream_t)stream;
+  if (patch == 3) fusion_cues_fr_kernel<3><<<grid, 256, 0, s>>>(pred_curr, pred_warp, flow_warp, conf_warp, H, W, out);
+  else if (patch == 5) fusion_cues_fr_kernel<5><<<grid, 256, 0, s>>>(pred_curr, pred_warp, flow_warp, conf_warp, H, W, out);
+  else return CODD_EUNSUPPORTED;
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }

@@ -29,20 +29,21 @@ class Fusion(nn.Module):
         self.loss = build_loss(loss) if loss is not None else None
         self.fusion_channel, self.ds_scale, self.in_channels = fusion_channel, ds_scale, in_channels
         self.patch_size = corr_cfg.get("patch_size", 3)
-        if self.patch_size != 3 or ds_scale != 4:
-            raise NotImplementedError("the HIP cue kernels implement patch_size=3, ds_scale=4 "
-                                      "(configs/models/codd.py:82-86)")
+        if self.patch_size not in (3, 5) or ds_scale < 2 or ds_scale % 2:
+            raise NotImplementedError("the HIP cue kernels are instantiated for patch_size 3 and 5 and even ds_scale "
+                                      "(configs/models/codd.py:82-86 uses 3 and 4)")
         fc = fusion_channel
+        p2 = self.patch_size ** 2  # cue channels (reference fusion.py:82-87): cross p2, self 2 (p2 - 1), stereo cost 6
         self.key_layer = nn.Sequential(nn.Conv2d(in_channels, fc, 1), nn.ReLU(inplace=True),
                                        BasicBlock(fc, fc, s=1, p=1, d=1), nn.ReLU(inplace=True), nn.Conv2d(fc, fc, 1))
-        self.conv_corr = nn.Sequential(nn.Conv2d(16 + 9 + 6, fc * 2, 1), nn.ReLU(inplace=True),
+        self.conv_corr = nn.Sequential(nn.Conv2d(2 * (p2 - 1) + p2 + 6, fc * 2, 1), nn.ReLU(inplace=True),
                                        nn.Conv2d(fc * 2, fc, 1), nn.ReLU(inplace=True))
         self.conv_disp = nn.Sequential(nn.Conv2d(2, fc, 7, padding=3), nn.ReLU(inplace=True),
                                        nn.Conv2d(fc, fc, 3, padding=1), nn.ReLU(inplace=True))
         self.motion_conv = nn.Sequential(nn.Conv2d(fc * 2, fc - 2, 7, padding=3), nn.ReLU(inplace=True))
         self.weight_head = nn.Sequential(nn.Conv2d(fc, fc, 3, padding=1), nn.Conv2d(fc, 1, 1), nn.Identity(),
                                          nn.Sigmoid())
-        self.forget_head = nn.Sequential(nn.Conv2d(6 + 16 + 9 + 1, 16, 1), nn.Conv2d(16, 8, 3, padding=1),
+        self.forget_head = nn.Sequential(nn.Conv2d(6 + 2 * (p2 - 1) + p2 + 1, 16, 1), nn.Conv2d(16, 8, 3, padding=1),
                                          nn.Conv2d(8, 1, 1), nn.Identity(), nn.Sigmoid())
         self.residual_conv = nn.Sequential(nn.Conv2d(fc * 2, fc, 3, padding=1), nn.ReLU(inplace=True))
 
@@ -66,19 +67,21 @@ class Fusion(nn.Module):
         B, _, H, W = pred_curr.shape
         fc = self.fusion_channel
         # [mo (fc-2) | pc | pw] : second half of residual_conv's input (reference fuse(), :343-346)
-        tail = torch.empty(B, fc, H // 4, W // 4, device=pred_curr.device, dtype=torch.float32)
+        ds = self.ds_scale
+        tail = torch.empty(B, fc, H // ds, W // ds, device=pred_curr.device, dtype=torch.float32)
         # the full-resolution forget-head chain (reference fusion.py:123-132) only needs the warped state: it runs
         # on a side stream beside the quarter-resolution cue / weight-head chain
         if getattr(self, "_fk", None) is None or self._fk.dev != pred_curr.device:
             self._fk = ops.Fork(pred_curr.device, 1)
 
         def forget_chain():
-            cues_fr = ops.fusion_cues_fr(pred_curr, pred_warp, flow_warp, conf_warp)
+            cues_fr = ops.fusion_cues_fr(pred_curr, pred_warp, flow_warp, conf_warp, patch=self.patch_size)
             t = cv(self.forget_head[1], cv(self.forget_head[0], cues_fr))
             return cv(self.forget_head[2], t, act="sigmoid")
 
         wr = self._fk.run(0, forget_chain)
-        corr_feat = ops.fusion_cues_lr(pred_curr, pred_warp, feat_curr, feat_warp, fea_l, fea_r, Slice(tail, fc - 2, 2))
+        corr_feat = ops.fusion_cues_lr(pred_curr, pred_warp, feat_curr, feat_warp, fea_l, fea_r, Slice(tail, fc - 2, 2),
+                                       patch=self.patch_size, ds=ds)
         corr = cv(self.conv_corr[2], cv(self.conv_corr[0], corr_feat, act="relu"), act="relu")
         disp = cv(self.conv_disp[0], Slice(tail, fc - 2, 2), act="relu")
         disp = cv(self.conv_disp[2], disp, act="relu")

@@ -1003,25 +1003,25 @@ class Fork:
 
 
 # ----------------------------------------------------------------------------------------- fusion
-def fusion_cues_lr(pred_curr, pred_warp, feat_curr, feat_warp, fea_l, fea_r, dsub):
-    """-> corr_feat [B,31,H/4,W/4]; writes (pc, pw) sub-sampled into the 2-channel Slice ``dsub``."""
+def fusion_cues_lr(pred_curr, pred_warp, feat_curr, feat_warp, fea_l, fea_r, dsub, patch=3, ds=4):
+    """-> corr_feat [B, 3 patch^2 + 4, H/ds, W/ds]; writes (pc, pw) sub-sampled into the 2-channel Slice ``dsub``."""
     lib = _abi.load()
     B, _, H, W = pred_curr.shape
-    corr = _f32(B, 31, H // 4, W // 4, like=pred_curr)
+    corr = _f32(B, 3 * patch * patch + 4, H // ds, W // ds, like=pred_curr)
     ds_ = _as_slice(dsub)
     _abi.check(lib.codd_fusion_cues_lr(pred_curr.data_ptr(), pred_warp.data_ptr(), feat_curr.data_ptr(),
-                                       feat_warp.data_ptr(), fea_l.data_ptr(), fea_r.data_ptr(), B, H, W,
+                                       feat_warp.data_ptr(), fea_l.data_ptr(), fea_r.data_ptr(), B, H, W, patch, ds,
                                        feat_curr.shape[1], fea_l.shape[1], corr.data_ptr(), ds_.buf.data_ptr(),
                                        ds_.buf.shape[1], ds_.coff, _stream()), "fusion_cues_lr")
     return corr
 
 
-def fusion_cues_fr(pred_curr, pred_warp, flow_warp, conf_warp):
+def fusion_cues_fr(pred_curr, pred_warp, flow_warp, conf_warp, patch=3):
     lib = _abi.load()
     B, _, H, W = pred_curr.shape
-    out = _f32(B, 32, H, W, like=pred_curr)
+    out = _f32(B, 3 * patch * patch + 5, H, W, like=pred_curr)
     _abi.check(lib.codd_fusion_cues_fr(pred_curr.data_ptr(), pred_warp.data_ptr(), flow_warp.data_ptr(),
-                                       conf_warp.data_ptr(), B, H, W, out.data_ptr(), _stream()), "fusion_cues_fr")
+                                       conf_warp.data_ptr(), B, H, W, patch, out.data_ptr(), _stream()), "fusion_cues_fr")
     return out
 
 

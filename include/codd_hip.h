@@ -310,19 +310,20 @@ int codd_gru_gate_q_xs(const float* t1, const float* t2, const float* inp, const
 /* ---------------------------------------------------------------------------------------------
  * Fusion
  * --------------------------------------------------------------------------------------------- */
-/* 1/4-resolution cues (fusion.py:200-241, 168-198, 243-318): corr_feat [B,31,h4,w4] =
- * [feat cross (9) | feat self curr (8) | feat self warp (8) | cost_curr (3) | cost_warp (3)]
+/* 1/ds-resolution cues (fusion.py:200-241, 168-198, 243-318), patch = corr_cfg.patch_size (3 or 5; P2 = patch^2),
+ * ds = Fusion.ds_scale (even): corr_feat [B, 3 P2 + 4, H/ds, W/ds] =
+ * [feat cross (P2) | feat self curr (P2-1) | feat self warp (P2-1) | cost_curr (3) | cost_warp (3)]  (31 at patch 3)
  * and the sub-sampled disparities pc, pw (fuse(), fusion.py:331-342) written to channels
  * (dsub_coff, dsub_coff+1) of dsub. */
 int codd_fusion_cues_lr(const float* pred_curr, const float* pred_warp, const float* feat_curr,
                         const float* feat_warp, const float* fea_l, const float* fea_r,
-                        int B, int H, int W, int CF, int CS, float* corr_feat,
+                        int B, int H, int W, int patch, int ds, int CF, int CS, float* corr_feat,
                         float* dsub, int dsub_ctot, int dsub_coff, void* stream);
 
-/* Full-resolution cues (fusion.py:243-318): corr_feat_fr [B,32,H,W] = [|disp cross| (9) |
- * |disp self curr| (8) | |disp self warp| (8) | flow_warp (3) | pred_warp>0 (1) | conf_warp (3)]. */
+/* Full-resolution cues (fusion.py:243-318): corr_feat_fr [B, 3 P2 + 5, H, W] = [|disp cross| (P2) |
+ * |disp self curr| (P2-1) | |disp self warp| (P2-1) | flow_warp (3) | pred_warp>0 (1) | conf_warp (3)]  (32 at patch 3). */
 int codd_fusion_cues_fr(const float* pred_curr, const float* pred_warp, const float* flow_warp,
-                        const float* conf_warp, int B, int H, int W, float* out, void* stream);
+                        const float* conf_warp, int B, int H, int W, int patch, float* out, void* stream);
 
 /* Blend (fusion.py:383-394): wf = up4(wf_lr) * (pw>0); wr *= (pw>0);
  * fused = pc*(1-wf*wr) + pw*wf*wr. */

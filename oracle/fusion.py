@@ -23,17 +23,17 @@ def key_layer(sd, p, x):
     return conv(sd, p + ".4", F.relu(u))
 
 
-def px2patch(k, m, self_corr=False):
-    """reference fusion.py:168-198 (+ unfold_feat :412-425):
-    out[b, ky*3+kx, y, x] = <k[b,:,y,x], m~[b,:,y+2(ky-1), x+2(kx-1)]> / sqrt(C)  (C > 1)
-                          = (k - m~) / sqrt(1)                                     (C == 1)
-    zero padding; ``self_corr`` drops the centre tap."""
+def px2patch(k, m, self_corr=False, P=3):
+    """reference fusion.py:168-198 (+ unfold_feat :412-425; nn.Unfold(kernel P, padding P-1, dilation 2), :66-70):
+    out[b, ky*P+kx, y, x] = <k[b,:,y,x], m~[b,:,y+2ky-(P-1), x+2kx-(P-1)]> / sqrt(C)  (C > 1)
+                          = (k - m~) / sqrt(1)                                         (C == 1)
+    zero padding; ``self_corr`` drops tap index P*P // 2 (the centre for odd P)."""
     B, C, H, W = k.shape
-    mp = F.pad(m, (2, 2, 2, 2))
+    mp = F.pad(m, (P - 1, P - 1, P - 1, P - 1))
     outs = []
-    for ky in range(3):
-        for kx in range(3):
-            if self_corr and ky == 1 and kx == 1:
+    for ky in range(P):
+        for kx in range(P):
+            if self_corr and ky * P + kx == (P * P) // 2:
                 continue
             sh = mp[:, :, 2 * ky:2 * ky + H, 2 * kx:2 * kx + W]
             outs.append((k - sh) if C == 1 else (k * sh).sum(1, keepdim=True))
@@ -52,13 +52,13 @@ def disparity_confidence(pred_curr, pred_warp, fea_l, fea_r, ds=4, in_channels=2
     return torch.cat(cp, 1), torch.cat(cw, 1)
 
 
-def input_cues(pred_curr, pred_warp, feat_curr, feat_warp, flow_warp, conf_warp, fea_l, fea_r):
-    """reference fusion.py:243-318 -> corr_feat [B,31,H/4,W/4], corr_feat_fr [B,32,H,W]."""
-    cost_curr, cost_warp = disparity_confidence(pred_curr, pred_warp, fea_l, fea_r)
-    f_cross = px2patch(feat_curr, feat_warp)
-    f_self = torch.cat([px2patch(feat_curr, feat_curr, True), px2patch(feat_warp, feat_warp, True)], 1)
-    d_cross = px2patch(pred_curr, pred_warp).abs()
-    d_self = torch.cat([px2patch(pred_curr, pred_curr, True), px2patch(pred_warp, pred_warp, True)], 1).abs()
+def input_cues(pred_curr, pred_warp, feat_curr, feat_warp, flow_warp, conf_warp, fea_l, fea_r, P=3, ds=4):
+    """reference fusion.py:243-318 -> corr_feat [B,3P^2+4,H/ds,W/ds], corr_feat_fr [B,3P^2+5,H,W] (31 / 32 at P = 3)."""
+    cost_curr, cost_warp = disparity_confidence(pred_curr, pred_warp, fea_l, fea_r, ds=ds, in_channels=fea_l.shape[1])
+    f_cross = px2patch(feat_curr, feat_warp, P=P)
+    f_self = torch.cat([px2patch(feat_curr, feat_curr, True, P), px2patch(feat_warp, feat_warp, True, P)], 1)
+    d_cross = px2patch(pred_curr, pred_warp, P=P).abs()
+    d_self = torch.cat([px2patch(pred_curr, pred_curr, True, P), px2patch(pred_warp, pred_warp, True, P)], 1).abs()
     corr_feat = torch.cat([f_cross, f_self, cost_curr, cost_warp], 1)
     corr_feat_fr = torch.cat([d_cross, d_self, flow_warp, (pred_warp > 0).float(), conf_warp], 1)
     return corr_feat, corr_feat_fr
@@ -85,7 +85,7 @@ def forget_head(sd, p, x):
     return torch.sigmoid(conv(sd, p + ".forget_head.2", t))
 
 
-def memory_query(sd, outputs, state, p="fusion"):
+def memory_query(sd, outputs, state, p="fusion", patch_size=3, ds=4):
     """reference fusion.py:357-402 (mutates ``outputs``)."""
     left_feat, pred_curr = outputs["left_feat"], outputs["pred_disp"]
     feat_curr = key_layer(sd, p + ".key_layer", left_feat)
@@ -94,9 +94,9 @@ def memory_query(sd, outputs, state, p="fusion"):
         return
     _, feat_warp, conf_warp, pred_warp, flow_warp = state["memory"]
     corr_feat, corr_feat_fr = input_cues(pred_curr, pred_warp, feat_curr, feat_warp, flow_warp, conf_warp,
-                                         outputs["left_feat"], outputs["right_feat"])
+                                         outputs["left_feat"], outputs["right_feat"], P=patch_size, ds=ds)
     valid = (pred_warp > 0.0).float()
-    wf = fuse(sd, p, corr_feat, pred_curr, pred_warp, feat_curr) * valid
+    wf = fuse(sd, p, corr_feat, pred_curr, pred_warp, feat_curr, ds=ds) * valid
     wr = forget_head(sd, p, corr_feat_fr) * valid
     outputs["pred_disp"] = pred_curr * (1 - wf * wr) + pred_warp * wf * wr
     outputs["fusion_weights"] = wf

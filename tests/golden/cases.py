@@ -46,6 +46,16 @@ def fusion_case(H=64, W=128):
     return out, dict(memory=mem)
 
 
+def fusion_p5_state_dict():
+    """The fusion.* weights for corr_cfg.patch_size = 5: the two layers that read the cue tensors get
+    3*25+4 = 79 and 3*25+5 = 80 input channels (reference fusion.py:82-126); everything else as state_dict()."""
+    sd = {k: v for k, v in state_dict().items() if k.startswith("fusion.")}
+    R = _gen(150)
+    sd["fusion.conv_corr.0.weight"] = R(64, 79, 1, 1) * (1.4 / 79 ** 0.5)
+    sd["fusion.forget_head.0.weight"] = R(16, 80, 1, 1) * (1.4 / 80 ** 0.5)
+    return sd
+
+
 def update_inputs(h=8, w=16):
     R = _gen(200)
     return R(1, 128, h, w), R(1, 384, h, w), R(1, 196, h, w), R(1, h, w, 2), R(1, h, w, 6), R(1, h, w, 1)

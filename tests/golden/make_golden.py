@@ -84,6 +84,13 @@ def main():
         o1, _ = cases.fusion_case()
         fus.memory_query(o1, {})
         out["fusion_first_left_feat"] = o1["left_feat"]
+        # the same with the non-default correlation patch (corr_cfg.patch_size = 5: 25-tap px2patch windows)
+        fus5 = load(MODELS.build(dict(type="Fusion", in_channels=24, fusion_channel=32,
+                                      corr_cfg=dict(type="px2patch", patch_size=5))), cases.fusion_p5_state_dict(), "fusion.")
+        o5, st5 = cases.fusion_case()
+        fus5.memory_query(o5, st5)
+        for k in ("pred_disp", "fusion_weights", "reset_weights"):
+            out[f"fusion_p5_{k}"] = o5[k]
         # ---- RAFT3D pure-torch blocks ------------------------------------------------------------
         fnet = load(BasicEncoder(output_dim=128, norm_fn="instance"), sd, "motion.raft3d.fnet.")
         out["fnet"] = fnet(cases.image(64, 128))

@@ -226,6 +226,47 @@ def test_fusion_query():
         assert rel(o_gpu[k].cpu(), o_ref[k]) < 2e-4, (k, rel(o_gpu[k].cpu(), o_ref[k]))
 
 
+@pytest.mark.parametrize("patch,ds", [(5, 4), (3, 2)])
+def test_fusion_non_default_geometry(patch, ds):
+    """Fusion with corr_cfg.patch_size != 3 / ds_scale != 4 (reference fusion.py:55-72 is generic): HIP vs the oracle,
+    and for patch_size = 5 vs the REFERENCE's own output (tests/golden: fusion_p5_*)."""
+    import numpy as np
+    from codd_amd.registry import MODELS
+    from oracle import fusion as ofu
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import cases
+    fus = MODELS.build(dict(type="Fusion", in_channels=24, fusion_channel=32, corr_cfg=dict(type="px2patch", patch_size=patch),
+                            ds_scale=ds)).eval()
+    if patch == 5:
+        sd = cases.fusion_p5_state_dict()
+    else:
+        g = torch.Generator().manual_seed(3)
+        sd = {"fusion." + k: (cases.state_dict()["fusion." + k] if cases.state_dict()["fusion." + k].shape == v.shape
+                              else torch.randn(v.shape, generator=g) * (1.4 / v[0].numel() ** 0.5))
+              for k, v in fus.state_dict().items()}
+    fus.load_state_dict({k[len("fusion."):]: v for k, v in sd.items()})
+    fus = fus.to(DEV)
+    o, st = cases.fusion_case()
+    if ds != 4:  # the stereo / memory features live at 1/ds resolution
+        H, W = o["pred_disp"].shape[-2:]
+        R = cases._gen(7)
+        o["left_feat"], o["right_feat"] = R(1, 24, H // ds, W // ds), R(1, 24, H // ds, W // ds)
+        st["memory"][1] = R(1, 32, H // ds, W // ds)
+    o_ref = dict(o)
+    with torch.no_grad():
+        ofu.memory_query(sd, o_ref, dict(memory=list(st["memory"])), patch_size=patch, ds=ds)
+        o_gpu = {k: v.to(DEV) for k, v in o.items()}
+        fus.memory_query(o_gpu, dict(memory=[m.to(DEV) for m in st["memory"]]))
+    for k in ("fusion_weights", "reset_weights", "pred_disp"):
+        assert rel(o_gpu[k].cpu(), o_ref[k]) < 2e-4, (k, rel(o_gpu[k].cpu(), o_ref[k]))
+    if patch == 5:
+        G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_outputs.npz"))
+        for k in ("fusion_weights", "reset_weights", "pred_disp"):
+            ref = torch.from_numpy(G[f"fusion_p5_{k}"])
+            assert rel(o_gpu[k].cpu(), ref) < 2e-4, (k, rel(o_gpu[k].cpu(), ref))
+
+
 @pytest.mark.parametrize("iters", [2])
 def test_full_codd_sequence(iters):
     from codd_amd import synth

@@ -52,6 +52,16 @@ def test_fusion():
     close(o1["left_feat"], "fusion_first_left_feat")
 
 
+def test_fusion_patch_size_5():
+    """Fusion with corr_cfg.patch_size = 5 (25-tap windows, 79 / 80 cue channels) against the reference's output."""
+    sd = cases.fusion_p5_state_dict()
+    o, st = cases.fusion_case()
+    with torch.no_grad():
+        ofu.memory_query(sd, o, st, patch_size=5)
+    for k in ("pred_disp", "fusion_weights", "reset_weights"):
+        close(o[k], f"fusion_p5_{k}")
+
+
 def test_raft_blocks():
     sd = cases.state_dict()
     with torch.no_grad():
