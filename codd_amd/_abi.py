@@ -91,7 +91,7 @@ SIGNATURES = {
     "codd_conv2d_pack_weights_bf16": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _f, _p]),
     "codd_fusion_select": (_i, [_i, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p]),
     "codd_gt_motion": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
-    "codd_tepe_metrics": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p]),
+    "codd_tepe_metrics": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p]),
     "codd_sceneflow_metrics": (_i, [_p] * 6 + [_i] * 5 + [_f] * 7 + [_p, _p, _p]),
     "codd_preprocess": (_i, [_p, _i, _i, _i, C.POINTER(C.c_float), C.POINTER(C.c_float), _i, _i, _p, _p]),
     "codd_fusion_blend": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),

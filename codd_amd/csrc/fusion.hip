@@ -286,8 +286,13 @@ extern "C" int codd_disp_metrics(const float* pred, const float* gt, int B, int 
 __global__ __launch_bounds__(256) void tepe_partial_kernel(const float* __restrict__ pred, const float* __restrict__ gt,
                                                            const float* __restrict__ pred_prev,
                                                            const float* __restrict__ gt_prev,
-                                                           const float* __restrict__ flow, int W, int h, int w, float lo,
+                                                           const float* __restrict__ flow,
+                                                           const float* __restrict__ gt_mask,
+                                                           const float* __restrict__ gt2_prev, int W, int h, int w, float lo,
                                                            float hi, float bf, long long HW, double* __restrict__ partial) {
+  // gt_mask: the map the CURRENT frame's validity is taken from (the reference substitutes a constant in-range map when
+  // a frame has no disparity ground truth at all, model/codd.py:478-486); gt2_prev: second-frame disparity in the previous
+  // frame's coordinates, used instead of the flow-warped ground truth when the data set provides it (:497-499)
   __shared__ double red[6][4];
   const int b = blockIdx.y;
   const long long n = (long long)h * w;
@@ -303,13 +308,15 @@ __global__ __launch_bounds__(256) void tepe_partial_kernel(const float* __restri
     const float sx = nearbyintf((float)x + fx), sy = nearbyintf((float)y + fy);
     if (!(sx >= 0.f && sx <= (float)(w - 1) && sy >= 0.f && sy <= (float)(h - 1))) continue;
     const size_t sidx = (size_t)b * HW + (size_t)((int)sy) * W + (int)sx;
-    const float gw = gt[sidx], pw = pred[sidx];
+    float gw = gt[sidx];
+    const float pw = pred[sidx], gmw = gt_mask[sidx];
     // mask of the current frame (disp range & |flow| < BF) at the SAMPLED and at the UNWARPED position
     const float fxs = flow[(size_t)b * 2 * HW + (size_t)((int)sy) * W + (int)sx];
     const float fys = flow[(size_t)b * 2 * HW + HW + (size_t)((int)sy) * W + (int)sx];
-    const bool mw = gw > lo && gw < hi && sqrtf(fxs * fxs + fys * fys) < bf;
-    const float gc = gt[idx];
-    const bool mc = gc > lo && gc < hi && sqrtf(fx * fx + fy * fy) < bf;
+    const bool mw = gmw > lo && gmw < hi && sqrtf(fxs * fxs + fys * fys) < bf;
+    const float gc = gt_mask[idx];
+    bool mc = gc > lo && gc < hi && sqrtf(fx * fx + fy * fy) < bf;
+    if (gt2_prev) { gw = gt2_prev[idx]; mc = mc && gw > 0.f; }
     if (!(mprev && mw && mc)) continue;
     const float dgt = gw - gp;
     const float te = fabsf((pw - pred_prev[idx]) - dgt);
@@ -341,13 +348,14 @@ __global__ void tepe_finish_kernel(const double* __restrict__ partial, int nblk,
 }
 
 extern "C" int codd_tepe_metrics(const float* pred, const float* gt, const float* pred_prev, const float* gt_prev,
-                                 const float* flow_prev, int B, int H, int W, int h, int w, float lo, float hi,
-                                 float bf, double* scratch, double* meters, void* stream) {
+                                 const float* flow_prev, const float* gt_mask, const float* gt2_prev, int B, int H, int W,
+                                 int h, int w, float lo, float hi, float bf, double* scratch, double* meters,
+                                 void* stream) {
   if (!pred || !gt || !pred_prev || !gt_prev || !flow_prev || !scratch || !meters || h > H || w > W) return CODD_EINVAL;
   const int nblk = 128;
   hipStream_t s = (hipStream_t)stream;
-  tepe_partial_kernel<<<dim3(nblk, B), 256, 0, s>>>(pred, gt, pred_prev, gt_prev, flow_prev, W, h, w, lo, hi, bf,
-                                                    (long long)H * W, scratch);
+  tepe_partial_kernel<<<dim3(nblk, B), 256, 0, s>>>(pred, gt, pred_prev, gt_prev, flow_prev, gt_mask ? gt_mask : gt,
+                                                    gt2_prev, W, h, w, lo, hi, bf, (long long)H * W, scratch);
   CODD_LAUNCH_CHECK();
   tepe_finish_kernel<<<1, 64, 0, s>>>(scratch, nblk, B, (double)h * w, meters);
   CODD_LAUNCH_CHECK();

@@ -81,13 +81,21 @@ class ConsistentOnlineDynamicDepth(nn.Module):
                 gt_dc = [g.contiguous() for g in torch.unbind(kwargs["gt_disp_change"][0], 1)]
             if kwargs.get("gt_flow_occ") is not None:
                 gt_occ = [(g > 0).contiguous() for g in torch.unbind(kwargs["gt_flow_occ"][0], 1)]
+            # KITTI-style inputs (model/codd.py:350-363): second-frame disparity and the non-occluded mask
+            gt_d2 = ([g.contiguous() for g in torch.unbind(kwargs["gt_disp2"][0], 1)]
+                     if kwargs.get("gt_disp2") is not None else None)
+            gt_seg = ([(g <= 0).contiguous() for g in torch.unbind(kwargs["gt_disp_occ"][0], 1)]
+                      if kwargs.get("gt_disp_occ") is not None else None)
+            derive_dc = gt_dc is None and (gt_occ is not None or gt_d2 is not None) and gt_flow is not None
+            if derive_dc:
+                gt_dc = [None] * len(gt_disp)  # filled frame by frame below
             seqm = SequenceMetrics(img_meta[0], img.device)
         outputs = []
         # ``use_graph`` (set by the CLI unless --no-graph): steady-state frames run by hipGraph replay through
         # codd_amd.runtime.FrameRunner (one capture per input shape and camera, reused across videos) instead of ~900
         # eager launches per frame.  The scene-flow columns need the per-frame SE3 field, so that evaluation stays eager.
         runner = None
-        if getattr(self, "use_graph", False) and self.motion is not None and self.fusion is not None and gt_dc is None:
+        if getattr(self, "use_graph", False) and self.motion is not None and self.fusion is not None and gt_dc is None:  # noqa: E501
             from .runtime import FrameRunner
             rkey = (tuple(img.shape[-2:]), tuple(img_meta[0].get("intrinsics", ())), img.device)
             cache = self.__dict__.setdefault("_runners", {})
@@ -107,15 +115,33 @@ class ConsistentOnlineDynamicDepth(nn.Module):
             self.inference_state["pred_disp"].append(pred)
             outputs.append(pred[:, :, :img_h, :img_w])
             if evaluate:
-                seqm.update_disparity_device(pred, gt_disp[idx], (img_h, img_w))
+                from . import metrics as M
+                seg = None if gt_seg is None else gt_seg[idx]
+                gt_i = M.apply_seg(gt_disp[idx], seg)  # (the kernels' masks are functions of the ground-truth value)
+                seqm.update_disparity_device(pred, gt_i, (img_h, img_w))
+                if derive_dc:  # disparity change not provided: derive it as the reference does (model/codd.py:340-357)
+                    if gt_occ is not None:
+                        if idx > 0:
+                            c = (slice(None), slice(None), slice(0, img_h), slice(0, img_w))
+                            dc = torch.full_like(gt_disp[idx], M.BF_DEFAULT)
+                            dc[c] = M.disp_change_from_flow(gt_occ[idx - 1][c], gt_disp[idx - 1][c], gt_disp[idx][c],
+                                                            gt_flow[idx - 1][c])
+                            gt_dc[idx] = dc
+                    else:
+                        gt_dc[idx] = M.disp_change_from_disp2(gt_disp[idx], gt_d2[idx])
                 if idx > 0 and gt_flow is not None:
-                    seqm.update_temporal_device(pred, gt_disp[idx], self.inference_state["pred_disp"][-2],
-                                                gt_disp[idx - 1], gt_flow[idx - 1], (img_h, img_w))
+                    seqm.update_temporal_device(pred, gt_i, self.inference_state["pred_disp"][-2],
+                                                M.apply_seg(gt_disp[idx - 1], None if gt_seg is None else gt_seg[idx - 1]),
+                                                gt_flow[idx - 1], (img_h, img_w),
+                                                gt_mask=M.temporal_mask_source(gt_disp[idx], seg),
+                                                gt2_prev=None if gt_d2 is None else gt_d2[idx - 1])
                     if gt_dc is not None and out.get("Ts") is not None:
                         # with occlusion maps the disparity change belongs to the CURRENT entry and the occlusion to
-                        # the previous frame; without, the change of the PREVIOUS entry is used (model/codd.py:521-540)
-                        seqm.update_scene_flow_device(out["Ts"], self.inference_state["pred_disp"][-2], gt_disp[idx - 1],
-                                                      gt_flow[idx - 1], gt_dc[idx] if gt_occ is not None else gt_dc[idx - 1],
+                        # the previous frame; without, the change of the PREVIOUS entry is used (model/codd.py:521-540);
+                        # the mask takes the CURRENT frame's non-occluded map (:524, 534)
+                        seqm.update_scene_flow_device(out["Ts"], self.inference_state["pred_disp"][-2],
+                                                      M.apply_seg(gt_disp[idx - 1], seg), gt_flow[idx - 1],
+                                                      gt_dc[idx] if gt_occ is not None else gt_dc[idx - 1],
                                                       None if gt_occ is None else gt_occ[idx - 1], (img_h, img_w))
         if evaluate:
             from .metrics import COLUMNS

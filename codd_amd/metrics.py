@@ -19,12 +19,44 @@ COLUMNS = ("epe", "th3", "tepe", "th3_tepe", "tepe_rel", "th1_tepe_rel", "flow_m
 BF_DEFAULT = 1050 * 0.2
 
 
-def valid_mask(gt_disp, meta, gt_flow_prev=None):
-    """reference utils/misc.py:12-36."""
+def valid_mask(gt_disp, meta, gt_flow_prev=None, seg=None):
+    """reference utils/misc.py:12-36 (``seg``: gt_semantic_seg > 0, i.e. the non-occluded mask of KITTI-style data)."""
     m = (gt_disp > meta["disp_range"][0]) & (gt_disp < meta["disp_range"][1])
+    if seg is not None:
+        m &= seg
     if gt_flow_prev is not None:
         m &= torch.sum(gt_flow_prev ** 2, dim=1, keepdim=True).sqrt() < BF_DEFAULT
     return m
+
+
+def apply_seg(gt_disp, seg):
+    """Ground truth with the pixels outside ``seg`` set to 0 (= invalid for any disp_range with lo >= 0): lets the
+    metric kernels, whose masks are functions of the ground-truth value, honour the reference's gt_semantic_seg mask."""
+    return gt_disp if seg is None else torch.where(seg, gt_disp, torch.zeros_like(gt_disp))
+
+
+def temporal_mask_source(gt_disp, seg=None):
+    """The map the temporal validity mask of the current frame is computed from (reference model/codd.py:478-486): the
+    ground truth itself, or -- when the frame has no positive ground-truth disparity at all (KITTI provides disparity for
+    one frame only) -- the constant BF_DEFAULT / 2; masked by ``seg``.  No host sync (0-dim device condition)."""
+    dummy = torch.full_like(gt_disp, BF_DEFAULT / 2.0)
+    return apply_seg(torch.where((gt_disp > 0.0).any(), gt_disp, dummy), seg)
+
+
+def disp_change_from_disp2(gt_disp, gt_disp2):
+    """reference model/codd.py:352-357: disparity change from the second-frame disparity of the data set."""
+    dc = gt_disp2 - gt_disp
+    bad = (gt_disp2 <= 0.0) | (gt_disp <= 0.0)
+    return torch.where(bad, torch.full_like(dc, BF_DEFAULT), dc)
+
+
+def disp_change_from_flow(gt_flow_occ_prev, gt_disp_prev, gt_disp_curr, gt_flow_prev):
+    """reference utils/misc.py:39-59 (compute_gt_disp_change): warp the current ground truth to the previous frame with
+    the ground-truth flow (nearest), difference to the previous ground truth, BF_DEFAULT where the warp leaves the image
+    or the flow is occluded."""
+    warped, valid = flow_warp_nearest(gt_disp_curr, gt_flow_prev)
+    dc = warped - gt_disp_prev
+    return torch.where(~valid | gt_flow_occ_prev, torch.full_like(dc, BF_DEFAULT), dc)
 
 
 def scene_flow_sums(Ts, pred_prev, gt_disp_prev, gt_flow_prev, gt_disp_change, gt_flow_occ, meta, K):
@@ -115,15 +147,17 @@ class SequenceMetrics:
         ops.disp_metrics(pred, gt, crop_hw, self.meta["disp_range"][0], self.meta["disp_range"][1], 3.0,
                          self._dev_meters, self._dev_scratch)
 
-    def update_temporal_device(self, pred, gt, pred_prev, gt_prev, flow_prev, crop_hw):
+    def update_temporal_device(self, pred, gt, pred_prev, gt_prev, flow_prev, crop_hw, gt_mask=None, gt2_prev=None):
         """TEPE family + flow magnitude of one frame pair through the HIP kernel (no host sync).
-        flow_prev [B,2,H,W]: GT flow of the PREVIOUS frame (reference state['gt_flow'][-2])."""
+        flow_prev [B,2,H,W]: GT flow of the PREVIOUS frame (reference state['gt_flow'][-2]); gt_mask / gt2_prev: see
+        temporal_mask_source / ops.tepe_metrics."""
         from . import ops
         if getattr(self, "_dev_tmeters", None) is None:
             self._dev_tmeters = torch.zeros(7, device=self.device, dtype=torch.float64)
             self._dev_tscratch = torch.empty(6 * 128 * pred.shape[0], device=self.device, dtype=torch.float64)
         ops.tepe_metrics(pred, gt, pred_prev, gt_prev, flow_prev, crop_hw, self.meta["disp_range"][0],
-                         self.meta["disp_range"][1], BF_DEFAULT, self._dev_tmeters, self._dev_tscratch)
+                         self.meta["disp_range"][1], BF_DEFAULT, self._dev_tmeters, self._dev_tscratch, gt_mask=gt_mask,
+                         gt2_prev=gt2_prev)
 
     def update_scene_flow(self, Ts, pred_prev, gt_disp_prev, gt_flow_prev, gt_disp_change, gt_flow_occ=None):
         """torch restatement of the reference's scene-flow block for one frame pair (cropped [h,w] maps)."""
@@ -141,20 +175,25 @@ class SequenceMetrics:
                               self.meta["disp_range"][0], self.meta["disp_range"][1], BF_DEFAULT,
                               self.meta["intrinsics"], self.sf, self._dev_sscratch)
 
-    def update(self, pred, gt, gt_flow=None):
+    def update(self, pred, gt, gt_flow=None, seg=None, gt_disp2=None):
         """pred, gt [B,1,h,w]; gt_flow [B,2,h,w] = flow from THIS frame to the next (reference
-        state['gt_flow'][-2] semantics when the next frame arrives)."""
-        mask = valid_mask(gt, self.meta)
+        state['gt_flow'][-2] semantics when the next frame arrives); seg: the frame's non-occluded mask (gt_disp_occ
+        <= 0); gt_disp2: the data set's second-frame disparity of THIS frame (model/codd.py:350-363, 478-499)."""
+        mask = valid_mask(gt, self.meta, seg=seg)
         err = (pred - gt).abs()
         self.m["epe"].update(err, mask)
         self.m["th3"].update((err > 3.0).to(err.dtype), mask)
         if self.prev is not None:
-            p_pred, p_gt, p_mask, flow = self.prev
+            p_pred, p_gt, p_mask, flow, p_gt2 = self.prev
             if flow is not None:
-                mk = valid_mask(gt, self.meta, gt_flow_prev=flow)
+                src = torch.where((gt > 0.0).any(), gt, torch.full_like(gt, BF_DEFAULT / 2.0))  # KITTI: dummy gt
+                mk = valid_mask(src, self.meta, gt_flow_prev=flow, seg=seg)
                 warped, valid = flow_warp_nearest(torch.cat([gt, pred, mk.to(gt.dtype)], 1), flow)
                 w_gt, w_pred, w_mask = warped[:, 0:1], warped[:, 1:2], warped[:, 2:3]
                 m_curr = valid & w_mask.bool() & mk
+                if p_gt2 is not None:
+                    w_gt = p_gt2
+                    m_curr = m_curr & (p_gt2 > 0.0)
                 both = p_mask & m_curr
                 d_est, d_gt = w_pred - p_pred, w_gt - p_gt
                 tepe = (d_est - d_gt).abs()
@@ -164,7 +203,7 @@ class SequenceMetrics:
                 self.m["th1_tepe_rel"].update((rel > 1.0).to(rel.dtype), both)
                 self.m["th3_tepe"].update((tepe > 3.0).to(rel.dtype), both)
                 self.m["flow_mag"].update(torch.sum(flow ** 2, dim=1).sqrt())
-        self.prev = (pred, gt, mask, gt_flow)
+        self.prev = (pred, gt, mask, gt_flow, gt_disp2)
 
     def row(self):
         """[12] fp64 tensor; meter columns without data are NaN (reference nanmean semantics), the five scene-flow

@@ -1049,16 +1049,21 @@ def disp_metrics(pred, gt, crop_hw, lo, hi, thr, meters, scratch=None):
     return meters
 
 
-def tepe_metrics(pred, gt, pred_prev, gt_prev, flow_prev, crop_hw, lo, hi, bf, meters, scratch=None):
-    """Accumulate the temporal metrics of one frame pair into ``meters`` ([7] fp64 on the device)."""
+def tepe_metrics(pred, gt, pred_prev, gt_prev, flow_prev, crop_hw, lo, hi, bf, meters, scratch=None, gt_mask=None,
+                 gt2_prev=None):
+    """Accumulate the temporal metrics of one frame pair into ``meters`` ([7] fp64 on the device).  ``gt_mask``: the map
+    the current frame's validity is computed from (default ``gt``); ``gt2_prev``: second-frame ground-truth disparity in
+    the previous frame's coordinates, replacing the flow-warped ground truth (include/codd_hip.h)."""
     lib = _abi.load()
     _require_gpu(pred)
     B, _, H, W = pred.shape
-    _same_hw(pred, gt, pred_prev, gt_prev, flow_prev)
+    _same_hw(pred, gt, pred_prev, gt_prev, flow_prev, gt_mask, gt2_prev)
     if scratch is None:
         scratch = torch.empty(6 * 128 * B, device=pred.device, dtype=torch.float64)
     _abi.check(lib.codd_tepe_metrics(pred.data_ptr(), gt.data_ptr(), pred_prev.data_ptr(), gt_prev.data_ptr(),
-                                     flow_prev.data_ptr(), B, H, W, crop_hw[0], crop_hw[1], float(lo), float(hi),
+                                     flow_prev.data_ptr(), None if gt_mask is None else gt_mask.data_ptr(),
+                                     None if gt2_prev is None else gt2_prev.data_ptr(),
+                                     B, H, W, crop_hw[0], crop_hw[1], float(lo), float(hi),
                                      float(bf), scratch.data_ptr(), meters.data_ptr(), _stream()), "tepe_metrics")
     return meters
 

@@ -341,10 +341,13 @@ int codd_disp_metrics(const float* pred, const float* gt, int B, int H, int W, i
 /* Temporal metrics (model/codd.py:473-521; utils/metric.py:19-37; utils/warp.py:69-92): pulls the current
  * (gt, pred, mask) back with the previous frame's GT flow [B,2,H,W] (nearest, zeros) and adds the
  * frame's mean TEPE, (TEPE>3) rate, relative TEPE, (rel>1) rate and 1 to meters[0..4] (when the joint mask
- * is non-empty), mean |flow| and 1 to meters[5..6].  scratch: 6*128*B doubles.  No host sync. */
+ * is non-empty), mean |flow| and 1 to meters[5..6].  scratch: 6*128*B doubles.  No host sync.  gt_mask (or NULL = gt): the map the current frame's validity mask is computed from -- the reference substitutes a
+ * constant in-range map for frames without any disparity ground truth (model/codd.py:478-486); gt2_prev (or NULL):
+ * ground-truth second-frame disparity in the previous frame's coordinates, used instead of the flow-warped gt and
+ * requiring gt2_prev > 0 (:497-499). */
 int codd_tepe_metrics(const float* pred, const float* gt, const float* pred_prev, const float* gt_prev,
-                      const float* flow_prev, int B, int H, int W, int h, int w, float lo, float hi,
-                      float bf, double* scratch, double* meters, void* stream);
+                      const float* flow_prev, const float* gt_mask, const float* gt2_prev, int B, int H, int W,
+                      int h, int w, float lo, float hi, float bf, double* scratch, double* meters, void* stream);
 
 /* Scene-flow metric columns (model/codd.py:519-575; utils/misc.py:12-36, 62-77): over the crop [0,h) x [0,w) of
  * [B,*,H,W] maps and the mask lo < gt_disp_prev < hi & |gt_flow_prev| < bf & |gt_disp_change| < bf (& gt_flow_occ == 0

@@ -97,6 +97,21 @@ def metric_case(H=128, W=192, MF=3, h=120, w=180):
     return img, r_img, gt, flow, meta
 
 
+def kitti_metric_case():
+    """metric_case() with KITTI-style ground truth (reference model/codd.py:350-363, 478-499): disparity for the first
+    frame of every pair only (frame 1 has none at all -> the dummy-mask branch), second-frame disparity ``gt_disp2``
+    (with holes) and an occlusion map ``gt_disp_occ`` (> 0 = occluded)."""
+    img, r_img, gt, flow, meta = metric_case()
+    R = _gen(750)
+    gt = gt.clone()
+    gt[:, 1] = 0.0
+    gt2 = (gt + 0.8 * R(*gt.shape)).clamp(min=0.0)
+    gt2[:, 0] = (gt[:, 0] + 0.8 * R(*gt[:, 0].shape)).abs()
+    gt2[:, :, :, 50:60, 60:90] = 0.0
+    occ = (R(*gt.shape) > 1.0).float()
+    return img, r_img, gt, flow, gt2, occ, meta
+
+
 def sceneflow_case(H=64, W=96, MF=3, h=60, w=90):
     """Inputs of the reference's calc_metric INCLUDING its scene-flow block (model/codd.py:519-575): per-frame
     predictions, ground truth (disparity, flow, disparity change, flow occlusion) and a dense SE3 field."""

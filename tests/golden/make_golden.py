@@ -122,6 +122,12 @@ def main():
         names = [k for k in res.keys()]
         out["metric_values"] = torch.stack([res[k].double().reshape(()) for k in names]).float()
         globals()["_METRIC_NAMES"] = names
+        # KITTI-style ground truth: no disparity on frame 1 (dummy-mask branch), gt_disp2, gt_disp_occ
+        img, r_img, gtk, flowk, gt2k, occk, meta = cases.kitti_metric_case()
+        est.reset_inference_state()
+        resk = est.inference(img, r_img, meta, evaluate=True, gt_disp=[gtk], gt_flow=[flowk], gt_disp2=[gt2k],
+                             gt_disp_occ=[occk])
+        out["metric_kitti_values"] = torch.stack([resk[k].double().reshape(()) for k in names]).float()
         # ---- scene-flow columns: the reference's own calc_metric (model/codd.py:435-575) driven frame by frame ----
         # Ts is a lietorch.SE3 in the reference (un-vendored): the stand-in below supplies only indexing and the
         # action T * X (oracle/se3.py); masks, depth clipping, induced_flow, BF scaling and the sums are the reference's.

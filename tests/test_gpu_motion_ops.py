@@ -462,6 +462,42 @@ def test_eval_harness_on_device_metrics_match_torch_restatement(tmp_path):
     assert (tmp_path / "stats.csv").exists()
 
 
+def test_inference_with_kitti_style_ground_truth_and_derived_disp_change():
+    """estimator.inference(evaluate=True) with gt_disp2 / gt_disp_occ (and, on the full model, gt_flow_occ without
+    gt_disp_change: the disparity change is derived as utils/misc.py:39-59 does): the on-device rows must equal the torch
+    restatement driven with the same inputs (which is pinned to the reference in tests/test_oracle_golden.py)."""
+    from codd_amd import configs, metrics as M, synth
+    from codd_amd.registry import build_estimator
+    H, W, MF, h, w = 128, 256, 3, 120, 250
+    est = build_estimator(configs.codd(iters=2)).to(DEV).eval()
+    synth.load_synthetic_weights(est, gain=1.4)
+    left, right, disp = synth.stereo_sequence(H, W, MF, 32.0)
+    metas = synth.default_metas(H, W, img_shape=(h, w))
+    metas[0][0].update(disp_range=(1, 210))
+    gt = disp.clone()
+    gt[:, 1] = 0.0  # no ground truth on frame 1
+    gt2 = (disp + 0.5 * rnd(1, MF, 1, H, W, seed=3)).clamp(min=0)
+    occ = (rnd(1, MF, 1, H, W, seed=4) > 1.0).float()
+    flow = rnd(1, MF, 2, H, W, seed=5) * 2
+    focc = (rnd(1, MF, 1, H, W, seed=6) > 1.2).float()
+    d = lambda t: [t.to(DEV)]
+    kw = dict(gt_disp=d(gt), gt_flow=d(flow), gt_disp2=d(gt2), gt_disp_occ=d(occ))
+    row = est(img=d(left), r_img=d(right), img_metas=metas, return_loss=False, evaluate=True, **kw)[0]
+    pred = est(img=d(left), r_img=d(right), img_metas=metas, return_loss=False, evaluate=False)[0].cpu()
+    sm = M.SequenceMetrics(metas[0][0], torch.device("cpu"))
+    c = lambda t, f: t[:, f, :, :h, :w]
+    for f in range(MF):
+        sm.update(pred[:, f:f + 1], c(gt, f), c(flow, f), seg=c(occ, f) <= 0, gt_disp2=c(gt2, f))
+    ref = sm.row()
+    for i, k in enumerate(M.COLUMNS[:7]):
+        got = float(row[k][0])
+        assert abs(got - ref[i].item()) < 1e-4 * max(1.0, abs(ref[i].item())), (k, got, ref[i].item())
+    # scene-flow columns with the disparity change derived from flow + occlusion
+    kw2 = dict(gt_disp=d(disp), gt_flow=d(flow), gt_flow_occ=d(focc))
+    row2 = est(img=d(left), r_img=d(right), img_metas=metas, return_loss=False, evaluate=True, **kw2)[0]
+    assert float(row2["count"][0]) > 0 and float(row2["epe2d_scene_flow"][0]) > 0
+
+
 def test_cli_folder_of_frames_writes_disparities(tmp_path):
     """codd_amd.inference on a folder of PNG frames == the estimator called on the same pre-processed
     tensors (reference inference.py --img-dir/--r-img-dir/--show)."""
@@ -549,6 +585,37 @@ def test_metric_kernels_match_reference_calc_metric():
     row = sm.row().cpu()
     ref = G["metric_values"]
     for i, k in enumerate(metrics.COLUMNS[:7]):
+        assert abs(row[i].item() - float(ref[i])) < 2e-5 * max(1.0, abs(float(ref[i]))), (k, row[i].item(), ref[i])
+
+
+def test_metric_kernels_kitti_style_ground_truth():
+    """The HIP metric kernels with KITTI-style ground truth (frame without disparity -> dummy mask source, gt_disp2,
+    gt_disp_occ) against the reference's own metric dict (golden metric_kitti_values)."""
+    import numpy as np
+    import sys
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gdir)
+    import cases
+    from codd_amd import metrics as M
+    G = np.load(os.path.join(gdir, "reference_outputs.npz"))
+    img, r_img, gt, flow, gt2, occ, meta = cases.kitti_metric_case()
+    h, w = meta[0]["img_shape"][:2]
+    H, W = img.shape[-2:]
+    pred = torch.zeros(1, gt.shape[1], 1, H, W)
+    pred[:, :, 0, :h, :w] = torch.from_numpy(G["metric_pred_disp"])
+    sm = M.SequenceMetrics(meta[0], torch.device(DEV))
+    pd, gd, fd, g2, seg = pred.to(DEV), gt.to(DEV), flow.to(DEV), gt2.to(DEV), (occ <= 0).to(DEV)
+    F_ = lambda t, f: t[:, f].contiguous()
+    for f in range(pred.shape[1]):
+        gi = M.apply_seg(F_(gd, f), F_(seg, f))
+        sm.update_disparity_device(F_(pd, f), gi, (h, w))
+        if f > 0:
+            sm.update_temporal_device(F_(pd, f), gi, F_(pd, f - 1), M.apply_seg(F_(gd, f - 1), F_(seg, f - 1)),
+                                      F_(fd, f - 1), (h, w), gt_mask=M.temporal_mask_source(F_(gd, f), F_(seg, f)),
+                                      gt2_prev=F_(g2, f - 1))
+    row = sm.row().cpu()
+    ref = G["metric_kitti_values"]
+    for i, k in enumerate(M.COLUMNS[:7]):
         assert abs(row[i].item() - float(ref[i])) < 2e-5 * max(1.0, abs(float(ref[i]))), (k, row[i].item(), ref[i])
 
 

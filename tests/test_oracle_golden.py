@@ -103,6 +103,24 @@ def test_metrics_restatement_matches_reference_calc_metric():
     assert float(ref[2]) > 0 and float(ref[6]) > 0  # the temporal columns were really exercised
 
 
+def test_metrics_kitti_style_ground_truth_matches_reference():
+    """KITTI-style evaluation inputs (model/codd.py:350-363, 478-499): a frame without any disparity ground truth (the
+    reference's dummy-mask branch), gt_disp2 replacing the flow-warped ground truth, gt_disp_occ as validity mask."""
+    from codd_amd import metrics
+    img, r_img, gt, flow, gt2, occ, meta = cases.kitti_metric_case()
+    h, w = meta[0]["img_shape"][:2]
+    pred = torch.from_numpy(G["metric_pred_disp"])
+    sm = metrics.SequenceMetrics(meta[0], torch.device("cpu"))
+    for f in range(pred.shape[1]):
+        sm.update(pred[:, f:f + 1], gt[:, f, :, :h, :w], flow[:, f, :, :h, :w], seg=occ[:, f, :, :h, :w] <= 0,
+                  gt_disp2=gt2[:, f, :, :h, :w])
+    row = sm.row()
+    ref = G["metric_kitti_values"]
+    for i, k in enumerate(metrics.COLUMNS[:7]):
+        assert abs(row[i].item() - float(ref[i])) < 2e-5 * max(1.0, abs(float(ref[i]))), (k, row[i].item(), ref[i])
+    assert abs(float(ref[2]) - float(G["metric_values"][2])) > 1e-3  # the branches really changed the numbers
+
+
 def test_scene_flow_columns_match_reference_calc_metric():
     """The five scene-flow accumulators (count, epe2d_scene_flow, epe2d_optical_flow, 1px_*): codd_amd.metrics'
     restatement against the reference's own calc_metric (model/codd.py:519-575) driven frame by frame with a dense
