@@ -130,7 +130,7 @@ def test_splat(ds, radius, C):
     bad = ((got.cpu() - ref).abs().amax(1) > 1e-3).float().mean().item()
     badz = ((z.cpu() - zref).abs() > 1e-3).float().mean().item()
     print("splat mismatching pixels", bad, badz, "coverage", (zref > 0).float().mean().item())
-    assert bad < 1e-3 and badz < 1e-3
+    assert bad < 1e-4 and badz < 1e-4  # (measured on MI355X: 0 mismatching pixels)
     # with induced flow + disparity conversion
     if ds == 1:
         bf = 210.0
@@ -328,7 +328,7 @@ def test_full_codd_kitti_aspect_matches_oracle(H, W, intr):
         epe_rest = diff[~flipped].mean().item()
         print(f"frame {f} (graph={rg.graph is not None}): flipped {flipped.float().mean().item():.2e}, "
               f"EPE delta elsewhere {epe_rest:.3e}, raw EPE delta {diff.mean().item():.3e}")
-        assert flipped.float().mean().item() < 5e-3 and epe_rest < 1e-3
+        assert flipped.float().mean().item() < 5e-4 and epe_rest < 1e-3  # (measured: no flipped pixel)
 
 
 @pytest.mark.parametrize("H,W,intr", [(384, 1280, (721.54, 721.54, 621.0, 187.5)), (512, 640, (320.0, 320.0, 320.0, 240.0))])
@@ -763,7 +763,8 @@ def test_full_codd_parity_with_autotuned_launch_configurations():
                 og = est.consistent_online_depth_estimation(img[:, f].to(DEV).contiguous(), r_img[:, f].to(DEV).contiguous(),
                                                             metas, sg)
                 d = (og["pred_disp"].cpu() - oo["pred_disp"]).abs()
-                assert d.median().item() < 1e-4 and (d > 1e-2).float().mean().item() < 5e-3, (f, d.mean().item())
+                print(f"tuned frame {f}: mean {d.mean().item():.3e}  >1e-2 px: {(d > 1e-2).float().mean().item():.2e}")
+                assert d.median().item() < 1e-4 and (d > 1e-2).float().mean().item() < 2e-3, (f, d.mean().item())
                 assert d[d <= 1e-2].mean().item() < 1e-3
     finally:
         ops.enable_autotune(False)
