@@ -271,9 +271,15 @@ class SplitTensor:
         self.bt, self.bl, self.hp, self.wp, self.c8, self.terms = bt, bl, hp, wp, c8, terms
 
 
+def _split_rows(H):
+    """Image rows of a shared split tensor: enough for the row overhang of EVERY instantiated tile height
+    (4, 5, 6, 8, 9, 10, 12, 16 rows: ceil(H / th) * th <= H + th - 1)."""
+    return max(-(-H // th) * th for th in (4, 5, 6, 8, 9, 10, 12, 16))
+
+
 def split_input(x, x2=None, border=0, c8=None, hp=None, wp=None, out=None):
     """codd_split_bf16 of (x | x2) with a zero border of ``border`` pixels (int or (top, left)); hp / wp default to
-    the size that serves every instantiated tile (rows up to 16, 32-pixel columns) of a stride-1 'same' convolution
+    the size that serves every instantiated tile (4 ... 16 rows, 32-pixel columns) of a stride-1 'same' convolution
     whose padding does not exceed the border.  Returns None outside the split / bf16 precision modes."""
     terms = _TERMS.get(CONV_PRECISION, 0)
     if not terms:
@@ -289,7 +295,7 @@ def split_input(x, x2=None, border=0, c8=None, hp=None, wp=None, out=None):
         return out
     bt, bl = (border, border) if isinstance(border, int) else border
     c8 = -(-(C0 + C1) // 32) * 4 if c8 is None else c8  # whole 32-channel chunks
-    hp = 2 * bt + -(-H // 16) * 16 if hp is None else hp
+    hp = 2 * bt + _split_rows(H) if hp is None else hp
     wp = 2 * bl + -(-W // 32) * 32 if wp is None else wp
     buf = torch.empty(lib.codd_split_bf16_bytes(B, c8, hp, wp, terms), device=xs.buf.device, dtype=torch.uint8)
     _abi.check(lib.codd_split_bf16(_view(xs), C0, _view(x2), C1, B, H, W, bt, bl, c8, hp, wp, terms, buf.data_ptr(),
@@ -314,7 +320,7 @@ def split_buffer(key, B, C, H, W, border=0, device=None):
     st = _SPLIT_BUFFERS.get(k)
     if st is None:
         c8 = -(-C // 32) * 4
-        hp, wp = 2 * bt + -(-H // 16) * 16, 2 * bl + -(-W // 32) * 32
+        hp, wp = 2 * bt + _split_rows(H), 2 * bl + -(-W // 32) * 32
         buf = torch.zeros(lib.codd_split_bf16_bytes(B, c8, hp, wp, terms), device=device, dtype=torch.uint8)
         st = _SPLIT_BUFFERS[k] = SplitTensor(buf, B, C, H, W, bt, bl, hp, wp, c8, terms)
     return st
