@@ -282,7 +282,11 @@ class RAFT3D(nn.Module):
         self.update_block = BasicUpdateBlock(hidden_dim=128)
 
     def context(self, image):
-        return self.cnet[1](self.cnet[0](image))
+        # exact-fp32 convolutions (ops.stage policy): the context features enter every one of the 16 updates, and their
+        # split-bf16 rounding (1e-5 relative) was what moved near-camera points across pixel boundaries in the splat --
+        # 63 flipped pixels at 640x512 with the context network on split-bf16, none with it on fp32
+        with ops.stage("context"):
+            return self.cnet[1](self.cnet[0](image))
 
     # -- side-stream prefetch ------------------------------------------------------------------
     # fnet(image) (needed before the correlation pyramid) and cnet(image) (only needed by the NEXT

@@ -207,7 +207,7 @@ def set_conv_precision(mode):
 # north-star budget -- and its arg-min / arg-max selections flip for ~1.5 % of the pixels; the stereo network
 # (7 % of the frame's conv FLOPs) therefore stays on the exact-fp32 kernels, everything else (RAFT3D encoders and the
 # 16 update iterations, Fusion: 93 % of the FLOPs, O(1) feature scales, smooth outputs) runs split-bf16.
-_STAGE_PRECISION = dict(stereo="fp32")
+_STAGE_PRECISION = dict(stereo="fp32", context="fp32")
 
 
 class stage:

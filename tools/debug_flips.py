@@ -11,6 +11,18 @@ est = est.to("cuda:0")
 img, r_img, _ = synth.stereo_sequence(H, W, MF)
 metas = synth.default_metas(H, W, img_shape=img_shape, intrinsics=intr)
 ops.enable_autotune(True, shipped=True)
+def fp32(fn):
+    def w(*a, **k):
+        with ops.stage("stereo"):  # the stage name whose policy is exact fp32
+            return fn(*a, **k)
+    return w
+r3 = est.motion.raft3d
+for what in sys.argv[1:]:
+    if what in ("fp32", "split", "bf16"): ops.set_conv_precision(what)
+    elif what == "fnet": r3.fnet.forward = fp32(r3.fnet.forward)
+    elif what == "cnet": r3.context = fp32(r3.context)
+    elif what == "update": r3.update_block.run = fp32(r3.update_block.run)
+    elif what == "fusion": est.fusion.memory_query = fp32(est.fusion.memory_query)
 runner = FrameRunner(est, metas[0], use_graph=False)
 for f in range(MF):
     d = runner.step(img[:, f].to("cuda:0").contiguous(), r_img[:, f].to("cuda:0").contiguous()).cpu()
