@@ -392,7 +392,7 @@ def main():
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"split": "f32 (split-bf16 MFMA operands, f32 accumulate; HITNet exact f32)", "fp32": "f32",
+            "dtype": {"split": "f32 (split-bf16 MFMA operands, f32 accumulate; HITNet + context network exact f32)", "fp32": "f32",
                       "bf16": "bf16 (MFMA operands; f32 accumulate, f32 everywhere outside the convolutions)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": ("HITNetMF stereo-only" if args.stereo_only else
