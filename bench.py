@@ -38,6 +38,38 @@ RAW_H, RAW_W = 540, 960
 PAD_H, PAD_W = 576, 960
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md chip-level parameters
 BF16_MATRIX_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (same table)
+HBM_PEAK_GBS = 8000.0  # HBM3E (same table)
+
+
+def _hbm_specs():
+    """HBM-bound kernels of the path -> ALGORITHMIC bytes of one call from its C-ABI arguments
+    (fp32 words; every operand read once, every result written once)."""
+    def costvol(a):  # L, R, B, C, Ht, Wt, Wr, D, ...: reads both tile-feature maps, writes (cost, d)
+        B, C, Ht, Wt, Wr = a[2], a[3], a[4], a[5], a[6]
+        return 4 * B * (C * Ht * Wt + C * Ht * Wr + 2 * Ht * Wt)
+
+    def tile_warp(a):  # fl, fr, B, C, Ht, Wt, hyp0, hyp1, nhyp, ...: both feature maps once for all hypothesis sets
+        B, C, Ht, Wt, nh = a[2], a[3], a[4], a[5], a[8]
+        return 4 * B * (2 * C * 16 * Ht * Wt + nh * (3 + 64) * Ht * Wt)
+
+    def lookup(a):  # ..., B, h, w, ...: 4 levels x 8x8 integer taps read, 196 features + 9 motion channels written
+        B, h, w = a[7], a[8], a[9]
+        return 4 * B * h * w * (4 * 64 + 196 + 9 + 3 + 7 + 2)
+
+    def splat(a):  # T, depth, HT, WT, oy, ox, ds, featA, CA, featB, CB, with_flow, B, H, W, ...
+        HT, WT, ds, CA, CB, wf, B, H, W = a[2], a[3], a[6], a[8], a[10], a[11], a[12], a[13], a[14]
+        n = -(-HT // ds) * -(-WT // ds)
+        C = CA + CB + (3 if wf else 0)
+        return 4 * B * (n * (1 + 7 + C) + (C + 1) * H * W)
+
+    def cvx(a):  # data, mask, B, h, w, dim, mode, out
+        B, h, w, D = a[2], a[3], a[4], a[5]
+        return 4 * B * h * w * (576 + D + 64 * D)
+
+    return {"codd_tile_costvol_argmin": ("costvol_argmin (S3+S4)", costvol), "codd_tile_warp_cost": ("tile_warp (S6)", tile_warp),
+            "codd_raft_geometry_lookup_xs": ("corr_lookup + geometry (M4+M5)", lookup),
+            "codd_raft_geometry_lookup": ("corr_lookup + geometry (M4+M5)", lookup),
+            "codd_splat": ("splat (M9: project+count+reserve+fill+gather)", splat), "codd_cvx_upsample": ("cvx_upsample (M8)", cvx)}
 
 
 _T0 = time.time()
@@ -67,6 +99,9 @@ def parse():
                          "tested at 1e-3 px); fp32 = exact-fp32 kernels everywhere; bf16 = bf16 operands / fp32 "
                          "accumulate everywhere (BASELINE.json configs[4])")
     ap.add_argument("--stereo-only", action="store_true")
+    ap.add_argument("--fp32-steps", type=int, default=30,
+                    help="after the timed region (rank 0, N = 1, split precision only): time this many steady-state frames "
+                         "with EVERY convolution on the exact-fp32 kernels and report them as fp32_exact_fps (0 = skip)")
     ap.add_argument("--tune-db", default=None,
                     help="JSON file of tuned launch configurations: loaded if it exists (no tuning launches, e.g. under "
                          "a profiler), written at the end otherwise")
@@ -118,6 +153,23 @@ def conv_roofline(runner, frames, device):
     ops._launch_conv = timed
     serial_before = ops.Fork.serial
     ops.Fork.serial = True  # one launch at a time, so that every event pair brackets exactly one kernel
+    # the HBM-bound kernels of the same frame: event brackets around their C-ABI entry points
+    from codd_amd import _abi
+    lib = _abi.load()
+    hbm_recs, saved = [], {}
+    for fname, (label, nbytes) in _hbm_specs().items():
+        fn = getattr(lib, fname)
+        saved[fname] = fn
+
+        def wrapped(*a, _fn=fn, _label=label, _nbytes=nbytes):
+            s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s_.record(torch.cuda.current_stream(device))
+            rc = _fn(*a)
+            e_.record(torch.cuda.current_stream(device))
+            hbm_recs.append((_label, s_, e_, float(_nbytes(a))))
+            return rc
+
+        setattr(lib, fname, wrapped)
     try:
         l, r = frames
         runner.eager_frame_on_static_state(l, r)
@@ -125,6 +177,15 @@ def conv_roofline(runner, frames, device):
     finally:
         ops._launch_conv = orig
         ops.Fork.serial = serial_before
+        for fname, fn in saved.items():
+            setattr(lib, fname, fn)
+    hbm = {}
+    for label, s_, e_, nb in hbm_recs:
+        c = hbm.setdefault(label, [0, 0.0, 0.0])
+        c[0] += 1; c[1] += s_.elapsed_time(e_); c[2] += nb
+    hbm = {k: dict(calls_per_frame=v[0], ms_per_frame=round(v[1], 4), algorithmic_mb_per_frame=round(v[2] / 1e6, 2),
+                   achieved_gbs=round(v[2] / 1e6 / v[1], 1), frac_of_hbm_peak=round(v[2] / 1e6 / v[1] / HBM_PEAK_GBS, 4))
+           for k, v in hbm.items() if v[1] > 0}
     t_ms = sum(r[0].elapsed_time(r[1]) for r in recs)
     flops = sum(r[2] for r in recs)
     fam = {}  # kernel family -> [launches, ms, algorithmic flop, issued MFMA flop]
@@ -140,7 +201,7 @@ def conv_roofline(runner, frames, device):
         for key, (n, ms, f) in sorted(by.items(), key=lambda kv: -kv[1][1]):
             log("conv B%d Cin%-4d Cout%-4d k%dx%d out %3dx%-3d s%d m%d terms%d : n=%3d  %7.3f ms  %6.1f us/launch  %5.1f TF"
                 % (*key, n, ms, ms / n * 1e3, f / ms / 1e9))
-    return dict(launches=len(recs), time_ms=t_ms, gflop=flops / 1e9,
+    return dict(launches=len(recs), time_ms=t_ms, gflop=flops / 1e9, hbm=hbm,
                 families={k: dict(launches=v[0], ms=round(v[1], 3), gflop=round(v[2] / 1e9, 2),
                                   issued_gflop=round(v[3] / 1e9, 2)) for k, v in fam.items()})
 
@@ -268,10 +329,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     import torch.distributed as dist
     use_dist = world > 1 or "RANK" in os.environ  # launched by torch.distributed.run -> RCCL even at N = 1
+    if world != args.gpus and "RANK" in os.environ:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: one rank per GPU is the contract")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(f"bench.py --gpus {args.gpus} must be launched by torch.distributed.run (one rank per GPU)")
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     pin_rank_to_cores(local, max(world, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
@@ -335,6 +401,13 @@ def main():
                            lambda d, g: seqm.update_disparity_device(d, g, (raw_h, raw_w)), seqm.row, device, use_dist)
 
     log(f"timed region done: {dt:.3f} s")
+    # every rank reports in: (rank, local GPU index, frames it timed) gathered over RCCL -> ranks_seen in the JSON line
+    ranks_seen = [[rank, local, args.steps]]
+    if use_dist:
+        mine = torch.tensor([rank, local, args.steps], device=device, dtype=torch.int64)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        ranks_seen = [t.tolist() for t in allr]
     if args.tune_db and rank == 0:  # (re)write: shapes met for the first time in this run were tuned on the fly
         _ops_tune.save_tune_db(args.tune_db)
     if os.environ.get("CODD_BENCH_VERBOSE"):
@@ -343,6 +416,7 @@ def main():
                 log("autotune %-34s heuristic %s %.1f us -> %s %.1f us" % (r[0], r[1], r[2] or -1, r[3], r[4]))
     roof = None
     cpu = None
+    fp32_fps = None
     if rank == 0:
         try:
             l, r, _ = frame(1)
@@ -358,29 +432,57 @@ def main():
             dom = max(fams, key=lambda k_: fams[k_]["issued_gflop"])
             fd = fams[dom]
             peak = FP32_MATRIX_PEAK_TFLOPS if dom == "fp32" else BF16_MATRIX_PEAK_TFLOPS
-            ach = fd["issued_gflop"] / fd["ms"]  # GFLOP/ms = TFLOP/s of MFMA work issued
+            ach = fd["gflop"] / fd["ms"]  # GFLOP/ms = TFLOP/s of ALGORITHMIC direct-convolution work
+            issued = fd["issued_gflop"] / fd["ms"]  # MFMA work issued (3 bf16 MFMAs per product on the split path)
+            # `traffic` needs the PMC counters of a separate rocprofv3 pass and cannot be measured from inside this
+            # process: the figure of the newest committed capture is quoted with its source, else null
             traffic, tsrc = None, None
-            tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_conv_traffic.json")
-            if os.path.exists(tp):  # HBM-side bytes per launch of that family from the committed rocprofv3 PMC passes
-                tj = json.load(open(tp))
+            pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+            for tname in sorted((f for f in os.listdir(pdir) if f.endswith("_conv_traffic.json")), reverse=True):
+                tj = json.load(open(os.path.join(pdir, tname)))
                 if tj.get("family") == dom:
-                    traffic, tsrc = round(tj["traffic_bytes_per_launch"]), "profiles/r02_conv_traffic.json: " + tj["correction"]
+                    traffic, tsrc = round(tj["traffic_bytes_per_launch"]), f"profiles/{tname} (committed rocprofv3 --pmc passes, not this run): " + tj["correction"]
+                    break
             kern = {"split_bf16": "conv_bf16_kernel<*, TERMS=3> (split-bf16: 3 bf16 MFMAs per product, fp32 accumulate)",
                     "bf16": "conv_bf16_kernel<*, TERMS=1> (bf16 operands, fp32 accumulate)",
                     "fp32": "conv_mfma_kernel<*> + conv_quad_kernel<*> (exact fp32 MFMA)"}[dom]
             roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+                        issued_tflops=round(issued, 2), issued_frac=round(issued / peak, 4),
                         traffic=traffic, traffic_unit="bytes/launch (PMC, separate rocprofv3 passes)", traffic_source=tsrc,
-                        kernel=kern, basis="MFMA FLOPs issued by the family's launches of one frame / their summed HIP-event "
-                        "durations (algorithmic direct-conv FLOPs x MFMA terms per product)",
+                        kernel=kern, basis="ALGORITHMIC direct-convolution FLOPs (2 Cin Cout kh kw Hout Wout) of the family's "
+                        "launches of one frame / their summed HIP-event durations; issued_* counts the MFMA work actually "
+                        "issued (x3 bf16 MFMAs per product on the split path)",
                         launches_per_frame=fd["launches"], ms_per_frame=fd["ms"],
-                        algorithmic_tflops=round(fd["gflop"] / fd["ms"], 2),
-                        algorithmic_frac_of_fp32_matrix_peak=round(fd["gflop"] / fd["ms"] / FP32_MATRIX_PEAK_TFLOPS, 4),
+                        algorithmic_frac_of_fp32_matrix_peak=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4),
                         families=fams, conv_launches_per_frame=cr["launches"], conv_gflop_per_frame=round(cr["gflop"], 2),
                         conv_ms_per_frame=round(cr["time_ms"], 3),
-                        whole_conv_algorithmic_tflops=round(cr["gflop"] / cr["time_ms"], 2))
+                        whole_conv_algorithmic_tflops=round(cr["gflop"] / cr["time_ms"], 2),
+                        # the HBM-bound kernels of the same frame against SURVEY.md 8(d)'s algorithmic bytes and the 8 TB/s peak
+                        hbm=dict(peak_gbs=HBM_PEAK_GBS, basis="algorithmic bytes of the call (operands read once, results "
+                                 "written once) / HIP-event duration of the call in the serial eager frame",
+                                 kernels=cr["hbm"]))
         except Exception as e:  # pragma: no cover
             roof = dict(error=repr(e))
         log(f"roofline pass done: {roof}")
+        if world == 1 and args.precision == "split" and args.fp32_steps > 0 and not args.stereo_only and not pipelined:
+            # secondary figure: the same frame with every convolution on the exact-fp32 MFMA kernels (own graph)
+            try:
+                prev = _ops_tune.set_conv_precision("fp32")
+                r32 = FrameRunner(est, metas[0], use_graph=not args.no_graph)
+                for i in range(12):  # frame 0 primes the state, capture, clocks
+                    r32.step(*frame(i)[:2])
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for i in range(args.fp32_steps):
+                    r32.step(*frame(12 + i)[:2])
+                torch.cuda.synchronize(device)
+                fp32_fps = round(args.fp32_steps / (time.perf_counter() - t0), 3)
+                del r32
+            except Exception as e:  # pragma: no cover
+                fp32_fps = repr(e)
+            finally:
+                _ops_tune.set_conv_precision(prev)
+            log(f"fp32-exact pass done: {fp32_fps}")
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline_subprocess(args)
             log("cpu baseline done")
@@ -408,8 +510,11 @@ def main():
                                              sum(1 for r in _ops_tune.AUTOTUNE_LOG if r[1] != r[3]))),
                        "frame_pipeline": ("depth 2: stereo/encoders of frame t+1 overlap motion+fusion of frame t "
                                           "(identical outputs, +1 frame latency)" if pipelined else "off"),
-                       "fps_per_gpu": round(fps / world, 3)},
+                       "fps_per_gpu": round(fps / world, 3),
+                       "ranks_seen": ranks_seen, "frames_timed_all_ranks": sum(r[2] for r in ranks_seen)},
             "epe_vs_synthetic_gt": red["epe"][0],
+            # every convolution on the exact-fp32 kernels (--precision fp32), same frame, shorter run
+            "fp32_exact_fps": fp32_fps,
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

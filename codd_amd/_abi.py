@@ -34,7 +34,7 @@ class ConvParams(C.Structure):
         ("xs", C.c_void_p), ("xs_c8", C.c_int), ("xs_hp", C.c_int), ("xs_wp", C.c_int),
         ("xs_bt", C.c_int), ("xs_bl", C.c_int), ("xs_o8", C.c_int),
         ("xso", C.c_void_p), ("xso_c8", C.c_int), ("xso_hp", C.c_int), ("xso_wp", C.c_int), ("xso_bt", C.c_int),
-        ("xso_bl", C.c_int), ("xso_o8", C.c_int), ("xso_terms", C.c_int),
+        ("xso_bl", C.c_int), ("xso_o8", C.c_int), ("xso_terms", C.c_int), ("ksplit", C.c_int),
     ]
 
 
@@ -97,7 +97,7 @@ SIGNATURES = {
     "codd_fusion_blend": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 5  # CODD_ABI_VERSION of include/codd_hip.h
+ABI_VERSION = 6  # CODD_ABI_VERSION of include/codd_hip.h
 _lib = None
 MISSING = []
 
@@ -117,19 +117,26 @@ def load():
         return _lib
     path = lib_path()
     # One process at a time decides / rebuilds (torchrun starts every rank at once on a fresh checkout); a rebuild
-    # that is needed but fails is an error -- a stale library is never loaded silently against newer sources.
-    import fcntl
-    with open(os.path.join(os.path.dirname(path), ".build.lock"), "w") as lock:
-        fcntl.flock(lock, fcntl.LOCK_EX)
+    # that is needed but fails is an error -- a stale library is never loaded silently against newer sources.  The
+    # lock file is only opened when a build is needed, so a current library loads from a read-only install.
+    if not os.path.exists(path) or _build.needs_build():
+        import fcntl
         try:
-            if not os.path.exists(path) or _build.needs_build():
-                try:
-                    _build.build(verbose=False)
-                except Exception as e:  # pragma: no cover
-                    raise CoddHipError(f"libcodd_hip.so is missing or older than its sources and the rebuild "
-                                       f"failed: {e}") from e
-        finally:
-            fcntl.flock(lock, fcntl.LOCK_UN)
+            lock = open(os.path.join(os.path.dirname(path), ".build.lock"), "w")
+        except OSError as e:
+            raise CoddHipError(f"libcodd_hip.so is missing or older than its sources and {os.path.dirname(path)} is "
+                               f"not writable: {e}") from e
+        with lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if not os.path.exists(path) or _build.needs_build():  # (another rank may have built it meanwhile)
+                    try:
+                        _build.build(verbose=False)
+                    except Exception as e:  # pragma: no cover
+                        raise CoddHipError(f"libcodd_hip.so is missing or older than its sources and the rebuild "
+                                           f"failed: {e}") from e
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         try:

@@ -49,14 +49,14 @@ extern "C" int codd_conv2d_pack_weights_bf16(const float* w, void* wpacked, int 
   return CODD_OK;
 }
 
-template <int PGW, int CGW, int A, int B, int TERMS, int OUTF>
+template <int PGW, int CGW, int A, int B, int TERMS, int OUTF, int KS>
 static int launch_b(const ConvB& k, size_t lds, int grid, hipStream_t s) {
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_bf16_kernel<PGW, CGW, A, B, TERMS, OUTF>,
+    hipError_t e = hipFuncSetAttribute((const void*)conv_bf16_kernel<PGW, CGW, A, B, TERMS, OUTF, KS>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  conv_bf16_kernel<PGW, CGW, A, B, TERMS, OUTF><<<grid, (PGW * CGW + CONVB_NWP) * 64, lds, s>>>(k);
+  conv_bf16_kernel<PGW, CGW, A, B, TERMS, OUTF, KS><<<grid, (PGW * CGW * KS + CONVB_NWP) * 64, lds, s>>>(k);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }
@@ -71,13 +71,14 @@ int codd_conv2d_bf16(const codd_conv_params* pp, void* stream, int dry_run) {
   const codd_conv_params& p = k.p;
   const int a = cdiv(k.pu, p.pgw), bb = p.mb / p.cgw;
   hipStream_t s = (hipStream_t)stream;
-#define X(PGW, CGW, A, B)                                                                        \
-  if (p.pgw == PGW && p.cgw == CGW && a == A && bb == B)                                         \
+  const int ks = p.ksplit == 2 ? 2 : 1;
+#define X(PGW, CGW, A, B, KS)                                                                    \
+  if (p.pgw == PGW && p.cgw == CGW && a == A && bb == B && ks == KS)                             \
     return dry_run ? CODD_OK                                                                     \
-           : p.xso ? (p.terms == 3 ? launch_b<PGW, CGW, A, B, 3, 1>(k, lds, (int)grid, s)        \
-                                   : launch_b<PGW, CGW, A, B, 1, 1>(k, lds, (int)grid, s))       \
-                   : (p.terms == 3 ? launch_b<PGW, CGW, A, B, 3, 0>(k, lds, (int)grid, s)        \
-                                   : launch_b<PGW, CGW, A, B, 1, 0>(k, lds, (int)grid, s));
+           : p.xso ? (p.terms == 3 ? launch_b<PGW, CGW, A, B, 3, 1, KS>(k, lds, (int)grid, s)    \
+                                   : launch_b<PGW, CGW, A, B, 1, 1, KS>(k, lds, (int)grid, s))   \
+                   : (p.terms == 3 ? launch_b<PGW, CGW, A, B, 3, 0, KS>(k, lds, (int)grid, s)    \
+                                   : launch_b<PGW, CGW, A, B, 1, 0, KS>(k, lds, (int)grid, s));
   CONVB_ALL(X)
 #undef X
   return CODD_EUNSUPPORTED;

@@ -57,7 +57,8 @@ struct ConvB {
 
 constexpr int CONVB_NWP = 4;  // producer waves per workgroup
 constexpr int CONVB_MAXP = 6; // input DMA pieces per producer wave whose source offsets are kept in registers
-// dev ablations (tools/ubench/convb_ablate.hip): drop the weight DMA / the input loads
+// dev ablations (tools/ubench/convb_ablate.hip): drop the weight DMA / the input loads; CONVB_NO_BARRIER (with
+// CONVB_NO_PRODUCER) / CONVB_NO_LDSREAD time the consumer loop without its chunk barriers / its fragment reads
 #ifdef CONVB_NO_DMA
 #define CONVB_DMA_N(n) 0
 #else
@@ -100,10 +101,13 @@ static inline int convb_geometry(const codd_conv_params* pp, ConvB& k, size_t& l
   k.cout_eff = p.store_mode ? 4 * p.Cout : p.Cout;
   k.ncog = cdiv(k.cout_eff, k.nco);
   // ring of (weights + input) buffers + entry table: three deep when that fits the 160 KiB of a CU, else two
-  const size_t per = ((size_t)k.wslots + (size_t)k.ibuf16) * 16, tab = ((size_t)k.nk + 1) * 16;
+  const size_t per = ((size_t)k.wslots + (size_t)k.ibuf16) * 16, tab = ((size_t)k.nk + 2) * 16;
   k.nring = (k.nchunks >= 3 && 3 * per + tab <= 160 * 1024) ? 3 : 2;
   lds = k.nring * per + tab;
   if (lds > 160 * 1024) return CODD_EUNSUPPORTED;
+  if (p.ksplit < 0 || p.ksplit > 2) return CODD_EINVAL;
+  // k-split pairs exchange half of their accumulator tiles through the (then idle) ring: 1 KiB per tile and wave
+  if (p.ksplit == 2 && (size_t)cdiv(k.pu, p.pgw) * p.mb * p.pgw * 1024 > k.nring * per) return CODD_EUNSUPPORTED;
   // DMA pieces a producer wave issues per chunk; nring - 1 chunks are in flight and vmcnt counts to 63
   if ((k.nring - 1) * (cdiv(k.wslots >> 6, CONVB_NWP) + cdiv(k.ibuf16 >> 6, CONVB_NWP)) > 56) return CODD_EUNSUPPORTED;
   k.xplane = p.xs_c8 * p.xs_hp * p.xs_wp;
@@ -184,9 +188,10 @@ struct ConvbSched {
   }
 };
 
-template <int PGW, int CGW, int A, int B, int TERMS, int OUTF>
-__global__ __launch_bounds__((PGW * CGW + CONVB_NWP) * 64) void conv_bf16_kernel(const ConvB k) {
-  constexpr int NWC = PGW * CGW;          // consumer waves
+template <int PGW, int CGW, int A, int B, int TERMS, int OUTF, int KS>
+__global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_kernel(const ConvB k) {
+  constexpr int NWT = PGW * CGW;          // accumulator-tile sets (one per consumer wave, or per k-split pair)
+  constexpr int NWC = NWT * KS;           // consumer waves
   constexpr int NTP = CONVB_NWP * 64;     // producer threads
   constexpr int NPL = TERMS == 1 ? 1 : 2; // precision planes
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
@@ -219,7 +224,7 @@ __global__ __launch_bounds__((PGW * CGW + CONVB_NWP) * 64) void conv_bf16_kernel
   if (wave >= NWC) {
     // =============================== producers ===============================
     const int pt = tid - NWC * 64;
-    for (int e = pt; e < (k.nk + 1) * 4; e += NTP) {  // one spare row: the consumers fetch one k-step ahead
+    for (int e = pt; e < (k.nk + 2) * 4; e += NTP) {  // spare rows: the consumers fetch one (k-split: two) k-steps ahead
       const int tap = e / k.noct, oct = e - tap * k.noct;
       int off = 0;
       if (e < k.nk * 4 && tap < k.ntaps) {
@@ -296,7 +301,10 @@ __global__ __launch_bounds__((PGW * CGW + CONVB_NWP) * 64) void conv_bf16_kernel
 
   // ================================= consumers =================================
   const int g = lane >> 4, j = lane & 15;
-  const int cgi = wave % CGW, pgi = wave / CGW;
+  // KS = 2: waves w and w + NWT (same SIMD: a workgroup's waves cycle over the four SIMDs) share the tile set of
+  // w and take alternate k-steps of every chunk
+  const int kpart = KS == 1 ? 0 : wave / NWT, wset = KS == 1 ? wave : wave - kpart * NWT;
+  const int cgi = wset % CGW, pgi = wset / CGW;
   f32x4 acc[A][B];
 #pragma unroll
   for (int a = 0; a < A; ++a)
@@ -319,11 +327,11 @@ __global__ __launch_bounds__((PGW * CGW + CONVB_NWP) * 64) void conv_bf16_kernel
   struct Frag { bf16x8 ah[B], al[B], bh[A], bl[A]; };
   // reads the fragments of k-step KS with the entry offset fetched one load earlier, and fetches the next offset
   // (the table has one spare row), so that no ds_read_b128 waits for a dependent table read
-#define BF_LOAD(F, KS)                                                                                    \
+#define BF_LOAD(F, KSTP)                                                                                   \
   {                                                                                                       \
     const int eo_ = eo;                                                                                   \
-    eo = etab[((KS) + 1) * 4 + g];                                                                        \
-    const uint4* wp_ = wb + woff + (KS) * wstep;                                                          \
+    eo = etab[((KSTP) + KS) * 4 + g];                                                                   \
+    const uint4* wp_ = wb + woff + (KSTP) * wstep;                                                          \
     _Pragma("unroll") for (int m_ = 0; m_ < B; ++m_) {                                                    \
       F.ah[m_] = __builtin_bit_cast(bf16x8, wp_[m_ * 16]);                                                \
       if (TERMS == 3) F.al[m_] = __builtin_bit_cast(bf16x8, wp_[k.wplane16 + m_ * 16]);                   \
@@ -361,28 +369,59 @@ __global__ __launch_bounds__((PGW * CGW + CONVB_NWP) * 64) void conv_bf16_kernel
     // software pipeline over the k-steps, two register sets, no branch inside the loop body (hipcc can then count
     // the outstanding LDS reads instead of draining them): the fragments of step s+1 are in flight while the MFMAs
     // of step s issue.  A clamped (redundant) load replaces the conditional one at the end of the chunk.
-    Frag f0, f1;
-    int eo = etab[g];
-    BF_LOAD(f0, 0);
-    int ks = 0;
-    for (; ks + 1 < k.nk; ks += 2) {
-      BF_LOAD(f1, ks + 1);
-      BF_MFMA(f0);
-#ifndef CONVB_NO_SCHED
-      ConvbSched<0, NRD, NMF>::run();
+    // k-split: this wave's k-steps are kfirst, kfirst + 2, ... (the odd one of an odd count alternates between the
+    // partners chunk by chunk)
+    const int kfirst = KS == 1 ? 0 : ((kpart + ch) & 1);
+    if (KS == 1 || kfirst < k.nk) {
+      const int mylast = KS == 1 ? klast : kfirst + ((klast - kfirst) / KS) * KS;
+      Frag f0, f1;
+      int eo = etab[kfirst * 4 + g];
+      BF_LOAD(f0, kfirst);
+      int ks = kfirst;
+      for (; ks + KS < k.nk; ks += 2 * KS) {
+#ifdef CONVB_NO_LDSREAD
+        if (ch == 0 && ks == kfirst)
 #endif
-      BF_LOAD(f0, ks + 2 < klast ? ks + 2 : klast);
-      BF_MFMA(f1);
+        BF_LOAD(f1, ks + KS);
+        BF_MFMA(f0);
 #ifndef CONVB_NO_SCHED
-      ConvbSched<0, NRD, NMF>::run();
+        ConvbSched<0, NRD, NMF>::run();
 #endif
+#ifdef CONVB_NO_LDSREAD
+        if (ch == 0 && ks == kfirst)
+#endif
+        BF_LOAD(f0, ks + 2 * KS < mylast ? ks + 2 * KS : mylast);
+        BF_MFMA(f1);
+#ifndef CONVB_NO_SCHED
+        ConvbSched<0, NRD, NMF>::run();
+#endif
+      }
+      if (ks < k.nk) BF_MFMA(f0);
     }
-    if (ks < k.nk) BF_MFMA(f0);
+#ifndef CONVB_NO_BARRIER
     __syncthreads();  // every consumer is done with buffer ch & 1; the producers have filled the other one
+#endif
   }
 #endif
 #undef BF_LOAD
 #undef BF_MFMA
+  if constexpr (KS == 2) {
+    // partial sums of the pair: tile t = a * B + m is finished (and stored) by the partner with kpart == (t & 1), so
+    // each wave ships half of its tiles through the ring (idle now: the last chunk's barrier is behind us, the
+    // producers have retired) and runs half of the epilogue
+    f32x4* red = (f32x4*)smem4 + (size_t)wset * (A * B) * 64 + lane;
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+      for (int m = 0; m < B; ++m)
+        if (((a * B + m) & 1) != kpart) red[(a * B + m) * 64] = acc[a][m];
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < A; ++a)
+#pragma unroll
+      for (int m = 0; m < B; ++m)
+        if (((a * B + m) & 1) == kpart) acc[a][m] += red[(a * B + m) * 64];
+  }
 
 #ifdef CONVB_NO_EPILOGUE
   {  // dev ablation: one store per lane keeps the accumulators alive
@@ -413,6 +452,7 @@ __global__ __launch_bounds__((PGW * CGW + CONVB_NWP) * 64) void conv_bf16_kernel
       const bool inb = u < k.pu && oy < p.Hout && ox < p.Wout;
 #pragma unroll
       for (int m = 0; m < B; ++m) {
+        if (KS == 2 && ((a * B + m) & 1) != kpart) continue;  // the k-split partner's tile
         const int co0 = (cog * CGW * B + cgi * B + m) * 16 + 4 * g;  // this lane's first channel
         f32x4 v = acc[a][m];
         if (p.bias) {
@@ -459,6 +499,7 @@ __global__ __launch_bounds__((PGW * CGW + CONVB_NWP) * 64) void conv_bf16_kernel
     const int pix = oy * p.Wout + ox;
 #pragma unroll
     for (int m = 0; m < B; ++m) {
+      if (KS == 2 && ((a * B + m) & 1) != kpart) continue;  // the k-split partner's tile
       const int co = (cog * CGW * B + cgi * B + m) * 16 + j;
       if (co >= k.cout_eff) continue;
       f32x4 v = acc[a][m];
@@ -498,29 +539,37 @@ __global__ __launch_bounds__((PGW * CGW + CONVB_NWP) * 64) void conv_bf16_kernel
   }
 }
 
-// ---- instantiation list: X(PGW, CGW, A, B), each for TERMS = 1 and 3 -------------------------------------------
+// ---- instantiation list: X(PGW, CGW, A, B, KS), each for TERMS = 1 and 3 and both output forms ----------------
 //   (2,2,5,2): 9/10-unit tiles x 64 channels (the 72x120 GRU maps: 256 workgroups of 144 px x 64 co)
 //   (4,1,4,4) / (4,1,4,2) / (4,1,4,1): 16-unit tiles (8 x 32 px) x 64 / 32 / 16 channels
 //   (4,1,2,2) / (4,1,2,1): 8-unit tiles (4 x 32 or 8 x 16 px) x 32 / 16 channels (small maps)
 //   (4,1,8,1): 32-unit tiles (16 x 32 px) x 16 channels (full-resolution 16-channel layers)
-#define CONVB_GROUP_A(X) X(2, 2, 5, 2)
-#define CONVB_GROUP_B(X) X(4, 1, 4, 4)
-#define CONVB_GROUP_C(X) X(4, 1, 4, 2)
-#define CONVB_GROUP_D(X) X(4, 1, 4, 1) X(4, 1, 8, 1)
-#define CONVB_GROUP_E(X) X(4, 1, 2, 2) X(4, 1, 2, 1)
 //   (4,1,3,4) / (4,1,3,2): 12-unit tiles (12 x 16 or 6 x 32 px) x 64 / 32 channels: 192 workgroups = ONE dispatch
 //   round on a 72x120 map with 256 / 128 output channels (the 16-unit tiles give 136-160, the 10-unit ones 216-256
 //   with a worse LDS-read : MFMA ratio)
-#define CONVB_GROUP_F(X) X(4, 1, 3, 4) X(4, 1, 3, 2)
-#define CONVB_ALL(X) \
-  CONVB_GROUP_A(X) CONVB_GROUP_B(X) CONVB_GROUP_C(X) CONVB_GROUP_D(X) CONVB_GROUP_E(X) CONVB_GROUP_F(X)
-#define CONVB_DECLARE(PGW, CGW, A, B)                                                        \
-  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, 0>(const ConvB);      \
-  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 0>(const ConvB);      \
-  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, 1>(const ConvB);      \
-  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 1>(const ConvB);
-#define CONVB_DEFINE(PGW, CGW, A, B)                                                         \
-  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, 0>(const ConvB);             \
-  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 0>(const ConvB);             \
-  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, 1>(const ConvB);             \
-  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 1>(const ConvB);
+//   KS = 2 (k-split pairs, 8 consumer waves = 2 per SIMD; needs <= 168 registers): the tiles of the update block
+//   (4,2,4,2) / (4,2,3,2): 16- / 12-unit tiles x 64 channels on 8 consumer waves that split the TILE instead
+#define CONVB_GROUP_A(X) X(2, 2, 5, 2, 1)
+#define CONVB_GROUP_B(X) X(4, 1, 4, 4, 1)
+#define CONVB_GROUP_C(X) X(4, 1, 4, 2, 1)
+#define CONVB_GROUP_D(X) X(4, 1, 4, 1, 1) X(4, 1, 8, 1, 1)
+#define CONVB_GROUP_E(X) X(4, 1, 2, 2, 1) X(4, 1, 2, 1, 1)
+#define CONVB_GROUP_F(X) X(4, 1, 3, 4, 1) X(4, 1, 3, 2, 1)
+#define CONVB_GROUP_G(X) X(2, 2, 5, 2, 2)
+#define CONVB_GROUP_H(X) X(4, 1, 4, 2, 2)
+#define CONVB_GROUP_I(X) X(4, 1, 3, 2, 2) X(4, 1, 3, 4, 2)
+#define CONVB_GROUP_J(X) X(4, 2, 4, 2, 1)
+#define CONVB_GROUP_K(X) X(4, 2, 3, 2, 1)
+#define CONVB_ALL(X)                                                                                   \
+  CONVB_GROUP_A(X) CONVB_GROUP_B(X) CONVB_GROUP_C(X) CONVB_GROUP_D(X) CONVB_GROUP_E(X) CONVB_GROUP_F(X) \
+  CONVB_GROUP_G(X) CONVB_GROUP_H(X) CONVB_GROUP_I(X) CONVB_GROUP_J(X) CONVB_GROUP_K(X)
+#define CONVB_DECLARE(PGW, CGW, A, B, KS)                                                        \
+  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, 0, KS>(const ConvB);      \
+  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 0, KS>(const ConvB);      \
+  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, 1, KS>(const ConvB);      \
+  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 1, KS>(const ConvB);
+#define CONVB_DEFINE(PGW, CGW, A, B, KS)                                                         \
+  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, 0, KS>(const ConvB);             \
+  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 0, KS>(const ConvB);             \
+  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, 1, KS>(const ConvB);             \
+  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 1, KS>(const ConvB);

@@ -92,20 +92,16 @@ class ConsistentOnlineDynamicDepth(nn.Module):
             seqm = SequenceMetrics(img_meta[0], img.device)
         outputs = []
         # ``use_graph`` (set by the CLI unless --no-graph): steady-state frames run by hipGraph replay through
-        # codd_amd.runtime.FrameRunner (one capture per input shape and camera, reused across videos) instead of ~900
-        # eager launches per frame.  The scene-flow columns need the per-frame SE3 field, so that evaluation stays eager.
+        # codd_amd.runtime.FrameRunner (one capture per batch / input shape / camera / launch policy, reused across
+        # videos) instead of ~700 eager launches per frame; the scene-flow columns read the per-frame SE3 field from
+        # the graph's static output (runner.last["Ts"]).
         runner = None
-        if getattr(self, "use_graph", False) and self.motion is not None and self.fusion is not None and gt_dc is None:  # noqa: E501
-            from .runtime import FrameRunner
-            rkey = (tuple(img.shape[-2:]), tuple(img_meta[0].get("intrinsics", ())), img.device)
-            cache = self.__dict__.setdefault("_runners", {})
-            runner = cache.get(rkey)
-            if runner is None:
-                runner = cache[rkey] = FrameRunner(self, img_meta, use_graph=True)
+        if getattr(self, "use_graph", False) and self.motion is not None and self.fusion is not None:
+            runner = self._frame_runner(img, img_meta)
             runner.reset()
         for idx, (l_img, r) in enumerate(zip(torch.unbind(img, 1), torch.unbind(r_img, 1))):
             if runner is not None:
-                out = dict(pred_disp=runner.step(l_img.contiguous(), r.contiguous()).clone())
+                out = dict(pred_disp=runner.step(l_img.contiguous(), r.contiguous()).clone(), **runner.last)
             else:
                 out = self.consistent_online_depth_estimation(l_img.contiguous(), r.contiguous(), img_meta,
                                                               self.inference_state)
@@ -170,10 +166,41 @@ class ConsistentOnlineDynamicDepth(nn.Module):
             with open(out_file.replace(osp.splitext(out_file)[1], ".disp.pred.npz"), "wb") as f:
                 np.savez_compressed(f, disp=disp)
 
+    RUNNER_CACHE = 2  # captured frame graphs kept per model (each owns a private memory pool)
+
+    def _frame_runner(self, img, img_meta):
+        """The FrameRunner (captured hipGraph) for this batch / shape / camera under the CURRENT launch policy.  A graph
+        bakes in the packed-weight images, the conv precision, the tuned launch configurations and the stream plan, so
+        all of them are part of the key (and invalidate_packed() drops the cache): a stale graph would replay reads of
+        freed weight memory.  Least-recently-used entries beyond RUNNER_CACHE are dropped."""
+        from . import ops
+        from .runtime import FrameRunner
+        rkey = (tuple(img.shape[-2:]), int(img.shape[0]), tuple(img_meta[0].get("intrinsics", ())), str(img.device),
+                ops.CONV_PRECISION, bool(ops._AUTOTUNE), bool(ops.Fork.serial), self._weights_token())
+        cache = self.__dict__.setdefault("_runners", OrderedDict())
+        runner = cache.pop(rkey, None)
+        if runner is None:
+            runner = FrameRunner(self, img_meta, use_graph=True)
+        cache[rkey] = runner  # most recently used last
+        while len(cache) > self.RUNNER_CACHE:
+            cache.popitem(last=False)
+        return runner
+
+    def _weights_token(self):
+        """Changes whenever a parameter or buffer is written in place or replaced (load_state_dict, .to(), .data = ...)."""
+        return hash(tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers())))
+
     def invalidate_packed(self):
-        """Drop every cached re-laid-out weight tensor (called by apis.load_checkpoint after a state dict is loaded)."""
+        """Drop every cached re-laid-out weight tensor AND every captured frame graph that points at them (called by
+        apis.load_checkpoint after a state dict is loaded)."""
         from .stereo import invalidate_packed
         invalidate_packed(self)
+        self.__dict__.pop("_runners", None)
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop("_runners", None)  # captured graphs are neither picklable nor copyable
+        return state
 
     def train(self, mode=True):
         """reference model/codd.py:601-612 overrides train(); kept chainable here."""

@@ -229,17 +229,19 @@ class stage:
 
 
 # split-bf16 kernel instantiations (conv_bf16_kernel.h): (pgw, cgw, A, B) and the tiles (rows, units per row) tried
-_B_INST = ((2, 2, 5, 2), (4, 1, 4, 4), (4, 1, 4, 2), (4, 1, 4, 1), (4, 1, 8, 1), (4, 1, 2, 2), (4, 1, 2, 1),
-           (4, 1, 3, 4), (4, 1, 3, 2))
+_B_INST = ((2, 2, 5, 2, 1), (4, 1, 4, 4, 1), (4, 1, 4, 2, 1), (4, 1, 4, 1, 1), (4, 1, 8, 1, 1), (4, 1, 2, 2, 1),
+           (4, 1, 2, 1, 1), (4, 1, 3, 4, 1), (4, 1, 3, 2, 1),
+           # 8 consumer waves (two per SIMD): k-split pairs (ks = 2) and 4x2 wave grids that split the tile
+           (2, 2, 5, 2, 2), (4, 1, 4, 2, 2), (4, 1, 3, 2, 2), (4, 1, 3, 4, 2), (4, 2, 4, 2, 1), (4, 2, 3, 2, 1))
 _B_TILES = {5: ((9, 1), (10, 1), (5, 2)), 4: ((8, 2), (16, 1)), 8: ((16, 2),), 2: ((4, 2), (8, 1)), 3: ((12, 1), (6, 2))}
 
 
 def _bf16_candidates(pc, Hout, Wout, B, taps, terms):
-    """Launch configurations (xb, th, ck, mb, 2, pgw, cgw, terms) of the split-bf16 kernel for this layer, best guess first:
+    """Launch configurations (xb, th, ck, mb, 2, pgw, cgw, terms, ksplit) of the split-bf16 kernel for this layer, best guess first:
     fewest dispatch rounds over the 256 CUs times work per workgroup, larger channel groups and deeper chunks first."""
     nblk = -(-pc.cout_eff // 16)
     cands = []
-    for (pgw, cgw, a, b) in _B_INST:
+    for (pgw, cgw, a, b, ks) in _B_INST:
         mb = b * cgw
         if mb > 1 and mb // 2 >= nblk:  # a channel group at least twice as wide as the layer
             continue
@@ -247,16 +249,16 @@ def _bf16_candidates(pc, Hout, Wout, B, taps, terms):
             grid = -(-Hout // th) * -(-Wout // (16 * xb)) * -(-pc.cout_eff // (16 * mb)) * B
             rounds = -(-grid // 256)
             cost = rounds * (pgw * a) * mb
-            cands.append((cost, -mb, -th * xb, (xb, th, mb, pgw, cgw)))
+            cands.append((cost, ks if pgw * cgw == 4 else 2, -mb, -th * xb, (xb, th, mb, pgw, cgw, ks)))
     cands.sort()
     cin8 = -(-pc.cin // 8) * 8
     cks = [c for c in ((128, 64, 32, 16, 8) if taps == 1 else (32, 16, 8)) if c <= max(8, cin8)]
     if not cks or cks[0] < min(cin8, 32):
         cks.insert(0, min(cin8, 32))
     out = []
-    for _, _, _, (xb, th, mb, pgw, cgw) in cands:
+    for _, _, _, _, (xb, th, mb, pgw, cgw, ks) in cands:
         for ck in cks:
-            out.append((xb, th, ck, mb, 2, pgw, cgw, terms))
+            out.append((xb, th, ck, mb, 2, pgw, cgw, terms, ks))
     return out
 
 
@@ -402,8 +404,8 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
             pc.cout_eff, pc.cin, pc.kh, pc.kw, pc.mb, int(pc.deconv)) + ",".join(str(int(v)) for v in key[:9]) + (
                 "|split" if force_split else "")
         capturing = torch.cuda.is_current_stream_capturing()
-        if _AUTOTUNE and sig in TUNE_DB:  # same layer signature already timed (this process or a loaded file)
-            cfg = pc.tuned[key] = tuple(TUNE_DB[sig])
+        if _AUTOTUNE and sig in TUNE_DB and _db_cfg_ok(lib, p, TUNE_DB[sig], sig):
+            cfg = pc.tuned[key] = tuple(TUNE_DB[sig])  # same layer signature already timed (this process or a loaded file)
         elif force_split:
             # pinned to the split-bf16 kernel: the configuration this layer was tuned to in its plain form if that is
             # a split one, else the first candidate the library accepts
@@ -494,9 +496,25 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
     return out
 
 
+def _db_cfg_ok(lib, p, c, sig):
+    """A launch configuration loaded from a tune db must be one THIS build accepts (a db written by another version
+    may name tiles that no longer exist): split-bf16 entries are probed with codd_conv2d_check (fp32 entries are
+    validated at launch, rc -2 -> heuristic); a rejected entry is dropped with a warning and the layer is tuned /
+    given the heuristic as if the db had no entry."""
+    if len(c) > 4 and c[4] == 2:
+        if not p.terms or (len(c) > 7 and c[7] != p.terms) or not _cfg_ok(lib, p, c):
+            import warnings
+            warnings.warn("codd_amd: tune-db entry %s = %s is not a valid split-bf16 configuration of this build; ignored" % (
+                sig, tuple(c)))
+            del TUNE_DB[sig]
+            return False
+    return True
+
+
 def _cfg_ok(lib, p, c):
     """Does the library accept split-bf16 configuration ``c`` for the layer described by ``p``? (nothing is launched)"""
     p.npb, p.nw, p.ck, p.mb, p.layout, p.pgw, p.cgw = c[:7]
+    p.ksplit = c[8] if len(c) > 8 else 1
     return lib.codd_conv2d_check(C.byref(p)) == 0
 
 
@@ -505,6 +523,7 @@ def _set_cfg(p, pc, c):
     xb, th, ck, mb, _, pgw, cgw = c[:7]
     p.wpacked = pc.packed(ck, mb, 20 + p.terms).data_ptr()
     p.mb, p.npb, p.nw, p.ck, p.layout, p.pgw, p.cgw = mb, xb, th, ck, 2, pgw, cgw
+    p.ksplit = c[8] if len(c) > 8 else 1
 
 
 def _split_dims(p, cands):

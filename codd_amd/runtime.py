@@ -23,8 +23,10 @@ class FrameRunner:
         self.metas = img_metas
         self.use_graph = use_graph
         # split = True: the frame is FOUR graphs on three HIP streams (see _capture_split) instead of one graph with
-        # parallel branches; default on (CODD_SPLIT_GRAPHS=0 selects the single graph)
+        # parallel branches; default OFF (measured 72 vs 75 frames/s, DESIGN.md finding 14; CODD_SPLIT_GRAPHS=1 or
+        # split=True selects it; tests/test_gpu_stereo_net.py::test_split_graphs_equal_single_graph keeps it honest)
         self.split = (os.environ.get("CODD_SPLIT_GRAPHS", "0") == "1") if split is None else split
+        self.last = {}  # per-frame side outputs of the last step (e.g. "Ts", the SE3 field: scene-flow evaluation)
         self.state = {}
         self.graph = None
         self._static = None
@@ -40,6 +42,7 @@ class FrameRunner:
     # ---- eager ------------------------------------------------------------------------------
     def _eager(self, left, right):
         out = self.est.consistent_online_depth_estimation(left, right, self.metas, self.state)
+        self.last = {k: out[k] for k in ("Ts",) if out.get(k) is not None}
         return out["pred_disp"]
 
     # ---- graph ------------------------------------------------------------------------------
@@ -68,6 +71,7 @@ class FrameRunner:
             # to race with the neighbouring kernel nodes (GPU page faults after ~45 replays when
             # eager work ran between replays).  Only kernel nodes are used inside the frame graph.
             ops.copy_many([(dst, src.contiguous()) for dst, src in zip(s, self._state_tensors(state))])
+            st["last"] = {k: out[k] for k in ("Ts",) if out.get(k) is not None}  # (lives in the graph's memory pool)
             return out["pred_disp"]
 
         saved = [t.clone() for t in st["state"]]
@@ -124,6 +128,7 @@ class FrameRunner:
             # state write-back with kernels (see _capture); netinp is written by step() once s2 has finished
             for dst, src in zip(s[:4], self._state_tensors(state)[:4]):
                 ops.add_relu(src.contiguous(), None, relu=False, out=dst)
+            st["last"] = {k: outputs[k] for k in ("Ts",) if outputs.get(k) is not None}
             return outputs["pred_disp"]
 
         def capture(stream, fn):
@@ -230,6 +235,7 @@ class FrameRunner:
         else:
             self.graph.replay()
         self.state = {"memory": True}  # state now lives in the static buffers
+        self.last = st.get("last", {})
         return st["out"]
 
 

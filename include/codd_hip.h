@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CODD_ABI_VERSION 5
+#define CODD_ABI_VERSION 6
 
 #define CODD_OK 0
 #define CODD_EINVAL (-1)
@@ -108,6 +108,10 @@ typedef struct {
    * the octets past the output channels are NOT written: the caller keeps the tensor zero there. */
   void* xso;
   int xso_c8, xso_hp, xso_wp, xso_bt, xso_bl, xso_o8, xso_terms;
+  /* layout 2: 0 | 1 = every accumulator tile is owned by one consumer wave; 2 = by a PAIR of waves on the same SIMD
+   * that take alternate k-steps of every chunk and add their partial sums through LDS before the epilogue (two
+   * independent MFMA streams per SIMD: one wave's LDS / barrier stalls are filled by the other) */
+  int ksplit;
 } codd_conv_params;
 
 int codd_conv2d(const codd_conv_params* p, void* stream);

@@ -769,3 +769,96 @@ def test_full_codd_parity_with_autotuned_launch_configurations():
     finally:
         ops.enable_autotune(False)
     assert len(ops.TUNE_DB) > 50
+
+
+def test_graph_inference_follows_weight_and_policy_changes(tmp_path):
+    """estimator.inference(use_graph=True) caches captured frame graphs on the model.  A graph bakes in the packed
+    weights, so after apis.load_checkpoint (new weights), a precision change or an in-place weight edit the next
+    inference must NOT replay the stale graph: every result has to equal the eager path run under the same policy.
+    Also: the cache is bounded, keyed by batch size, and does not break copy / pickling of the model."""
+    import copy
+    from codd_amd import apis, configs, ops, synth
+    from codd_amd.registry import build_estimator
+    H, W, MF = 128, 192, 3
+    est = build_estimator(configs.codd(iters=2)).to(DEV).eval()
+    synth.load_synthetic_weights(est, gain=1.4)
+    left, right, _ = synth.stereo_sequence(H, W, MF, 24.0)
+    metas = synth.default_metas(H, W)
+    d = lambda t: [t.to(DEV)]
+
+    def run(graph):
+        est.use_graph = graph
+        return est(img=d(left), r_img=d(right), img_metas=metas, return_loss=False, evaluate=False)[0].clone()
+
+    g0, e0 = run(True), run(False)
+    assert (g0 - e0).abs().max().item() < 1e-4
+    # new weights through the checkpoint loader
+    other = build_estimator(configs.codd(iters=2)).eval()
+    synth.load_synthetic_weights(other, gain=1.1)
+    torch.save(dict(state_dict=other.state_dict()), str(tmp_path / "w2.pth"))
+    apis.load_checkpoint(est, str(tmp_path / "w2.pth"), strict=True)
+    g1, e1 = run(True), run(False)
+    assert (g1 - e1).abs().max().item() < 1e-4
+    assert (g1 - g0).abs().mean().item() > 1e-3, "the second checkpoint must change the result"
+    # an in-place edit without the loader (the weights token of the runner key notices it)
+    with torch.no_grad():
+        est.stereo.tile_update.tile_update6.lastconv.weight.mul_(0.5)
+    g2, e2 = run(True), run(False)
+    assert (g2 - e2).abs().max().item() < 1e-4 and (g2 - g1).abs().mean().item() > 1e-4
+    # precision policy
+    prev = ops.set_conv_precision("fp32")
+    try:
+        g3, e3 = run(True), run(False)
+    finally:
+        ops.set_conv_precision(prev)
+    assert (g3 - e3).abs().max().item() < 1e-4
+    assert len(est._runners) <= est.RUNNER_CACHE
+    copy.deepcopy(est)  # captured graphs are not part of the model's state
+    assert "_runners" not in est.__getstate__()
+
+
+def test_scene_flow_evaluation_through_graph_replay_equals_eager():
+    """inference(evaluate=True) with gt_disp_change: the scene-flow columns read the SE3 field of every frame; under
+    use_graph it comes from the captured graph's static output (FrameRunner.last["Ts"]) and the row must equal the
+    eager one."""
+    from codd_amd import configs, metrics as M, synth
+    from codd_amd.registry import build_estimator
+    H, W, MF = 128, 192, 3
+    est = build_estimator(configs.codd(iters=2)).to(DEV).eval()
+    synth.load_synthetic_weights(est, gain=1.4)
+    left, right, disp = synth.stereo_sequence(H, W, MF, 24.0)
+    metas = synth.default_metas(H, W)
+    metas[0][0].update(disp_range=(1, 210))
+    flow = rnd(1, MF, 2, H, W, seed=5) * 2
+    dc = rnd(1, MF, 1, H, W, seed=6) * 0.5
+    d = lambda t: [t.to(DEV)]
+    kw = dict(gt_disp=d(disp), gt_flow=d(flow), gt_disp_change=d(dc))
+    rows = []
+    for graph in (False, True):
+        est.use_graph = graph
+        rows.append(est(img=d(left), r_img=d(right), img_metas=metas, return_loss=False, evaluate=True, **kw)[0])
+    assert est._runners, "the graph path must have been taken"
+    assert float(rows[1]["count"][0]) > 0
+    for k in M.COLUMNS:
+        a, b = float(rows[0][k][0]), float(rows[1][k][0])
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (k, a, b)
+
+
+def test_split_graphs_equal_single_graph():
+    """FrameRunner(split=True): four graphs on three streams (runtime._capture_split) -- same kernels, same per-chain
+    order as the single graph, so the disparities must agree to rounding of nothing (identical launches)."""
+    from codd_amd import configs, synth
+    from codd_amd.registry import build_estimator
+    from codd_amd.runtime import FrameRunner
+    H, W, MF = 128, 192, 4
+    est = build_estimator(configs.codd(iters=2)).to(DEV).eval()
+    synth.load_synthetic_weights(est, gain=1.4)
+    left, right, _ = synth.stereo_sequence(H, W, MF, 24.0)
+    metas = synth.default_metas(H, W)
+    outs = []
+    for split in (False, True):
+        r = FrameRunner(est, metas[0], use_graph=True, split=split)
+        outs.append([r.step(left[:, f].to(DEV).contiguous(), right[:, f].to(DEV).contiguous()).clone() for f in range(MF)])
+        assert r.graph is not None
+    for a, b in zip(*outs):
+        assert (a - b).abs().max().item() < 1e-5

@@ -383,6 +383,17 @@ def test_tunable_configurations_with_views_and_two_inputs():
             n += 1
             assert (outbuf[:, 8:56].cpu() - ref).abs().max().item() < 1e-4, cfg
             assert outbuf[:, :8].abs().max().item() == 0 and outbuf[:, 56:].abs().max().item() == 0, cfg
+        # eight consumer waves: k-split pairs (ksplit = 2: partial sums exchanged through LDS, odd and even k-step
+        # counts per chunk) and 4 x 2 wave grids
+        for cfg in [(1, 10, 16, 4, 2, 2, 2, 3, 2), (1, 9, 8, 4, 2, 2, 2, 3, 2), (2, 5, 32, 4, 2, 2, 2, 3, 2),
+                    (2, 8, 16, 2, 2, 4, 1, 3, 2), (1, 12, 8, 2, 2, 4, 1, 3, 2), (1, 12, 16, 4, 2, 4, 1, 3, 2),
+                    (2, 6, 32, 4, 2, 4, 1, 3, 2), (1, 16, 16, 4, 2, 4, 2, 3, 1), (2, 8, 8, 4, 2, 4, 2, 3, 1),
+                    (1, 12, 16, 4, 2, 4, 2, 3, 1), (2, 6, 8, 4, 2, 4, 2, 3, 1)]:
+            pc.tuned[key] = cfg
+            outbuf = torch.zeros(1, 64, H, W, device="cuda")
+            ops.conv2d(Slice(bd, 6, 24), pc, x2=x2d, pad=1, act="relu", res1=resd, post=postd, out=Slice(outbuf, 8, 48))
+            assert (outbuf[:, 8:56].cpu() - ref).abs().max().item() < 1e-4, cfg
+            assert outbuf[:, :8].abs().max().item() == 0 and outbuf[:, 56:].abs().max().item() == 0, cfg
     finally:
         ops.set_conv_precision(prev)
 
@@ -414,5 +425,21 @@ def test_conv_chain_through_split_records(mode, tol):
             y2 = ops.conv2d(None, p2, xs=s1, xs_coff=8)
             assert (y1.cpu() - r1).abs().max().item() < tol * r1.abs().max().item(), frame
             assert (y2.cpu() - r2).abs().max().item() < tol * max(1.0, r2.abs().max().item()), frame
+        # the record-writing epilogue of the eight-consumer-wave configurations (k-split pairs finish half of the tiles each)
+        terms = 3 if mode == "split" else 1
+        k0 = (H, W, B, 1, 1, 1, 1, 1, False, terms, "split")
+        for cfg in [(1, 10, 8, 4, 2, 2, 2, terms, 2), (2, 8, 16, 2, 2, 4, 1, terms, 2), (1, 12, 8, 4, 2, 4, 1, terms, 2),
+                    (1, 16, 8, 4, 2, 4, 2, terms, 1), (2, 6, 16, 4, 2, 4, 2, terms, 1)]:
+            p0.tuned[k0] = cfg
+            p1.tuned[k0] = cfg
+            s0.buf.zero_()
+            s1.buf.zero_()
+            ops.conv2d(x.to(dev()), p0, pad=1, act="relu", xs_out=s0)
+            assert tuple(p0.tuned[k0]) == cfg
+            y1 = ops.conv2d(None, p1, pad=1, act="relu", xs=s0)
+            ops.conv2d(None, p1, pad=1, act="relu", xs=s0, xs_out=s1)
+            y2 = ops.conv2d(None, p2, xs=s1, xs_coff=8)
+            assert (y1.cpu() - r1).abs().max().item() < tol * r1.abs().max().item(), cfg
+            assert (y2.cpu() - r2).abs().max().item() < tol * max(1.0, r2.abs().max().item()), cfg
     finally:
         ops.set_conv_precision(prev)

@@ -5,8 +5,11 @@
 #include <stdlib.h>
 #include <vector>
 
+#ifndef KSPLIT
+#define KSPLIT 1
+#endif
 #ifndef CFG
-#define CFG 2, 2, 5, 2, 3, 0
+#define CFG 2, 2, 5, 2, 3, 0, 1
 #endif
 template __global__ void conv_bf16_kernel<CFG>(const ConvB);
 
@@ -49,7 +52,7 @@ int main(int argc, char** argv) {
   if (rc) { printf("geometry rc %d\n", rc); return 1; }
   auto kern = conv_bf16_kernel<CFG>;
   hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const int nt = (pgw * cgw + CONVB_NWP) * 64;
+  const int nt = (pgw * cgw * KSPLIT + CONVB_NWP) * 64; p.ksplit = KSPLIT;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 3; ++i) kern<<<(int)grid, nt, lds>>>(k);
