@@ -150,6 +150,21 @@ def conv_roofline(runner, frames, device):
                      p.terms if p.layout == 2 else 0))
         return rc
 
+    orig_chain = ops._launch_chain
+
+    def timed_chain(lib, p, stream):  # LDS-resident chain: algorithmic FLOPs of its layers (the halo recompute is not counted)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(torch.cuda.current_stream(device))
+        rc = orig_chain(lib, p, stream)
+        e.record(torch.cuda.current_stream(device))
+        fl = sum(2.0 * p.layer[i].cin * (p.cout_store if i == p.nlayers - 1 else p.layer[i].cout) * p.layer[i].k ** 2
+                 for i in range(p.nlayers)) * p.H * p.W * p.B
+        recs.append((s, e, fl, (p.B, p.C0 + p.C1, p.cout_store, p.layer[0].k, -p.nlayers, p.H, p.W, 1, 0), 0))
+        chains.append(p.nlayers)
+        return rc
+
+    chains = []
+    ops._launch_chain = timed_chain
     ops._launch_conv = timed
     serial_before = ops.Fork.serial
     ops.Fork.serial = True  # one launch at a time, so that every event pair brackets exactly one kernel
@@ -176,6 +191,7 @@ def conv_roofline(runner, frames, device):
         torch.cuda.synchronize(device)
     finally:
         ops._launch_conv = orig
+        ops._launch_chain = orig_chain
         ops.Fork.serial = serial_before
         for fname, fn in saved.items():
             setattr(lib, fname, fn)
@@ -202,6 +218,7 @@ def conv_roofline(runner, frames, device):
             log("conv B%d Cin%-4d Cout%-4d k%dx%d out %3dx%-3d s%d m%d terms%d : n=%3d  %7.3f ms  %6.1f us/launch  %5.1f TF"
                 % (*key, n, ms, ms / n * 1e3, f / ms / 1e9))
     return dict(launches=len(recs), time_ms=t_ms, gflop=flops / 1e9, hbm=hbm,
+                chain_launches=len(chains), chain_layers=sum(chains),
                 families={k: dict(launches=v[0], ms=round(v[1], 3), gflop=round(v[2] / 1e9, 2),
                                   issued_gflop=round(v[3] / 1e9, 2)) for k, v in fam.items()})
 
@@ -454,7 +471,8 @@ def main():
                         "issued (x3 bf16 MFMAs per product on the split path)",
                         launches_per_frame=fd["launches"], ms_per_frame=fd["ms"],
                         algorithmic_frac_of_fp32_matrix_peak=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4),
-                        families=fams, conv_launches_per_frame=cr["launches"], conv_gflop_per_frame=round(cr["gflop"], 2),
+                        families=fams, conv_launches_per_frame=cr["launches"],
+                        chain_launches_per_frame=cr["chain_launches"], conv_layers_inside_chains=cr["chain_layers"], conv_gflop_per_frame=round(cr["gflop"], 2),
                         conv_ms_per_frame=round(cr["time_ms"], 3),
                         whole_conv_algorithmic_tflops=round(cr["gflop"] / cr["time_ms"], 2),
                         # the HBM-bound kernels of the same frame against SURVEY.md 8(d)'s algorithmic bytes and the 8 TB/s peak

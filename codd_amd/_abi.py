@@ -40,6 +40,21 @@ class ConvParams(C.Structure):
 
 ACT = dict(none=0, lrelu=1, relu=2, sigmoid=3, tanh=4, mish=5, relu_ch0=6)
 
+CHAIN_MAX_LAYERS = 12
+
+
+class ChainLayer(C.Structure):
+    _fields_ = [("cin", C.c_int), ("cout", C.c_int), ("k", C.c_int), ("dil", C.c_int), ("act", C.c_int),
+                ("src", C.c_int), ("dst", C.c_int), ("res", C.c_int), ("wofs", C.c_longlong)]
+
+
+class ChainParams(C.Structure):
+    _fields_ = [("in0", View), ("in1", View), ("C0", C.c_int), ("C1", C.c_int),
+                ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("nlayers", C.c_int), ("stage", C.c_int),
+                ("layer", ChainLayer * CHAIN_MAX_LAYERS), ("wpacked", C.c_void_p), ("res1", View),
+                ("out", C.c_void_p), ("out_ctot", C.c_int), ("out_coff", C.c_int), ("cout_store", C.c_int),
+                ("th", C.c_int), ("tw", C.c_int)]
+
 _i, _f, _p, _ll = C.c_int, C.c_float, C.c_void_p, C.c_longlong
 
 # name -> (restype, argtypes); must list every function declared in include/codd_hip.h
@@ -47,6 +62,10 @@ SIGNATURES = {
     "codd_abi_version": (_i, []),
     "codd_conv2d": (_i, [C.POINTER(ConvParams), _p]),
     "codd_conv2d_check": (_i, [C.POINTER(ConvParams)]),
+    "codd_chain_layer_size": (_ll, [_i, _i, _i]),
+    "codd_chain_pack_layer": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    "codd_conv_chain_check": (_i, [C.POINTER(ChainParams)]),
+    "codd_conv_chain": (_i, [C.POINTER(ChainParams), _p]),
     "codd_conv2d_packed_size": (_ll, [_i] * 6),
     "codd_conv2d_pack_weights": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "codd_tile_costvol_argmin": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _i, _p]),

@@ -9,11 +9,12 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
+from .ops import RuntimeState
 from .registry import MODELS, register
 
 
 @register
-class ConsistentOnlineDynamicDepth(nn.Module):
+class ConsistentOnlineDynamicDepth(RuntimeState, nn.Module):
     def __init__(self, stereo=None, motion=None, fusion=None, train_cfg=None, test_cfg=None, init_cfg=None,
                  **kwargs):
         super().__init__()
@@ -34,7 +35,7 @@ class ConsistentOnlineDynamicDepth(nn.Module):
         """reference model/codd.py:80-126 (eval: everything under no_grad)."""
         with torch.no_grad():
             if self.motion is not None and hasattr(self.motion, "prefetch"):
-                self.motion.prefetch(left_img)  # image-only work overlaps the stereo network
+                self.motion.prefetch(left_img, state)  # image-only work (+ correlation pyramid) overlaps the stereo network
             outputs = self.stereo.stereo_matching(left_img, right_img, img_metas, state)
             if self.motion is not None:
                 self.motion(state, outputs, img_metas=img_metas, train_mode=False)
@@ -196,11 +197,6 @@ class ConsistentOnlineDynamicDepth(nn.Module):
         from .stereo import invalidate_packed
         invalidate_packed(self)
         self.__dict__.pop("_runners", None)
-
-    def __getstate__(self):
-        state = self.__dict__.copy()
-        state.pop("_runners", None)  # captured graphs are neither picklable nor copyable
-        return state
 
     def train(self, mode=True):
         """reference model/codd.py:601-612 overrides train(); kept chainable here."""

@@ -23,7 +23,7 @@ class BasicBlock(nn.Module):
 
 
 @register
-class Fusion(nn.Module):
+class Fusion(ops.RuntimeState, nn.Module):
     def __init__(self, in_channels, fusion_channel, loss=None, corr_cfg=dict(), ds_scale=4):
         super().__init__()
         self.loss = build_loss(loss) if loss is not None else None

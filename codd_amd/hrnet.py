@@ -31,6 +31,27 @@ def packed_cbn(conv, bn):
     return ent[1]
 
 
+def chain_blocks(owner, blocks):
+    """ops.PackedChain of consecutive BasicBlocks (conv-bn-relu, conv-bn + x, relu each; eval-mode BatchNorm folded):
+    one launch, the activations between the 2 * len(blocks) convolutions stay in LDS (csrc/chain.hip).  Cached on
+    ``owner`` per parameter version; dropped by stereo.invalidate_packed."""
+    pcs = [packed_cbn(c, b) for blk in blocks for c, b in ((blk.conv1, blk.bn1), (blk.conv2, blk.bn2))]
+    ver = tuple(id(pc) for pc in pcs)  # packed_cbn re-creates the PackedConv whenever conv / bn parameters change
+    cache = owner.__dict__.setdefault("_codd_packed_cat", {})
+    ent = cache.get("chain")
+    if ent is None or ent[0] != ver:
+        layers, n = [], len(blocks)
+        for i in range(n):  # block input in buffer 0 (staged for the first block): conv1 0 -> 1, conv2 1 -> 0 (+ 0)
+            c1, c2 = pcs[2 * i], pcs[2 * i + 1]
+            layers.append(dict(w=c1._w, b=c1.bias, src=-1 if i == 0 else 0, dst=1, act="relu"))
+            layers.append(dict(w=c2._w, b=c2.bias, src=1, dst=-1 if i == n - 1 else 0, res=0, act="relu"))
+        ent = cache["chain"] = (ver, ops.PackedChain(layers, stage=0), pcs)
+    return ent[1]
+
+
+CHAIN_MAX_CHANNELS = 48  # codd_conv_chain: cout <= 48 (three 16-channel MFMA blocks per wave)
+
+
 def cbn(conv, bn, x, act="none", **kw):
     return ops.conv2d(x, packed_cbn(conv, bn), stride=tuple(conv.stride), pad=tuple(conv.padding), act=act, **kw)
 
@@ -103,7 +124,11 @@ class HRModule(nn.Module):
         nb = len(xs)
         xs = list(xs)
         for i in range(nb):
-            for blk in self.branches[i]:
+            blocks = list(self.branches[i])
+            if ops.use_chain(*xs[i].shape[2:]) and blocks[0].conv1.out_channels <= CHAIN_MAX_CHANNELS:
+                xs[i] = ops.conv_chain(xs[i], chain_blocks(self.branches[i], blocks))  # the branch in one launch
+                continue
+            for blk in blocks:
                 xs[i] = blk.run(xs[i])
         outs = []
         for i in range(nb):

@@ -94,7 +94,7 @@ def _head(cout):
     return nn.Sequential(nn.Conv2d(128, 256, 3, padding=1), nn.ReLU(inplace=True), nn.Conv2d(256, cout, 1))
 
 
-class BasicUpdateBlock(nn.Module):
+class BasicUpdateBlock(ops.RuntimeState, nn.Module):
     """reference raft3d.py:44-106."""
 
     def __init__(self, hidden_dim=128, input_dim=128):
@@ -266,7 +266,7 @@ def pack_head_matrix(Wm):
 
 
 @register
-class RAFT3D(nn.Module):
+class RAFT3D(ops.RuntimeState, nn.Module):
     """reference raft3d.py:140-280 (inference branch)."""
 
     def __init__(self, cnet_cfg=None):
@@ -295,7 +295,10 @@ class RAFT3D(nn.Module):
     # ~200 small launches fill the CUs that HITNet's coarse levels and the GRU loop's 576-block
     # convolutions leave idle; under stream capture this becomes two parallel branches of the frame
     # graph.
-    def prefetch(self, image):
+    def prefetch(self, image, state=None):
+        """``state``: the recurrent state of the sequence; when it holds the previous frame's feature map the all-pairs
+        correlation pyramid (reference blocks/corr.py:28-45: a function of the two feature maps only) is built on the
+        fnet side stream as well, i.e. beside the stereo network instead of in front of the update loop."""
         if ops.Fork.serial:
             self._pending = None
             return
@@ -308,6 +311,8 @@ class RAFT3D(nn.Module):
             stream.wait_stream(cur)
             with torch.cuda.stream(stream):
                 out[key] = fn(image)
+                if key == "fmap" and state is not None and "memory" in state and state.get("raft_feat") is not None:
+                    out["pyr"] = (state["raft_feat"], ops.allpairs_corr(state["raft_feat"], out["fmap"]))
         self._pending = out
 
     def _join(self, key, dev):
@@ -331,10 +336,12 @@ class RAFT3D(nn.Module):
         K8 = [float(v / np.float32(8.0)) for v in K]
         fmap_prev, net_inp = state["raft_feat"], state["raft_netinp"]
         T = ops.se3_identity(B, h, w, image_curr.device)
+        pend = getattr(self, "_pending", None) or {}
+        pre = pend.pop("pyr", None)  # (fmap_prev it was built from, pyramid): made on the fnet side stream by prefetch
         fmap_curr = self._join("fmap", dev)
         if fmap_curr is None:
             fmap_curr = self.fnet(image_curr)
-        pyr = ops.allpairs_corr(fmap_prev, fmap_curr)
+        pyr = pre[1] if pre is not None and pre[0] is fmap_prev else ops.allpairs_corr(fmap_prev, fmap_curr)
         net, inp = ops.context_split(net_inp)
         d1 = depth_prev[:, 3::8, 3::8].contiguous()
         d2 = depth_curr[:, 3::8, 3::8].contiguous()
@@ -361,7 +368,7 @@ class RAFT3D(nn.Module):
 
 
 @register
-class Motion(nn.Module):
+class Motion(ops.RuntimeState, nn.Module):
     """reference motion.py:48-209."""
 
     def __init__(self, raft3d=None, ds_scale=4, iters=16, loss=None):
@@ -371,9 +378,9 @@ class Motion(nn.Module):
         self.raft3d = MODELS.build(raft3d)
         self.loss = build_loss(loss) if loss is not None else None
 
-    def prefetch(self, left_img):
-        """Issue the image-only parts of the motion stage (fnet, cnet) on side streams."""
-        self.raft3d.prefetch(left_img)
+    def prefetch(self, left_img, state=None):
+        """Issue the image-only parts of the motion stage (fnet [+ the correlation pyramid], cnet) on side streams."""
+        self.raft3d.prefetch(left_img, state)
 
     def forward(self, state, outputs, img_metas, train_mode=False, **kwargs):
         img_curr = outputs["left_img"]

@@ -11,6 +11,19 @@ from . import _abi
 from ._abi import ACT, ConvParams, View
 
 
+class RuntimeState:
+    """Mixin of the plug-in modules that keep launch-time objects (side streams, fork helpers, pending prefetches,
+    captured frame graphs) in their ``__dict__``: those are neither picklable nor copyable and are rebuilt on demand,
+    so they are left out of the module's pickled / deep-copied state."""
+    _RUNTIME_KEYS = ("_side", "_pending", "_nowait", "_fk", "_xs", "_runners")
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in self._RUNTIME_KEYS:
+            state.pop(k, None)
+        return state
+
+
 class Slice:
     """Channels [coff, coff + c) of a contiguous NCHW buffer."""
     __slots__ = ("buf", "coff", "c")
@@ -697,6 +710,120 @@ def _autotune(lib, p, pc, default, with_time=False):
     AUTOTUNE_LOG.append(("%dx%d k%dx%d %d->%d out %dx%d" % (p.sy, p.sx, pc.kh, pc.kw, pc.cin, pc.cout, p.Hout, p.Wout),
                          default, None if t_default is None else t_default * 1e3, best, best_t * 1e3))
     return (best, best_t) if with_time else best
+
+
+# ----------------------------------------------------------------------------------------- conv chains
+# LDS-resident chains (codd_conv_chain) are OFF by default.  Measured on MI355X (tools/time_chain.py, profiles/
+# r03_chain_times.log; DESIGN.md round-3 findings): a chain only beats its layers as separate launches where those are
+# launch-bound -- maps of up to 36 x 60 pixels (TileUpdate0-2: 64 vs 80 us for six layers; the three 3x3 convolutions
+# behind down4: 35 vs 40 us) -- and inside the captured frame graph even that gain vanishes (HITNetMF stereo-only 352
+# with vs 358 frames/s without).  From 72 x 120 up the per-tile halo recompute, a wave's serial (tap, octet) MFMA chain
+# and the single resident workgroup per CU (LDS + 200 registers) cost far more than the launches save (144 x 240: 261
+# vs 104 us; a 32-channel residual pair at 288 x 480: 135 vs 83 us).  CODD_CHAINS=1 enables them for maps of up to
+# CODD_CHAIN_MAX_PIXELS pixels (tests run both schedules).
+USE_CHAINS = _os.environ.get("CODD_CHAINS", "0") == "1"
+CHAIN_MAX_PIXELS = int(_os.environ.get("CODD_CHAIN_MAX_PIXELS", str(36 * 60)))
+
+
+def use_chain(H, W):
+    return USE_CHAINS and H * W <= CHAIN_MAX_PIXELS
+
+
+class PackedChain:
+    """A chain of small stride-1 convolutions packed for codd_conv_chain (include/codd_hip.h): ONE launch, the
+    intermediates stay in LDS.  ``layers``: dicts(w [cout,cin,k,k], b [cout] | None, dil, act, src, dst, res) -- src /
+    dst / res are LDS buffer ids (0 | 1), -1 = global (first src, last dst) or no residual; ``stage``: the buffer the
+    input tile is staged into when the first layer is a 3x3."""
+
+    TILES = ((8, 8), (8, 16), (16, 16), (4, 16), (16, 32), (4, 8), (4, 4), (2, 8))
+
+    def __init__(self, layers, stage=0):
+        lib = _abi.load()
+        assert 1 <= len(layers) <= _abi.CHAIN_MAX_LAYERS
+        self.layers, self.stage = [], stage
+        sizes = []
+        for L in layers:
+            w = L["w"].detach().float().contiguous()
+            _require_gpu(w)
+            cout, cin, k, _ = w.shape
+            n = lib.codd_chain_layer_size(cout, cin, k)
+            if n <= 0:
+                raise _abi.CoddHipError("conv chain: unsupported layer %dx%d %d->%d" % (k, k, cin, cout))
+            sizes.append(n)
+            self.layers.append(dict(cin=cin, cout=cout, k=k, dil=L.get("dil", 1), act=ACT[L.get("act", "none")],
+                                    src=L["src"], dst=L["dst"], res=L.get("res", -1)))
+        self.buf = torch.empty(sum(sizes), device=layers[0]["w"].device, dtype=torch.float32)
+        off = 0
+        for L, d, n in zip(layers, self.layers, sizes):
+            w = L["w"].detach().float().contiguous()
+            b = None if L.get("b") is None else L["b"].detach().float().contiguous()
+            d["wofs"] = off
+            _abi.check(lib.codd_chain_pack_layer(w.data_ptr(), None if b is None else b.data_ptr(), d["cout"], d["cin"],
+                                                 d["k"], self.buf.data_ptr() + 4 * off, _stream()), "chain_pack_layer")
+            off += n
+        self.cin, self.cout = self.layers[0]["cin"], self.layers[-1]["cout"]
+        self._tiles = {}
+
+    def fill(self, p):
+        p.nlayers, p.stage, p.wpacked = len(self.layers), self.stage, self.buf.data_ptr()
+        for i, d in enumerate(self.layers):
+            L = p.layer[i]
+            L.cin, L.cout, L.k, L.dil, L.act, L.src, L.dst, L.res, L.wofs = (
+                d["cin"], d["cout"], d["k"], d["dil"], d["act"], d["src"], d["dst"], d["res"], d["wofs"])
+
+    def tile(self, lib, p, B, H, W):
+        """Output tile of a workgroup: the accepted candidate with the fewest MFMAs on the busiest CU (halo recompute
+        against dispatch rounds over the 256 CUs)."""
+        key = (B, H, W)
+        if key not in self._tiles:
+            best = None
+            for th, tw in self.TILES:
+                p.th, p.tw = th, tw
+                if lib.codd_conv_chain_check(C.byref(p)) != 0:
+                    continue
+                halo = sum(d["dil"] * (d["k"] // 2) for d in self.layers)
+                m, per = 0, 0
+                for d in self.layers:
+                    m += d["dil"] * (d["k"] // 2)
+                    npx = (th + 2 * (halo - m)) * (tw + 2 * (halo - m))
+                    per += -(-npx // 32) * 2 * d["k"] ** 2 * 2 * -(-d["cin"] // 8) * -(-d["cout"] // 16)
+                wgs = -(-H // th) * -(-W // tw) * B
+                cost = -(-wgs // 256) * per
+                if best is None or cost < best[0]:
+                    best = (cost, th, tw)
+            if best is None:
+                raise _abi.CoddHipError("conv chain: no tile fits the LDS budget")
+            self._tiles[key] = best[1:]
+        return self._tiles[key]
+
+
+def conv_chain(x, pch, x2=None, res1=None, out=None, cout_store=None, tile=None):
+    """Run the packed chain on (x | x2) -> out [B, cout_store, H, W] (tensor or Slice); ``res1`` (tensor / Slice) is
+    added to the last layer's result before its activation."""
+    lib = _abi.load()
+    xs = _as_slice(x)
+    _require_gpu(xs.buf)
+    B, C0, H, W = xs.shape
+    C1 = 0 if x2 is None else _as_slice(x2).c
+    assert C0 + C1 == pch.cin, (C0, C1, pch.cin)
+    cs = pch.cout if cout_store is None else cout_store
+    if out is None:
+        out = torch.empty(B, cs, H, W, device=xs.buf.device, dtype=torch.float32)
+    os_ = _as_slice(out)
+    assert os_.shape == (B, cs, H, W), (os_.shape, (B, cs, H, W))
+    p = _abi.ChainParams()
+    p.in0, p.in1, p.C0, p.C1, p.B, p.H, p.W = _view(xs), _view(x2), C0, C1, B, H, W
+    pch.fill(p)
+    p.res1 = _view(res1)
+    p.out, p.out_ctot, p.out_coff, p.cout_store = os_.buf.data_ptr(), os_.buf.shape[1], os_.coff, cs
+    p.th, p.tw = pch.tile(lib, p, B, H, W) if tile is None else tile
+    _abi.check(_launch_chain(lib, p, _stream()), "codd_conv_chain")
+    return out
+
+
+def _launch_chain(lib, p, stream):
+    """Single choke point of every chain launch (bench.py wraps it with HIP events)."""
+    return lib.codd_conv_chain(C.byref(p), stream)
 
 
 # ----------------------------------------------------------------------------------------- stereo

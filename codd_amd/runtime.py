@@ -178,6 +178,8 @@ class FrameRunner:
     def eager_frame_on_static_state(self, left, right):
         """One eager (un-captured) steady-state frame on the current recurrent state -- used by
         bench.py to bracket individual launches with events.  Advances the state."""
+        if self.est.motion is None and self.est.fusion is None:  # stereo-only estimator: no recurrent state
+            return self._eager(left, right)
         if self._static is not None and self._static.get("primed"):
             s = self._static["state"]
             state = dict(memory=[s[0], s[1], s[2]], raft_feat=s[3], raft_netinp=s[4])

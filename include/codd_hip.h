@@ -152,6 +152,58 @@ int codd_conv2d_pack_weights_ex(const float* w, float* wpacked, int Cout, int Ci
                                 void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * LDS-resident convolution CHAIN (exact fp32, v_mfma_f32_16x16x4_f32): a sequence of stride-1 1x1 / 3x3 (dilated)
+ * convolutions with <= 64 channels executed by ONE launch.  A workgroup owns a th x tw output tile, keeps every
+ * intermediate activation of the tile (plus the halo the remaining layers need, recomputed per tile) in two LDS
+ * buffers and only touches global memory for the chain's input, the per-layer weights and the final result.
+ * Replaces the launch-bound small-layer chains of the reference: TileUpdate* conv0 -> resblock0 -> resblock1 ->
+ * lastconv (propagation.py:124-248), PostTileUpdate conv1 / resblocks / lastconv (propagation.py:251-333), BasicBlock
+ * (propagation.py:103-121) and mmseg HRNet BasicBlock pairs (configs/models/codd.py:44-74; BatchNorm folded).
+ *
+ *   layer l:  y = act_l( conv_l(x_l) + bias_l [+ r_l] ),  x_l = the buffer `src`, y -> the buffer `dst` (0 | 1);
+ *             r_l = the buffer `res` at the same pixel (res = -1: none; res == dst is allowed: in-place residual).
+ *   Every intermediate is forced to 0 outside the image, i.e. each layer sees the zero padding of a stand-alone
+ *   "same" convolution of its input map.
+ *   first layer: src = -1 -> the chain input (channel concatenation of in0 | in1) is read from global memory; a 1x1
+ *                first layer reads it directly, a 3x3 one has the tile staged into buffer `stage` first (which later
+ *                layers may use as a residual source).
+ *   last layer:  dst = -1 -> global `out` (channels [0, cout_store) of it), after  + res1 (global view, optional).
+ * Weights: one packed block per layer (codd_chain_pack_layer), all in one buffer at float offsets `wofs`.
+ * --------------------------------------------------------------------------------------------- */
+#define CODD_CHAIN_MAX_LAYERS 12
+typedef struct {
+  int cin, cout;  /* cin <= 64, cout <= 48 */
+  int k, dil;     /* k = 1 | 3 (square, stride 1, "same" padding dil * (k - 1) / 2) */
+  int act;        /* CODD_ACT_* */
+  int src, dst;   /* LDS buffer ids (0 | 1); -1 = global (first layer's src, last layer's dst) */
+  int res;        /* -1 | buffer id of the residual operand */
+  long long wofs; /* float offset of the layer's packed block inside wpacked (multiple of 4) */
+} codd_chain_layer;
+
+typedef struct {
+  codd_view in0, in1; /* chain input = channels [0,C0) of in0 | [0,C1) of in1 */
+  int C0, C1;
+  int B, H, W;
+  int nlayers;
+  int stage;          /* buffer the input tile is staged into when the first layer is a 3x3 */
+  codd_chain_layer layer[CODD_CHAIN_MAX_LAYERS];
+  const float* wpacked;
+  codd_view res1;     /* added to the last layer's result before its activation (ptr == NULL: none) */
+  float* out;
+  int out_ctot, out_coff;
+  int cout_store;     /* leading channels of the last layer that are stored (<= its cout) */
+  int th, tw;         /* output tile of a workgroup */
+} codd_chain_params;
+
+/* floats of one layer's packed block: [tap][k-step = cin/4][16-channel block][64 lanes] MFMA A operands + bias */
+long long codd_chain_layer_size(int cout, int cin, int k);
+/* w: [cout][cin][k][k] fp32 (device), bias: [cout] or NULL -> dst (device, codd_chain_layer_size floats) */
+int codd_chain_pack_layer(const float* w, const float* bias, int cout, int cin, int k, float* dst, void* stream);
+/* CODD_OK if codd_conv_chain accepts the program (LDS budget, buffer discipline); launches nothing */
+int codd_conv_chain_check(const codd_chain_params* p);
+int codd_conv_chain(const codd_chain_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Stereo (HITNetMF)
  * --------------------------------------------------------------------------------------------- */
 /* Tile cost volume + first arg-min, fused (never materialises cv):
