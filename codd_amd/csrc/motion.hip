@@ -1257,7 +1257,8 @@ extern "C" int codd_copy_many(const float* const* src, float* const* dst, const 
 // independent launches (concurrently, on forked streams); these two kernels apply
 //   z|r = sigmoid(conv1 + conv2 + (inp + cor + mot)[0:256]),  rh = r * h
 //   q   = tanh   (conv1 + conv2 + (inp + cor + mot)[256:384]), h' = (1 - z) h + z q
-// with the three input streams inp / cor / mot [B,384,hw] summed in the reference's order.
+// with the three input streams inp / cor / mot [B,384,hw] summed in the reference's order (cor = mot = NULL: ``inp``
+// already holds their sum -- the merged 1x1 encoder head of BasicUpdateBlock.run writes inp + cor + mot).
 // ------------------------------------------------------------------------------------------------
 __global__ void gru_gate_zr_kernel(const float* __restrict__ t1, const float* __restrict__ t2,
                                    const float* __restrict__ inp, const float* __restrict__ cor,
@@ -1267,7 +1268,7 @@ __global__ void gru_gate_zr_kernel(const float* __restrict__ t1, const float* __
   if (e >= total) return;  // total = B*256*hw
   const long long b = e / (256LL * hw), r = e - b * 256LL * hw;
   const long long i3 = b * 384LL * hw + r;
-  const float isum = (inp[i3] + cor[i3]) + mot[i3];
+  const float isum = cor ? (inp[i3] + cor[i3]) + mot[i3] : inp[i3];
   const float v = 1.f / (1.f + expf(-((t1[e] + t2[e]) + isum)));
   zr[e] = v;
   if (r >= 128LL * hw) { const long long hi = b * 128LL * hw + (r - 128LL * hw); rh[hi] = v * h[hi]; }
@@ -1280,14 +1281,14 @@ __global__ void gru_gate_q_kernel(const float* __restrict__ t1, const float* __r
   if (e >= total) return;  // total = B*128*hw
   const long long b = e / (128LL * hw), r = e - b * 128LL * hw;
   const long long i3 = b * 384LL * hw + 256LL * hw + r;
-  const float isum = (inp[i3] + cor[i3]) + mot[i3];
+  const float isum = cor ? (inp[i3] + cor[i3]) + mot[i3] : inp[i3];
   const float q = tanhf((t1[e] + t2[e]) + isum);
   const float z = zr[b * 256LL * hw + r];
   ho[e] = (1.f - z) * h[e] + z * q;
 }
 extern "C" int codd_gru_gate_zr(const float* t1, const float* t2, const float* inp, const float* cor,
                                 const float* mot, const float* h, int B, int hw, float* zr, float* rh, void* stream) {
-  if (!t1 || !t2 || !inp || !cor || !mot || !h || !zr || !rh) return CODD_EINVAL;
+  if (!t1 || !t2 || !inp || (!cor != !mot) || !h || !zr || !rh) return CODD_EINVAL;
   const long long total = (long long)B * 256 * hw;
   gru_gate_zr_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(t1, t2, inp, cor, mot, h, hw, zr, rh, total);
   CODD_LAUNCH_CHECK();
@@ -1295,7 +1296,7 @@ extern "C" int codd_gru_gate_zr(const float* t1, const float* t2, const float* i
 }
 extern "C" int codd_gru_gate_q(const float* t1, const float* t2, const float* inp, const float* cor, const float* mot,
                                const float* zr, const float* h, int B, int hw, float* hout, void* stream) {
-  if (!t1 || !t2 || !inp || !cor || !mot || !zr || !h || !hout) return CODD_EINVAL;
+  if (!t1 || !t2 || !inp || (!cor != !mot) || !zr || !h || !hout) return CODD_EINVAL;
   const long long total = (long long)B * 128 * hw;
   gru_gate_q_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(t1, t2, inp, cor, mot, zr, h, hw, hout, total);
   CODD_LAUNCH_CHECK();
@@ -1319,8 +1320,8 @@ __global__ void gru_gate_zr_xs_kernel(const float* __restrict__ t1, const float*
     const size_t ez = ((size_t)b * 256 + c) * hw + pix, er = ez + (size_t)128 * hw;
     const size_t iz = ((size_t)b * 384 + c) * hw + pix, ir = iz + (size_t)128 * hw;
     const size_t ih = ((size_t)b * 128 + c) * hw + pix;
-    z[ih] = 1.f / (1.f + expf(-((t1[ez] + t2[ez]) + ((inp[iz] + cor[iz]) + mot[iz]))));
-    const float r = 1.f / (1.f + expf(-((t1[er] + t2[er]) + ((inp[ir] + cor[ir]) + mot[ir]))));
+    z[ih] = 1.f / (1.f + expf(-((t1[ez] + t2[ez]) + (cor ? (inp[iz] + cor[iz]) + mot[iz] : inp[iz]))));
+    const float r = 1.f / (1.f + expf(-((t1[er] + t2[er]) + (cor ? (inp[ir] + cor[ir]) + mot[ir] : inp[ir]))));
     v[i] = r * h[ih];
   }
   xs_store8(rh, b, oct, pix / W, pix % W, v);
@@ -1340,7 +1341,7 @@ __global__ void gru_gate_q_xs_kernel(const float* __restrict__ t1, const float* 
     const int c = oct * 8 + i;
     const size_t ih = ((size_t)b * 128 + c) * hw + pix;
     const size_t i3 = ((size_t)b * 384 + 256 + c) * hw + pix;
-    const float q = tanhf((t1[ih] + t2[ih]) + ((inp[i3] + cor[i3]) + mot[i3]));
+    const float q = tanhf((t1[ih] + t2[ih]) + (cor ? (inp[i3] + cor[i3]) + mot[i3] : inp[i3]));
     const float zz = z[ih];
     v[i] = (1.f - zz) * h[ih] + zz * q;
     ho[ih] = v[i];
@@ -1350,7 +1351,7 @@ __global__ void gru_gate_q_xs_kernel(const float* __restrict__ t1, const float* 
 extern "C" int codd_gru_gate_zr_xs(const float* t1, const float* t2, const float* inp, const float* cor,
                                    const float* mot, const float* h, int B, int H, int W, float* z, codd_xs_view rh_xs,
                                    void* stream) {
-  if (!t1 || !t2 || !inp || !cor || !mot || !h || !z || !xs_view_ok(rh_xs, 128, H, W)) return CODD_EINVAL;
+  if (!t1 || !t2 || !inp || (!cor != !mot) || !h || !z || !xs_view_ok(rh_xs, 128, H, W)) return CODD_EINVAL;
   const long long total = (long long)B * 16 * H * W;
   gru_gate_zr_xs_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(t1, t2, inp, cor, mot, h, B, H, W, z, rh_xs);
   CODD_LAUNCH_CHECK();
@@ -1359,7 +1360,7 @@ extern "C" int codd_gru_gate_zr_xs(const float* t1, const float* t2, const float
 extern "C" int codd_gru_gate_q_xs(const float* t1, const float* t2, const float* inp, const float* cor, const float* mot,
                                   const float* z, const float* h, int B, int H, int W, float* hout, codd_xs_view h_xs,
                                   void* stream) {
-  if (!t1 || !t2 || !inp || !cor || !mot || !z || !h || !hout || !xs_view_ok(h_xs, 128, H, W)) return CODD_EINVAL;
+  if (!t1 || !t2 || !inp || (!cor != !mot) || !z || !h || !hout || !xs_view_ok(h_xs, 128, H, W)) return CODD_EINVAL;
   const long long total = (long long)B * 16 * H * W;
   gru_gate_q_xs_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(t1, t2, inp, cor, mot, z, h, B, H, W, hout, h_xs);
   CODD_LAUNCH_CHECK();

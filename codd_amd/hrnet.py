@@ -50,6 +50,12 @@ def chain_blocks(owner, blocks):
 
 
 CHAIN_MAX_CHANNELS = 48  # codd_conv_chain: cout <= 48 (three 16-channel MFMA blocks per wave)
+import os as _os
+# the 2-4 resolution branches of an HRModule (and then its fused outputs) on parallel streams.  OFF: eager it works
+# (context network alone 2.1 -> 1.6 ms), but the frame runs as a captured hipGraph and ROCm 7.2's hipGraphInstantiate
+# segfaults on these nested forks -- in round 2 with the branch streams forked from the context network's side stream,
+# in round 3 also with ops.Fork.prefork (streams brought into the capture through the origin stream first).
+FORK_BRANCHES = _os.environ.get("CODD_HRNET_FORK", "0") == "1"
 
 
 def cbn(conv, bn, x, act="none", **kw):
@@ -120,18 +126,30 @@ class HRModule(nn.Module):
             fuse.append(nn.ModuleList(row))
         self.fuse_layers = nn.ModuleList(fuse)
 
-    def run(self, xs):
+    def run(self, xs, fk=None):
+        """``fk``: ops.Fork with >= len(xs) - 1 streams -- the branches, and then the fused outputs, are independent of
+        each other and run side by side (branch / output 0 on the caller's stream)."""
         nb = len(xs)
         xs = list(xs)
-        for i in range(nb):
+
+        def on(i, fn):
+            return fn() if fk is None or i == 0 else fk.run(i - 1, fn)
+
+        def branch(i):
+            x = xs[i]
             blocks = list(self.branches[i])
-            if ops.use_chain(*xs[i].shape[2:]) and blocks[0].conv1.out_channels <= CHAIN_MAX_CHANNELS:
-                xs[i] = ops.conv_chain(xs[i], chain_blocks(self.branches[i], blocks))  # the branch in one launch
-                continue
+            if ops.use_chain(*x.shape[2:]) and blocks[0].conv1.out_channels <= CHAIN_MAX_CHANNELS:
+                return ops.conv_chain(x, chain_blocks(self.branches[i], blocks))  # the branch in one launch
             for blk in blocks:
-                xs[i] = blk.run(xs[i])
-        outs = []
-        for i in range(nb):
+                x = blk.run(x)
+            return x
+
+        ys = [on(i, lambda i=i: branch(i)) for i in range(nb)]
+        if fk is not None:
+            fk.join()
+        xs = ys
+
+        def fuse(i):
             acc = torch.empty_like(xs[i])
             for j in range(nb):
                 first, last = j == 0, j == nb - 1
@@ -149,7 +167,11 @@ class HRModule(nn.Module):
                             t = cbn(f[0], f[1], t, "relu")
                         else:
                             cbn(f[0], f[1], t, "relu" if last else "none", res1=None if first else acc, out=acc)
-            outs.append(acc)
+            return acc
+
+        outs = [on(i, lambda i=i: fuse(i)) for i in range(nb)]
+        if fk is not None:
+            fk.join()
         return outs
 
 
@@ -158,7 +180,7 @@ def _transition_new(cin, cout):
 
 
 @register
-class HRNet(nn.Module):
+class HRNet(ops.RuntimeState, nn.Module):
     """mmseg.models.backbones.HRNet restricted to what configs/models/codd.py:44-74 uses."""
 
     def __init__(self, extra=None, norm_cfg=None, norm_eval=True, init_cfg=None, **kwargs):
@@ -192,17 +214,26 @@ class HRNet(nn.Module):
             x = blk.run(x)
         t0, t1 = self.transition1[0], self.transition1[1][0]
         ys = [cbn(t0[0], t0[1], x, "relu"), cbn(t1[0], t1[1], x, "relu")]
+        fk = self.fork(x.device) if FORK_BRANCHES and getattr(self, "fork_branches", True) else None
         for m in self.stage2:
-            ys = m.run(ys)
+            ys = m.run(ys, fk)
         t = self.transition2[2][0]
         ys = ys + [cbn(t[0], t[1], ys[-1], "relu")]
         for m in self.stage3:
-            ys = m.run(ys)
+            ys = m.run(ys, fk)
         t = self.transition3[3][0]
         ys = ys + [cbn(t[0], t[1], ys[-1], "relu")]
         for m in self.stage4:
-            ys = m.run(ys)
+            ys = m.run(ys, fk)
         return ys
+
+    def fork(self, device):
+        """The branch streams (callers that run this network on a side stream pre-fork them from their origin stream:
+        ops.Fork.prefork)."""
+        fk = self.__dict__.get("_fk")
+        if fk is None or fk.dev != device:
+            fk = self.__dict__["_fk"] = ops.Fork(device, len(self.out_channels) - 1)
+        return fk
 
 
 class ResizeConcatConv(nn.Module):

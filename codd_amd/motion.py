@@ -22,6 +22,7 @@ from .registry import MODELS, build_backbone, build_loss, register
 from .stereo import cv, packed
 
 BF_DEFAULT = 1050 * 0.2  # reference motion.py:45
+MERGE_ENC_HEADS = os.environ.get("CODD_MERGE_ENC_HEADS", "1") == "1"  # (A/B switch; see BasicUpdateBlock.run)
 
 def packed_cat(mods):
     """One PackedConv whose output channels are the concatenation of several same-shape convs; cached on the first
@@ -33,6 +34,21 @@ def packed_cat(mods):
     if ent is None or ent[0] != ver:
         w = torch.cat([m.weight.detach() for m in mods], 0)
         b = torch.cat([m.bias.detach() for m in mods], 0)
+        ent = cache[key] = (ver, ops.PackedConv(w, b), tuple(mods))
+    return ent[1]
+
+
+def packed_cat_in(mods):
+    """One PackedConv computing the SUM of several same-geometry convs of different inputs: weights concatenated along
+    the input channels (the inputs are concatenated in the same order), biases added.  conv_a(x_a) + conv_b(x_b) =
+    conv_[a|b]([x_a | x_b]).  Cached like packed_cat."""
+    ver = tuple((m.weight.data_ptr(), m.weight._version, m.bias._version) for m in mods)
+    cache = mods[0].__dict__.setdefault("_codd_packed_cat", {})
+    key = ("in",) + tuple(id(m) for m in mods)
+    ent = cache.get(key)
+    if ent is None or ent[0] != ver:
+        w = torch.cat([m.weight.detach() for m in mods], 1)
+        b = sum(m.bias.detach() for m in mods)
         ent = cache[key] = (ver, ops.PackedConv(w, b), tuple(mods))
     return ent[1]
 
@@ -183,9 +199,23 @@ class BasicUpdateBlock(ops.RuntimeState, nn.Module):
         if zr is None:
             zr = self.zr_convs(net)
         t1, t2 = zr
-        mot = fk.run(2, flow_chain)
-        cor = corr_chain()
-        fk.join()
+        enc = sb("enc_cat", 384, 0)
+        if enc is not None and MERGE_ENC_HEADS:
+            # the two encoder chains end in 1x1 convolutions to the same 384 gate-input channels, which the gates only
+            # ever use summed (with the context stream ``inp``): their inputs are written side by side into ONE split
+            # tensor [corr_enc[2] out 256 | flow_enc[0] out 128] and ONE 1x1 convolution with the input-concatenated
+            # weights (+ res1 = inp) produces inp + cor + mot -- one launch and two 13 MB tensors less per update,
+            # and the gate kernels read one stream instead of three
+            fk.run(2, lambda: cv(self.flow_enc[0], minfo, act="relu", xs=min_, xs_out=enc, xs_out_coff=256))
+            cv(self.corr_enc[0], corr, act="relu", xs=cin, xs_out=sb("corr_enc0", 256, 1))
+            cv(self.corr_enc[2], None, act="relu", xs=sb("corr_enc0", 256, 1), xs_out=enc, xs_out_coff=0)
+            fk.join()
+            inp = ops.conv2d(None, packed_cat_in((self.corr_enc[4], self.flow_enc[2])), xs=enc, res1=inp)
+            cor = mot = None
+        else:
+            mot = fk.run(2, flow_chain)
+            cor = corr_chain()
+            fk.join()
         fkz.join()
         rs, hb = sb("rh", 128, 4), sb("net", 128, 4)
         if rs is None:
@@ -307,6 +337,8 @@ class RAFT3D(ops.RuntimeState, nn.Module):
             self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
         cur = torch.cuda.current_stream(dev)
         out = {}
+        if hasattr(self.cnet[0], "fork") and getattr(self.cnet[0], "fork_branches", True):
+            self.cnet[0].fork(dev).prefork(cur)  # HRNet's branch streams join the frame graph through THIS stream
         for key, stream, fn in (("fmap", self._side[0], self.fnet), ("netinp", self._side[1], self.context)):
             stream.wait_stream(cur)
             with torch.cuda.stream(stream):

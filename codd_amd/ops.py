@@ -1081,9 +1081,13 @@ def gru_gate_zr(t1, t2, inp, cor, mot, h):
     lib = _abi.load()
     B, _, hh, ww = h.shape
     zr, rh = _f32(B, 256, hh, ww, like=h), torch.empty_like(h)
-    _abi.check(lib.codd_gru_gate_zr(t1.data_ptr(), t2.data_ptr(), inp.data_ptr(), cor.data_ptr(), mot.data_ptr(),
+    _abi.check(lib.codd_gru_gate_zr(t1.data_ptr(), t2.data_ptr(), inp.data_ptr(), _ptr(cor), _ptr(mot),
                                     h.data_ptr(), B, hh * ww, zr.data_ptr(), rh.data_ptr(), _stream()), "gru_gate_zr")
     return zr, rh
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
 
 
 def _xs_view(st, coff=0):
@@ -1096,7 +1100,7 @@ def gru_gate_zr_xs(t1, t2, inp, cor, mot, h, rh_xs):
     lib = _abi.load()
     B, _, hh, ww = h.shape
     z = torch.empty_like(h)
-    _abi.check(lib.codd_gru_gate_zr_xs(t1.data_ptr(), t2.data_ptr(), inp.data_ptr(), cor.data_ptr(), mot.data_ptr(),
+    _abi.check(lib.codd_gru_gate_zr_xs(t1.data_ptr(), t2.data_ptr(), inp.data_ptr(), _ptr(cor), _ptr(mot),
                                        h.data_ptr(), B, hh, ww, z.data_ptr(), _xs_view(rh_xs), _stream()),
                "gru_gate_zr_xs")
     return z
@@ -1108,7 +1112,7 @@ def gru_gate_q_xs(t1, t2, inp, cor, mot, z, h, h_xs):
     lib = _abi.load()
     B, _, hh, ww = h.shape
     ho = torch.empty_like(h)
-    _abi.check(lib.codd_gru_gate_q_xs(t1.data_ptr(), t2.data_ptr(), inp.data_ptr(), cor.data_ptr(), mot.data_ptr(),
+    _abi.check(lib.codd_gru_gate_q_xs(t1.data_ptr(), t2.data_ptr(), inp.data_ptr(), _ptr(cor), _ptr(mot),
                                       z.data_ptr(), h.data_ptr(), B, hh, ww, ho.data_ptr(), _xs_view(h_xs), _stream()),
                "gru_gate_q_xs")
     return ho
@@ -1118,7 +1122,7 @@ def gru_gate_q(t1, t2, inp, cor, mot, zr, h):
     lib = _abi.load()
     B, _, hh, ww = h.shape
     ho = torch.empty_like(h)
-    _abi.check(lib.codd_gru_gate_q(t1.data_ptr(), t2.data_ptr(), inp.data_ptr(), cor.data_ptr(), mot.data_ptr(),
+    _abi.check(lib.codd_gru_gate_q(t1.data_ptr(), t2.data_ptr(), inp.data_ptr(), _ptr(cor), _ptr(mot),
                                    zr.data_ptr(), h.data_ptr(), B, hh * ww, ho.data_ptr(), _stream()), "gru_gate_q")
     return ho
 
@@ -1152,6 +1156,17 @@ class Fork:
         for s in self.used:
             cur.wait_stream(s)
         self.used = []
+
+    def prefork(self, origin=None):
+        """Bring every branch stream into the caller's ORIGIN stream's dependency graph (default: the current stream)
+        before the branches are first used from a stream that is itself a fork.  Under hipGraph capture (ROCm 7.2) a
+        stream whose FIRST captured operation is a wait on an already-forked stream crashes hipGraphInstantiate; a
+        stream that joined the capture through the origin stream can wait on forked streams freely."""
+        if Fork.serial:
+            return
+        cur = torch.cuda.current_stream(self.dev) if origin is None else origin
+        for s in self.streams:
+            s.wait_stream(cur)
 
 
 # ----------------------------------------------------------------------------------------- fusion

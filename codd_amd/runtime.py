@@ -260,6 +260,11 @@ class PipelinedRunner:
         if estimator.motion is None or estimator.fusion is None:
             raise ValueError("the frame pipeline needs the motion and fusion stages (use FrameRunner)")
         self.est, self.metas, self.use_graph = estimator, img_metas, use_graph
+        # stage A runs on a side stream of the captured graph: HRNet's branch streams could only be forked from that
+        # (already forked) stream, which hipGraphInstantiate of ROCm 7.2 does not survive -> branches in sequence
+        cn = getattr(estimator.motion.raft3d, "cnet", None)
+        if cn is not None and hasattr(cn[0], "fork"):
+            cn[0].fork_branches = False
         self.reset()
         self.graph = None
         self._static = None
