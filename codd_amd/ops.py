@@ -203,6 +203,7 @@ def _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl):
 #   "fp32"             exact-fp32 MFMA kernels (v_mfma_f32_16x16x4_f32)
 #   "bf16"             bf16 operands, fp32 accumulate (BASELINE.json configs[4]; reference auto_fp16 hook)
 CONV_PRECISION = _os.environ.get("CODD_CONV_PRECISION", "split")
+ALLPAIRS_SPLIT = _os.environ.get("CODD_ALLPAIRS_SPLIT", "1") == "1"  # (A/B switch of allpairs_corr)
 _TERMS = dict(split=3, bf16=1)
 
 
@@ -888,8 +889,113 @@ def instnorm(x, relu=True, res=None):
     return y
 
 
-def allpairs_corr(f1, f2):
-    """-> 4 pyramid levels [B, h*w, (h>>i)*(w>>i)]."""
+# configurations (xb, th, ck, mb, 2, pgw, cgw, 3, ks) tried, in order, for the split-bf16 all-pairs "convolution"
+# (1x1, Cout = h*w source pixels, Cin = 128): 64-channel groups, whole 32-channel chunks
+_ALLPAIRS_CFGS = ((2, 8, 32, 4, 2, 4, 2, 3, 1), (1, 16, 32, 4, 2, 4, 2, 3, 1), (1, 16, 32, 4, 2, 4, 1, 3, 1), (1, 12, 32, 4, 2, 4, 2, 3, 1),
+                  (1, 12, 32, 4, 2, 4, 1, 3, 1), (1, 10, 32, 4, 2, 2, 2, 3, 1), (2, 8, 32, 4, 2, 4, 1, 3, 1),
+                  (1, 8, 32, 2, 2, 4, 1, 3, 1), (1, 8, 16, 2, 2, 4, 1, 3, 1))
+_ALLPAIRS_PICK = {}  # (D, hh, ww) -> configuration (timed once per shape when autotuning, else the first accepted)
+
+
+def allpairs_corr_split(f1, f2):
+    """The all-pairs pyramid on the split-bf16 convolution kernel (3 bf16 MFMAs per product, fp32 accumulate): level i =
+    a 1x1 "convolution" of the i-times pooled f2 (as split records) whose output channels are the h*w source pixels and
+    whose weights are f1^T / 16, re-packed every frame.  Level 0 writes 299 MB at 960x576: on the exact-fp32 MFMA kernel
+    it was compute-bound at 0.87 TB/s (345 us); here it is write-bound."""
+    lib = _abi.load()
+    _require_gpu(f1)
+    B, D, h, w = f1.shape
+    N = h * w
+    lv = [_f32(B, N, (h >> i) * (w >> i), like=f1) for i in range(4)]
+    srcs = [f2.contiguous()]
+    for i in range(1, 4):
+        hh, ww = h >> (i - 1), w >> (i - 1)
+        nxt = _f32(B, D, hh >> 1, ww >> 1, like=f1)
+        _abi.check(lib.codd_avgpool2(srcs[-1].data_ptr(), B * D, hh, ww, nxt.data_ptr(), _stream()), "avgpool2")
+        srcs.append(nxt)
+    packs = {}
+    tune = _AUTOTUNE and not torch.cuda.is_current_stream_capturing()
+    for i, src in enumerate(srcs):
+        hh, ww = h >> i, w >> i
+        p = ConvParams()
+        p.C0, p.C1, p.B, p.Hin, p.Win, p.Cout, p.Hout, p.Wout = D, 0, 1, hh, ww, N, hh, ww
+        p.kh = p.kw = p.sy = p.sx = p.dil_y = p.dil_x = 1
+        p.terms, p.out_ctot = 3, N
+        key = (D, hh, ww)
+        cfg = _ALLPAIRS_PICK.get(key)
+        if cfg is None:
+            ok = [c for c in _ALLPAIRS_CFGS if _cfg_ok(lib, p, c)]
+            if not ok:
+                raise _abi.CoddHipError("all-pairs: no split-bf16 configuration for a %dx%d map" % (hh, ww))
+            cfg = _allpairs_tune(lib, p, ok, f1[0], N, D) if tune else ok[0]
+            if tune:
+                _ALLPAIRS_PICK[key] = cfg  # (un-tuned picks are not remembered: a later eager call may still time them)
+        xs = split_input_as(src, "split", cands=[cfg], p=p)
+        for b in range(B):
+            pk = (cfg[3], cfg[2])
+            if (pk, b) not in packs:  # weights[co = n1][ci = d] = f1[b, d, n1] / 16 for this (mb, ck)
+                nbytes = lib.codd_conv2d_packed_bytes_bf16(N, D, 1, 1, cfg[3], cfg[2], 3)
+                wp = torch.empty(nbytes, device=f1.device, dtype=torch.uint8)
+                _abi.check(lib.codd_conv2d_pack_weights_bf16(f1[b].data_ptr(), wp.data_ptr(), N, D, 1, 1, cfg[3], cfg[2], 3,
+                                                             1, N, 1.0 / 16.0, _stream()), "pack_weights_bf16")
+                packs[(pk, b)] = wp
+            p.wpacked = packs[(pk, b)].data_ptr()
+            p.out = lv[i][b].data_ptr()
+            p.xs = xs.buf.data_ptr() + b * (xs.buf.numel() // B)
+            p.xs_c8, p.xs_hp, p.xs_wp, p.xs_bt, p.xs_bl, p.xs_o8 = xs.c8, xs.hp, xs.wp, xs.bt, xs.bl, 0
+            p.npb, p.nw, p.ck, p.mb, p.layout, p.pgw, p.cgw = cfg[:7]
+            p.ksplit = cfg[8]
+            _abi.check(_launch_conv(lib, p, _stream()), "allpairs conv")
+    return lv
+
+
+def split_input_as(x, mode, cands, p):
+    """codd_split_bf16 of ``x`` (3 terms) sized for the configurations ``cands`` of the conv described by ``p``."""
+    lib = _abi.load()
+    c8, hp, wp = _split_dims(p, cands)
+    B, C0, H, W = x.shape
+    buf = torch.empty(lib.codd_split_bf16_bytes(B, c8, hp, wp, 3), device=x.device, dtype=torch.uint8)
+    _abi.check(lib.codd_split_bf16(_view(x), C0, _view(None), 0, B, H, W, 0, 0, c8, hp, wp, 3, buf.data_ptr(), _stream()),
+               "codd_split_bf16")
+    return SplitTensor(buf, B, C0, H, W, 0, 0, hp, wp, c8, 3)
+
+
+def _allpairs_tune(lib, p, cands, f1b, N, D):
+    """Time the accepted all-pairs configurations on this level's shape (own split input / weights per candidate)."""
+    best, best_t = cands[0], float("inf")
+    src = torch.zeros(1, D, p.Hin, p.Win, device=f1b.device)
+    for c in cands:
+        xs = split_input_as(src, "split", [c], p)
+        nbytes = lib.codd_conv2d_packed_bytes_bf16(N, D, 1, 1, c[3], c[2], 3)
+        wp = torch.empty(nbytes, device=f1b.device, dtype=torch.uint8)
+        lib.codd_conv2d_pack_weights_bf16(f1b.data_ptr(), wp.data_ptr(), N, D, 1, 1, c[3], c[2], 3, 1, N, 1.0 / 16.0, _stream())
+        p.wpacked, p.xs = wp.data_ptr(), xs.buf.data_ptr()
+        p.xs_c8, p.xs_hp, p.xs_wp, p.xs_bt, p.xs_bl, p.xs_o8 = xs.c8, xs.hp, xs.wp, xs.bt, xs.bl, 0
+        p.npb, p.nw, p.ck, p.mb, p.layout, p.pgw, p.cgw = c[:7]
+        p.ksplit = c[8]
+        if lib.codd_conv2d(C.byref(p), _stream()) != 0:
+            continue
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(3):
+            lib.codd_conv2d(C.byref(p), _stream())
+        e.record()
+        e.synchronize()
+        t = s.elapsed_time(e) / 3
+        if t < best_t * 0.97:
+            best, best_t = c, t
+    AUTOTUNE_LOG.append(("allpairs %dx%d" % (p.Hin, p.Win), cands[0], None, best, best_t * 1e3))
+    return best
+
+
+def allpairs_corr(f1, f2, split=None):
+    """-> 4 pyramid levels [B, h*w, (h>>i)*(w>>i)] (reference blocks/corr.py:28-45).  ``split`` (default: the "split"
+    conv precision is active): the GEMMs run on the split-bf16 kernel (allpairs_corr_split), else on exact-fp32 MFMA."""
+    if split is None:
+        split = CONV_PRECISION == "split" and ALLPAIRS_SPLIT
+    if split:
+        return allpairs_corr_split(f1, f2)
     lib = _abi.load()
     _require_gpu(f1)
     B, D, h, w = f1.shape
