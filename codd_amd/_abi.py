@@ -99,6 +99,7 @@ SIGNATURES = {
     "codd_gru_gate_q_xs": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, XsView, _p]),
     "codd_fusion_cues_lr": (_i, [_p] * 6 + [_i] * 7 + [_p, _p, _i, _i, _p]),
     "codd_fusion_cues_fr": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "codd_fusion_forget": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p]),
     "codd_disp_metrics": (_i, [_p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p]),
     "codd_raft_geometry_lookup": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p, _p]),
     "codd_raft_geometry_lookup_xs": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _p, XsView, XsView, _p]),

@@ -186,6 +186,105 @@ extern "C" int codd_fusion_cues_fr(const float* pred_curr, const float* pred_war
 }
 
 // ------------------------------------------------------------------------------------------------
+// The whole full-resolution forget branch in ONE kernel (reference fusion.py:123-132, 243-318, 383-394): cues ->
+// forget_head = Conv1x1(nc -> 16) -> Conv3x3(16 -> 8, zero padding) -> Conv1x1(8 -> 1) -> sigmoid.  The head has no
+// non-linearity before the sigmoid, so it IS one 3x3 convolution of the cue map with the merged weights
+//     W_eff[k] = w2 . W1[:, :, k] . W0   (1 x nc per tap k),   beta_k = w2 . W1[:, :, k] . b0,   c0 = w2 . b1 + b2,
+// where tap k only contributes (its weights AND its bias beta_k) if the neighbour lies inside the image -- the zero
+// padding of the 3x3 acts on the 16-channel map, bias included.  Host code merges the weights (fp64), this kernel
+// evaluates   wr(p) = sigmoid(c0 + sum_{k, p + k inside} (W_eff[k] . cues(p + k) + beta_k)):
+// the nc-channel cue tensor (70.8 MB at 960x576), the 16- and the 8-channel maps never exist; HBM traffic is the 8
+// input planes once + one output plane (22 MB with the blend).
+// Workgroup = 16 x 16 outputs; pc / pw tiles with halo 1 + (P - 1) in LDS; every position of the 18 x 18 halo-1 region
+// computes its nc cues in registers and leaves its nine per-tap dot products in LDS.
+// ------------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(256) void fusion_forget_kernel(const float* __restrict__ pc_, const float* __restrict__ pw_,
+                                                            const float* __restrict__ flow_warp,
+                                                            const float* __restrict__ conf_warp, int H, int W,
+                                                            const float* __restrict__ weff, float* __restrict__ wr) {
+  constexpr int P2 = P * P, NC = 3 * P2 + 5, HALO = P, TS = 16 + 2 * HALO, RS = 18;  // cue reach P - 1, + 1 for the 3x3
+  __shared__ float spc[TS * TS], spw[TS * TS];
+  __shared__ float sd[9][RS * RS];
+  __shared__ __attribute__((aligned(16))) float sw[9 * NC + 12];  // W_eff [9][NC] | beta[9] | c0
+  const int tid = threadIdx.x, b = blockIdx.z;
+  const int y0 = blockIdx.y * 16, x0 = blockIdx.x * 16;
+  const size_t N = (size_t)H * W;
+  const float* pcb = pc_ + (size_t)b * N;
+  const float* pwb = pw_ + (size_t)b * N;
+  for (int e = tid; e < 9 * NC + 10; e += 256) sw[e] = weff[e];
+  for (int e = tid; e < TS * TS; e += 256) {
+    const int yy = y0 - HALO + e / TS, xx = x0 - HALO + e % TS;
+    const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+    const size_t a = in ? (size_t)yy * W + xx : 0;
+    const float c = pcb[a], w_ = pwb[a];
+    spc[e] = in ? c : 0.f;
+    spw[e] = in ? w_ : 0.f;
+  }
+  __syncthreads();
+  for (int q = tid; q < RS * RS; q += 256) {
+    const int ry = q / RS, rx = q - ry * RS;
+    const int y = y0 - 1 + ry, x = x0 - 1 + rx;
+    float d[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) d[k] = 0.f;
+    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+      const int ly = ry - 1 + HALO, lx = rx - 1 + HALO;  // position inside the pc / pw tiles
+      const float pc = spc[ly * TS + lx], pw = spw[ly * TS + lx];
+      float cue[NC];
+#pragma unroll
+      for (int k = 0; k < P2; ++k) {
+        const int o = (ly + 2 * (k / P) - (P - 1)) * TS + lx + 2 * (k % P) - (P - 1);
+        const float mc = spc[o], mw = spw[o];
+        cue[k] = fabsf(pc - mw);
+        if (k != P2 / 2) {
+          const int kk = k < P2 / 2 ? k : k - 1;
+          cue[P2 + kk] = fabsf(pc - mc);
+          cue[2 * P2 - 1 + kk] = fabsf(pw - mw);
+        }
+      }
+      const size_t pix = (size_t)y * W + x;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        cue[3 * P2 - 2 + c] = flow_warp[((size_t)b * 3 + c) * N + pix];
+        cue[3 * P2 + 2 + c] = conf_warp[((size_t)b * 3 + c) * N + pix];
+      }
+      cue[3 * P2 + 1] = pw > 0.f ? 1.f : 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        float a = sw[9 * NC + k];  // beta_k
+#pragma unroll
+        for (int c = 0; c < NC; ++c) a = fmaf(sw[k * NC + c], cue[c], a);
+        d[k] = a;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sd[k][q] = d[k];
+  }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+  const int y = y0 + ty, x = x0 + tx;
+  if (y >= H || x >= W) return;
+  float v = sw[9 * NC + 9];  // c0
+#pragma unroll
+  for (int k = 0; k < 9; ++k) v += sd[k][(ty + k / 3) * RS + tx + k % 3];  // tap k reads position p + (k/3 - 1, k%3 - 1)
+  wr[(size_t)b * N + (size_t)y * W + x] = 1.f / (1.f + expf(-v));
+}
+
+extern "C" int codd_fusion_forget(const float* pred_curr, const float* pred_warp, const float* flow_warp,
+                                  const float* conf_warp, int B, int H, int W, int patch, const float* weff, float* wr,
+                                  void* stream) {
+  if (!pred_curr || !pred_warp || !flow_warp || !conf_warp || !weff || !wr || B < 1 || H < 1 || W < 1) return CODD_EINVAL;
+  dim3 grid(cdiv(W, 16), cdiv(H, 16), B);
+  hipStream_t s = (hipStream_t)stream;
+  if (patch == 3) fusion_forget_kernel<3><<<grid, 256, 0, s>>>(pred_curr, pred_warp, flow_warp, conf_warp, H, W, weff, wr);
+  else if (patch == 5) fusion_forget_kernel<5><<<grid, 256, 0, s>>>(pred_curr, pred_warp, flow_warp, conf_warp, H, W, weff, wr);
+  else return CODD_EUNSUPPORTED;
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Blend (reference fusion.py:344-355 nearest x4 up-sampling of the fusion weights, :383-394).
 // ------------------------------------------------------------------------------------------------
 __global__ void fusion_blend_kernel(const float* __restrict__ pc_, const float* __restrict__ pw_,

@@ -4,6 +4,8 @@ The reference's "fusion" has no GRU: it is key projection,
 correlation cues, two small conv heads and a blend.  The cue tensors are produced by two fused
 kernels (csrc/fusion.hip); the heads run on the MFMA conv family.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -11,6 +13,8 @@ from . import ops
 from .ops import Slice
 from .registry import build_loss, register
 from .stereo import cv
+
+FUSE_FORGET = os.environ.get("CODD_FUSE_FORGET", "1") == "1"  # (A/B switch: Fusion.memory_query forget branch)
 
 
 class BasicBlock(nn.Module):
@@ -47,6 +51,22 @@ class Fusion(ops.RuntimeState, nn.Module):
                                          nn.Conv2d(8, 1, 1), nn.Identity(), nn.Sigmoid())
         self.residual_conv = nn.Sequential(nn.Conv2d(fc * 2, fc, 3, padding=1), nn.ReLU(inplace=True))
 
+    def forget_matrix(self):
+        """forget_head (1x1 nc->16, 3x3 16->8, 1x1 8->1: no non-linearity in between, reference fusion.py:123-132) merged
+        into one 3x3 convolution of the cue map, as codd_fusion_forget takes it: [W_eff 9 x nc | beta 9 | c0] fp32,
+        products formed in fp64; cached per parameter version."""
+        m0, m1, m2 = self.forget_head[0], self.forget_head[1], self.forget_head[2]
+        ver = tuple((m.weight.data_ptr(), m.weight._version, m.bias._version) for m in (m0, m1, m2))
+        c = self.__dict__.get("_codd_forget_matrix")
+        if c is None or c[0] != ver:
+            W0, b0 = m0.weight.detach().double()[:, :, 0, 0], m0.bias.detach().double()      # [16, nc], [16]
+            W1, b1 = m1.weight.detach().double(), m1.bias.detach().double()                  # [8, 16, 3, 3], [8]
+            w2, b2 = m2.weight.detach().double()[0, :, 0, 0], m2.bias.detach().double()[0]   # [8]
+            A = torch.einsum("o,oikl->kli", w2, W1).reshape(9, -1)                           # [9, 16]: w2 . W1[:, :, k]
+            weff = torch.cat([(A @ W0).reshape(-1), A @ b0, (w2 @ b1 + b2).reshape(1)]).float().contiguous()
+            c = self.__dict__["_codd_forget_matrix"] = (ver, weff)
+        return c[1]
+
     def _key(self, x):
         """reference fusion.py:74-80."""
         k = self.key_layer
@@ -75,6 +95,11 @@ class Fusion(ops.RuntimeState, nn.Module):
             self._fk = ops.Fork(pred_curr.device, 1)
 
         def forget_chain():
+            if FUSE_FORGET and self.forget_head[1].kernel_size == (3, 3) and self.forget_head[1].padding == (1, 1):
+                # cues + the (linear) forget head + sigmoid as ONE kernel: the 32-channel full-resolution cue tensor
+                # (70.8 MB at 960x576) and the 16- / 8-channel maps are never materialised
+                return ops.fusion_forget(pred_curr, pred_warp, flow_warp, conf_warp, self.forget_matrix(),
+                                         patch=self.patch_size)
             cues_fr = ops.fusion_cues_fr(pred_curr, pred_warp, flow_warp, conf_warp, patch=self.patch_size)
             t = cv(self.forget_head[1], cv(self.forget_head[0], cues_fr))
             return cv(self.forget_head[2], t, act="sigmoid")

@@ -1298,6 +1298,19 @@ def fusion_cues_fr(pred_curr, pred_warp, flow_warp, conf_warp, patch=3):
     return out
 
 
+def fusion_forget(pred_curr, pred_warp, flow_warp, conf_warp, weff, patch=3):
+    """cues -> forget head -> sigmoid in one launch (codd_fusion_forget); ``weff`` = the merged head
+    [W_eff 9 x nc | beta 9 | c0] (fusion.Fusion.forget_matrix).  -> wr [B,1,H,W]."""
+    lib = _abi.load()
+    B, _, H, W = pred_curr.shape
+    assert weff.numel() == 9 * (3 * patch * patch + 5) + 10 and weff.is_contiguous()
+    wr = torch.empty_like(pred_curr)
+    _abi.check(lib.codd_fusion_forget(pred_curr.data_ptr(), pred_warp.data_ptr(), flow_warp.data_ptr(),
+                                      conf_warp.data_ptr(), B, H, W, patch, weff.data_ptr(), wr.data_ptr(), _stream()),
+               "fusion_forget")
+    return wr
+
+
 def fusion_blend(pred_curr, pred_warp, wf_lr, wr, ds=4):
     lib = _abi.load()
     B, _, H, W = pred_curr.shape

@@ -381,6 +381,16 @@ int codd_fusion_cues_lr(const float* pred_curr, const float* pred_warp, const fl
 int codd_fusion_cues_fr(const float* pred_curr, const float* pred_warp, const float* flow_warp,
                         const float* conf_warp, int B, int H, int W, int patch, float* out, void* stream);
 
+/* The full-resolution forget branch in one launch (fusion.py:123-132, 243-318): the cue map of codd_fusion_cues_fr fed
+ * through forget_head = Conv1x1(nc->16), Conv3x3(16->8, pad 1), Conv1x1(8->1), Sigmoid without materialising the cue
+ * tensor or the 16- / 8-channel maps.  The head is linear up to the sigmoid, so the caller passes it MERGED:
+ *   weff = [ W_eff[9][nc] | beta[9] | c0 ],  W_eff[k] = w2.W1[:,:,k].W0,  beta_k = w2.W1[:,:,k].b0,  c0 = w2.b1 + b2
+ * (nc = 3 patch^2 + 5; tap k = ky*3 + kx of the 3x3).  A tap contributes W_eff[k].cues(p+k) + beta_k only where p+k lies
+ * inside the image (the 3x3's zero padding acts on the biased 16-channel map).  wr [B,1,H,W] = sigmoid(...). */
+int codd_fusion_forget(const float* pred_curr, const float* pred_warp, const float* flow_warp,
+                       const float* conf_warp, int B, int H, int W, int patch, const float* weff, float* wr,
+                       void* stream);
+
 /* Blend (fusion.py:383-394): wf = up4(wf_lr) * (pw>0); wr *= (pw>0);
  * fused = pc*(1-wf*wr) + pw*wf*wr. */
 int codd_fusion_blend(const float* pred_curr, const float* pred_warp, const float* wf_lr,

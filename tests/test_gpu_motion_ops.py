@@ -862,3 +862,32 @@ def test_split_graphs_equal_single_graph():
         assert r.graph is not None
     for a, b in zip(*outs):
         assert (a - b).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("patch", [3, 5])
+def test_fused_forget_branch_equals_cues_plus_head_convolutions(patch):
+    """codd_fusion_forget (cues + merged linear forget head + sigmoid in one launch; the cue tensor is never written)
+    against torch on the materialised cue tensor of codd_fusion_cues_fr -- layer by layer, as the reference evaluates
+    forget_head (fusion.py:123-132) -- incl. image borders (the 3x3's zero padding acts on the BIASED 16-channel map),
+    warped-disparity holes and a map that is not a multiple of the 16x16 tile."""
+    from codd_amd import configs, ops, synth
+    from codd_amd.registry import MODELS
+    H, W = 50, 77
+    cfg = dict(configs.codd(iters=2)["fusion"])
+    cfg["corr_cfg"] = dict(cfg.get("corr_cfg", {}), patch_size=patch)
+    fus = MODELS.build(cfg).to(DEV).eval()
+    g = torch.Generator().manual_seed(patch)
+    for prm in fus.forget_head.parameters():
+        prm.data = (torch.randn(prm.shape, generator=g) * 0.3).to(DEV)
+    pc = (rnd(1, 1, H, W, seed=1).abs() * 20 + 1).to(DEV)
+    pw = (rnd(1, 1, H, W, seed=2).abs() * 20 + 1)
+    pw[:, :, 10:20, 30:44] = 0.0  # holes of the warped disparity
+    pw = pw.to(DEV)
+    flow, conf = rnd(1, 3, H, W, seed=3).to(DEV), rnd(1, 3, H, W, seed=4).abs().to(DEV)
+    cues = ops.fusion_cues_fr(pc, pw, flow, conf, patch=patch).cpu()
+    fh = fus.forget_head.cpu()
+    ref = torch.sigmoid(fh[2](fh[1](fh[0](cues))))
+    fus.forget_head.to(DEV)
+    got = ops.fusion_forget(pc, pw, flow, conf, fus.forget_matrix(), patch=patch).cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < 2e-5, (got - ref).abs().max().item()
