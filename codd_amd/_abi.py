@@ -73,6 +73,7 @@ SIGNATURES = {
     "codd_hyp_upsample": (_i, [View, _i, _i, _i, _f, _p, _i, _i, _p]),
     "codd_hyp_select": (_i, [_p, View, View, _i, _i, _i, _p, _i, _i, _p]),
     "codd_instnorm": (_i, [_p, _i, _i, _i, _p, _p, _i, _p, _p]),
+    "codd_instnorm_xs": (_i, [_p, _i, _i, _i, _i, _p, _p, _i, _i, _p, XsView, _p]),
     "codd_conv2d_pack_weights_ex": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _ll, _ll, _f, _p]),
     "codd_allpairs_corr": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "codd_allpairs_corr_scratch": (_ll, [_i, _i, _i, _i]),

@@ -86,6 +86,74 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __rest
   }
 }
 
+// The apply pass writing the NEXT convolution's input form: one thread = the 8 channels of an octet at one pixel ->
+// one split-bf16 record (hi | lo) through xs_store8, optionally the fp32 tensor as well (residual operand of the block
+// output).  v = norm(x); [relu]; [+ res; [relu]] -- the second ReLU is the one a residual block applies after adding
+// its input (reference blocks/extractor.py:52-58), so InstanceNorm -> ReLU -> (+ x) -> ReLU -> re-layout is one launch.
+__global__ __launch_bounds__(256) void instnorm_apply_xs_kernel(const float* __restrict__ x,
+                                                                const double* __restrict__ partial, int parts,
+                                                                const float* __restrict__ res, int C, int H, int W,
+                                                                int relu, int relu2, float* __restrict__ y,
+                                                                const codd_xs_view xs) {
+  __shared__ float st[8][2];
+  const int HW = H * W, oct = blockIdx.y, b = blockIdx.z;
+  const int bc0 = b * C + oct * 8;
+  if (threadIdx.x < 64) {
+    for (int c = 0; c < 8; ++c) {
+      double s = 0.0, q = 0.0;
+      if ((int)threadIdx.x < parts) {
+        s = partial[((size_t)(bc0 + c) * parts + threadIdx.x) * 2];
+        q = partial[((size_t)(bc0 + c) * parts + threadIdx.x) * 2 + 1];
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+      if (threadIdx.x == 0) {
+        const double md = s / HW;
+        const double var = fmax(q / HW - md * md, 0.0);
+        st[c][0] = (float)((double)x[(size_t)(bc0 + c) * HW] + md);
+        st[c][1] = (float)(1.0 / sqrt(var + 1e-5));
+      }
+    }
+  }
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= HW) return;
+  float v[8], r[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v[c] = x[(size_t)(bc0 + c) * HW + i];
+  if (res) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) r[c] = res[(size_t)(bc0 + c) * HW + i];
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float t = (v[c] - st[c][0]) * st[c][1];
+    if (relu) t = fmaxf(t, 0.f);
+    if (res) { t += r[c]; if (relu2) t = fmaxf(t, 0.f); }
+    v[c] = t;
+    if (y) y[(size_t)(bc0 + c) * HW + i] = t;
+  }
+  xs_store8(xs, b, oct, i / W, i % W, v);
+}
+
+extern "C" int codd_instnorm_xs(const float* x, int B, int C, int H, int W, float* stats, const float* res, int relu,
+                                int relu_after_res, float* y, codd_xs_view xs, void* stream) {
+  const int HW = H * W;
+  if (!x || !stats || B < 1 || C < 8 || (C & 7) || HW < 1 || ((uintptr_t)stats & 7) || !xs_view_ok(xs, C, H, W))
+    return CODD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  int parts = cdiv(2048, B * C);
+  parts = parts < 1 ? 1 : (parts > IN_MAXPARTS ? IN_MAXPARTS : parts);
+  if (parts > cdiv(HW, 1024)) parts = cdiv(HW, 1024);
+  double* partial = (double*)stats;
+  instnorm_stats_kernel<<<dim3(parts, B * C), 256, 0, s>>>(x, HW, parts, partial);
+  CODD_LAUNCH_CHECK();
+  instnorm_apply_xs_kernel<<<dim3(cdiv(HW, 256), C / 8, B), 256, 0, s>>>(x, partial, parts, res, C, H, W, relu,
+                                                                         relu_after_res, y, xs);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
 extern "C" int codd_instnorm(const float* x, int B, int C, int HW, float* stats, const float* res, int relu,
                              float* y, void* stream) {
   if (!x || !stats || !y || B < 1 || C < 1 || HW < 1 || ((uintptr_t)stats & 7)) return CODD_EINVAL;
@@ -521,6 +589,14 @@ static __host__ __device__ __forceinline__ int gn_groups(int nj, int q4, int gma
   return g < 1 ? 1 : (g > gmax ? gmax : g);
 }
 
+#ifdef GN_STATS
+__device__ unsigned long long gn_stats[2];
+extern "C" int codd_gn_stats(unsigned long long* out, int reset) {  // dev builds only (not part of the ABI)
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(gn_stats), 16) != hipSuccess) return CODD_EINVAL;
+  if (reset) { const unsigned long long z[2] = {0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(gn_stats), z, 16) != hipSuccess) return CODD_EINVAL; }
+  return CODD_OK;
+}
+#endif
 __global__ __launch_bounds__(64 * GN_WAVES) void se3_gn_build_kernel(
     const float* __restrict__ T, const float* __restrict__ jd, int h, int w, float fx, float fy, float cx, float cy,
     int radius, int tiles_x, int ntiles, int q4, int gmax, float* __restrict__ part) {
@@ -590,7 +666,12 @@ __global__ __launch_bounds__(64 * GN_WAVES) void se3_gn_build_kernel(
       const float a = in ? __builtin_amdgcn_rcpf(1.f + __expf(d2)) : 0.f;  // sigmoid(-d2), masked
       // the affinity of far neighbours underflows against the accumulated sums: skip their geometry when every
       // lane's weight is below 1e-9 (relative effect on H, b < 1e-9; wave-uniform branch)
+#ifdef GN_STATS  // dev build (tools/gn_skip_rate.py): neighbour visits / visits skipped by the test below, per wave
+      if (lane == 0) atomicAdd(&gn_stats[0], 1ull);
+      if (__ballot(a > 1e-9f) == 0ull) { if (lane == 0) atomicAdd(&gn_stats[1], 1ull); continue; }
+#elif !defined(GN_NO_SKIP)
       if (__ballot(a > 1e-9f) == 0ull) continue;
+#endif
       const float Yx = fmaf(c0.x, Xx, fmaf(c1.x, Xy, fmaf(c2.x, Xz, Ti.t.x)));
       const float Yy = fmaf(c0.y, Xx, fmaf(c1.y, Xy, fmaf(c2.y, Xz, Ti.t.y)));
       const float d = __builtin_amdgcn_rcpf(fmaxf(Yz, MIN_DEPTH));

@@ -23,6 +23,7 @@ from .stereo import cv, packed
 
 BF_DEFAULT = 1050 * 0.2  # reference motion.py:45
 MERGE_ENC_HEADS = os.environ.get("CODD_MERGE_ENC_HEADS", "1") == "1"  # (A/B switch; see BasicUpdateBlock.run)
+FUSE_NORM_RECORDS = os.environ.get("CODD_FUSE_NORM_RECORDS", "1") == "1"  # (A/B switch; see ResidualBlock.run)
 
 def packed_cat(mods):
     """One PackedConv whose output channels are the concatenation of several same-shape convs; cached on the first
@@ -63,12 +64,27 @@ class ResidualBlock(nn.Module):
         self.conv2 = nn.Conv2d(planes, planes, 3, padding=1)
         self.downsample = None if stride == 1 else nn.Sequential(nn.Conv2d(in_planes, planes, 1, stride=stride))
 
-    def run(self, x):
-        y = ops.instnorm(cv(self.conv1, x), relu=True)
-        y = ops.instnorm(cv(self.conv2, y), relu=True)
+    def run(self, x, xs=None):
+        """-> (block output fp32, the same as split-bf16 records | None).  In the split / bf16 precision modes the
+        InstanceNorm apply passes write the following convolution's input records themselves (ops.instnorm xs_out):
+        norm -> ReLU -> records for conv2, and norm -> ReLU -> + x -> ReLU -> fp32 + records for the block output --
+        no re-layout launches and no separate add (9 -> 6 launches per block)."""
+        B, _, H, W = x.shape
+        sy = self.conv1.stride[0]
+        Ho, Wo, C = (H + 2 - 3) // sy + 1, (W + 2 - 3) // sy + 1, self.conv1.out_channels
+        y1 = ops.split_buffer((id(self), "y1"), B, C, Ho, Wo, 1, x.device) if FUSE_NORM_RECORDS else None
+        if y1 is None:
+            y = ops.instnorm(cv(self.conv1, x), relu=True)
+            y = ops.instnorm(cv(self.conv2, y), relu=True)
+            if self.downsample is not None:
+                x = ops.instnorm(cv(self.downsample[0], x), relu=False)
+            return ops.add_relu(x, y, relu=True), None
+        ops.instnorm(cv(self.conv1, x, xs=xs), relu=True, xs_out=y1, want_fp32=False)
+        t = cv(self.conv2, None, xs=y1)
         if self.downsample is not None:
             x = ops.instnorm(cv(self.downsample[0], x), relu=False)
-        return ops.add_relu(x, y, relu=True)
+        out_xs = ops.split_buffer((id(self), "out"), B, C, Ho, Wo, 1, x.device)
+        return ops.instnorm(t, relu=True, res=x, res_relu=True, xs_out=out_xs), out_xs
 
 
 class BasicEncoder(nn.Module):
@@ -83,11 +99,14 @@ class BasicEncoder(nn.Module):
         self.conv2 = nn.Conv2d(128, output_dim, 1)
 
     def forward(self, x):
-        x = ops.instnorm(cv(self.conv1, x), relu=True)
+        t = cv(self.conv1, x)
+        B, C, H, W = t.shape
+        xs = ops.split_buffer((id(self), "stem"), B, C, H, W, 1, x.device) if FUSE_NORM_RECORDS else None
+        x = ops.instnorm(t, relu=True, xs_out=xs)
         for layer in (self.layer1, self.layer2, self.layer3):
             for blk in layer:
-                x = blk.run(x)
-        return cv(self.conv2, x)
+                x, xs = blk.run(x, xs)
+        return cv(self.conv2, x, xs=xs)
 
 
 # ------------------------------------------------------------------------------------- update block

@@ -877,11 +877,21 @@ def _f32(*shape, like):
     return torch.empty(*shape, device=like.device, dtype=torch.float32)
 
 
-def instnorm(x, relu=True, res=None):
+def instnorm(x, relu=True, res=None, res_relu=False, xs_out=None, want_fp32=True):
+    """InstanceNorm2d(+ReLU).  Plain form: relu(norm(x) + res).  With ``xs_out`` (a split_buffer tensor of the same
+    size) the result is written as split-bf16 records -- the next convolution's input -- by the apply pass itself:
+    v = norm(x); relu; [+ res; res_relu]; the fp32 tensor is only written (and returned) when ``want_fp32``."""
     lib = _abi.load()
     _require_gpu(x)
     B, Cc, H, W = x.shape
     stats = _f32(128 * B * Cc, like=x)
+    if xs_out is not None:
+        assert (xs_out.B, xs_out.H, xs_out.W) == (B, H, W) and Cc % 8 == 0 and Cc <= 8 * xs_out.c8
+        y = torch.empty_like(x) if want_fp32 else None
+        _abi.check(lib.codd_instnorm_xs(x.data_ptr(), B, Cc, H, W, stats.data_ptr(), _ptr(res), int(relu), int(res_relu),
+                                        _ptr(y), _xs_view(xs_out), _stream()), "instnorm_xs")
+        return y
+    assert not res_relu
     y = torch.empty_like(x)
     _abi.check(lib.codd_instnorm(x.data_ptr(), B, Cc, H * W, stats.data_ptr(),
                                  None if res is None else res.data_ptr(), int(relu), y.data_ptr(), _stream()),

@@ -243,6 +243,12 @@ int codd_hyp_select(const float* upd, codd_view cur, codd_view prev, int B, int 
  * stats: 8-byte aligned scratch of 128*B*C floats (fp64 partial moments, <= 32 parts per plane). */
 int codd_instnorm(const float* x, int B, int C, int HW, float* stats, const float* res, int relu,
                   float* y, void* stream);
+/* ... with the result written as split-bf16 records (the next convolution's input form, codd_xs_view: image interior
+ * only) and, when y != NULL, as fp32 too:  v = norm(x); relu ? max(v,0); res ? (v += res; relu_after_res ? max(v,0)).
+ * The second ReLU is the residual block's (blocks/extractor.py:52-58): InstanceNorm -> ReLU -> + x -> ReLU -> re-layout
+ * in one launch.  C must be a multiple of 8. */
+int codd_instnorm_xs(const float* x, int B, int C, int H, int W, float* stats, const float* res, int relu,
+                     int relu_after_res, float* y, codd_xs_view xs, void* stream);
 
 /* All-pairs correlation pyramid (CorrBlock.__init__/corr, blocks/corr.py:28-45,56-62):
  * lvl0[n1,n2] = <f1[:,n1], f2[:,n2]> / 16, lvl_{i+1} = avg_pool2d(lvl_i, 2) over (y2,x2), computed by

@@ -1,9 +1,10 @@
-"""Turn gpurun_out/prof_final/* (tools/profile_round.sh) into the committed summaries under profiles/:
-  r02_kernel_stats_{serial,default}.{csv,md}, r02_pmc_counters.md, r02_conv_traffic.json
-usage: python tools/make_profile_md.py [frames_in_stats_run=97] [frames_in_pmc_run=8]"""
+"""Turn gpurun_out/prof_<ROUND><TAG>/* (tools/profile_round.sh) into the committed summaries under profiles/:
+  <ROUND><TAG>_kernel_stats_{serial,default}.{csv,md}, <ROUND><TAG>_pmc_counters.md, <ROUND><TAG>_conv_traffic.json
+usage: ROUND=r03 TAG=_cfg4_1280x384 python tools/make_profile_md.py [frames_in_stats_run=217] [frames_in_pmc_run=8]"""
 import csv, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC, DST = os.path.join(ROOT, "gpurun_out", "prof_r02"), os.path.join(ROOT, "profiles")
+RT = os.environ.get("ROUND", "r03") + os.environ.get("TAG", "")
+SRC, DST = os.path.join(ROOT, "gpurun_out", "prof_" + RT), os.path.join(ROOT, "profiles")
 frames = float(sys.argv[1]) if len(sys.argv) > 1 else 217.0
 
 
@@ -17,7 +18,7 @@ def bench_line(mode):
 stats = {}
 for mode in ("serial", "default"):
     rows = list(csv.DictReader(open(os.path.join(SRC, f"{mode}_kernel_stats.csv"))))
-    shutil.copy(os.path.join(SRC, f"{mode}_kernel_stats.csv"), os.path.join(DST, f"r02_kernel_stats_{mode}.csv"))
+    shutil.copy(os.path.join(SRC, f"{mode}_kernel_stats.csv"), os.path.join(DST, f"{RT}_kernel_stats_{mode}.csv"))
     tot = sum(int(r["TotalDurationNs"]) for r in rows)
     conv = [r for r in rows if "conv_bf16_kernel" in r["Name"]]
     conv32 = [r for r in rows if "conv_mfma_kernel" in r["Name"] or "conv_quad_kernel" in r["Name"]]
@@ -25,8 +26,8 @@ for mode in ("serial", "default"):
     cn, ct = sum(int(r["Calls"]) for r in conv), sum(int(r["TotalDurationNs"]) for r in conv)
     b = bench_line(mode)
     stats[mode] = dict(rows=rows, tot=tot, conv_calls=cn, conv_ns=ct)
-    with open(os.path.join(DST, f"r02_kernel_stats_{mode}.md"), "w") as f:
-        f.write(f"# rocprofv3 --kernel-trace --stats: round 2, {'serial streams' if mode == 'serial' else 'default schedule (side streams ON)'}\n\n")
+    with open(os.path.join(DST, f"{RT}_kernel_stats_{mode}.md"), "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats: {RT}, {'serial streams' if mode == 'serial' else 'default schedule (side streams ON)'}\n\n")
         f.write(f"Command (tools/profile_round.sh): `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --no-cpu-baseline --tune-db <db>{' --serial-streams' if mode == 'serial' else ''}` "
                 f"({frames:.0f} frames: 1 priming + 150 pre-warm + 5 warm-up + 60 timed + 1 eager roofline frame; launch configurations = the shipped codd_amd/tuned/mi355x.json, so no tuning launches are in the statistics).\n\n")
         f.write(f"bench.py under the profiler: {b.get('value')} frames/s, {b.get('ms_per_step')} ms/step (the profiler slows the run and inflates bench.py's own event brackets: "
@@ -58,20 +59,20 @@ conv_n = sum(v[1] for (k, c), v in fetch.items() if "conv_bf16_kernel" in k)
 # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts
 # wide coalesced reads at half their size -> traffic upper estimate = 2 * FETCH + WRITE
 traffic_per_launch = (2 * conv_f + conv_w) * 1024.0 / conv_n
-json.dump(dict(family="split_bf16", kernel="conv_bf16_kernel<*>", launches=conv_n, fetch_kib_per_launch=conv_f / conv_n,
+json.dump(dict(family="bf16" if "bf16" in RT else "split_bf16", kernel="conv_bf16_kernel<*>", launches=conv_n, fetch_kib_per_launch=conv_f / conv_n,
                write_kib_per_launch=conv_w / conv_n, traffic_bytes_per_launch=traffic_per_launch,
                correction="traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950: FETCH_SIZE counts wide reads at half size)",
                source="tools/profile_round.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) on "
                       "bench.py --serial-streams --no-graph --steps 4"),
-          open(os.path.join(DST, "r02_conv_traffic.json"), "w"), indent=1)
-with open(os.path.join(DST, "r02_pmc_counters.md"), "w") as f:
-    f.write("# rocprofv3 PMC counters per kernel (round 2)\n\n")
+          open(os.path.join(DST, RT + "_conv_traffic.json"), "w"), indent=1)
+with open(os.path.join(DST, RT + "_pmc_counters.md"), "w") as f:
+    f.write(f"# rocprofv3 PMC counters per kernel ({RT})\n\n")
     f.write("Collected by `tools/profile_round.sh`: three separate passes of `rocprofv3 --kernel-trace --pmc <set> -- python bench.py "
             "--no-cpu-baseline --serial-streams --steps 4 --prewarm 2 --warmup 1 --no-graph` with the sets `FETCH_SIZE`, `WRITE_SIZE`, "
             "`SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES`.  FETCH_SIZE / WRITE_SIZE are KiB; per MI355X_MICROARCH.md "
             "(HBM section) FETCH_SIZE on gfx950 counts wide coalesced reads at half their size, so `traffic = (2*FETCH + WRITE) KiB` "
             "(an upper estimate for narrow gathers).  Durations are the un-counted serial-stream averages of "
-            "`r02_kernel_stats_serial.csv`.\n\n")
+            f"`{RT}_kernel_stats_serial.csv`.\n\n")
     f.write(f"## Convolution families\n\nAll `conv_bf16_kernel<*>` (split-bf16) launches: FETCH {conv_f/conv_n:.0f} KiB + WRITE {conv_w/conv_n:.0f} KiB per launch "
             f"-> L2-miss-side traffic {(traffic_per_launch)/1e6:.2f} MB per launch ({conv_n} launches in the pass).\n\n")
     f.write("| instantiation <NW,NPB,MB,WREG,IREG|QREG> | launches in pass | MFMA busy cycles/launch | MFMA pipe utilisation | FETCH KiB/launch | WRITE KiB/launch |\n|---|---|---|---|---|---|\n")
