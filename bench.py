@@ -163,6 +163,22 @@ def conv_roofline(runner, frames, device):
         chains.append(p.nlayers)
         return rc
 
+    orig_multi = ops._launch_conv_multi
+
+    def timed_multi(lib, params, n, stream):  # several independent small convolutions in one launch
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(torch.cuda.current_stream(device))
+        rc = orig_multi(lib, params, n, stream)
+        e.record(torch.cuda.current_stream(device))
+        fl = sum(2.0 * params[i].C0 * params[i].Cout * params[i].kh * params[i].kw * params[i].Hout * params[i].Wout * params[i].B
+                 for i in range(n))
+        p0 = params[0]
+        recs.append((s, e, fl, (p0.B, p0.C0, p0.Cout, p0.kh, p0.kw, p0.Hout, p0.Wout, -n, 0), 0))
+        multis.append(n)
+        return rc
+
+    multis = []
+    ops._launch_conv_multi = timed_multi
     chains = []
     ops._launch_chain = timed_chain
     ops._launch_conv = timed
@@ -192,6 +208,7 @@ def conv_roofline(runner, frames, device):
     finally:
         ops._launch_conv = orig
         ops._launch_chain = orig_chain
+        ops._launch_conv_multi = orig_multi
         ops.Fork.serial = serial_before
         for fname, fn in saved.items():
             setattr(lib, fname, fn)
@@ -218,7 +235,7 @@ def conv_roofline(runner, frames, device):
             log("conv B%d Cin%-4d Cout%-4d k%dx%d out %3dx%-3d s%d m%d terms%d : n=%3d  %7.3f ms  %6.1f us/launch  %5.1f TF"
                 % (*key, n, ms, ms / n * 1e3, f / ms / 1e9))
     return dict(launches=len(recs), time_ms=t_ms, gflop=flops / 1e9, hbm=hbm,
-                chain_launches=len(chains), chain_layers=sum(chains),
+                chain_launches=len(chains), chain_layers=sum(chains), multi_launches=len(multis), multi_jobs=sum(multis),
                 families={k: dict(launches=v[0], ms=round(v[1], 3), gflop=round(v[2] / 1e9, 2),
                                   issued_gflop=round(v[3] / 1e9, 2)) for k, v in fam.items()})
 
@@ -472,7 +489,8 @@ def main():
                         launches_per_frame=fd["launches"], ms_per_frame=fd["ms"],
                         algorithmic_frac_of_fp32_matrix_peak=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4),
                         families=fams, conv_launches_per_frame=cr["launches"],
-                        chain_launches_per_frame=cr["chain_launches"], conv_layers_inside_chains=cr["chain_layers"], conv_gflop_per_frame=round(cr["gflop"], 2),
+                        chain_launches_per_frame=cr["chain_launches"], conv_layers_inside_chains=cr["chain_layers"],
+                        multi_job_launches_per_frame=cr["multi_launches"], convs_inside_multi_job_launches=cr["multi_jobs"], conv_gflop_per_frame=round(cr["gflop"], 2),
                         conv_ms_per_frame=round(cr["time_ms"], 3),
                         whole_conv_algorithmic_tflops=round(cr["gflop"] / cr["time_ms"], 2),
                         # the HBM-bound kernels of the same frame against SURVEY.md 8(d)'s algorithmic bytes and the 8 TB/s peak

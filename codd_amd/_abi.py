@@ -62,6 +62,7 @@ SIGNATURES = {
     "codd_abi_version": (_i, []),
     "codd_conv2d": (_i, [C.POINTER(ConvParams), _p]),
     "codd_conv2d_check": (_i, [C.POINTER(ConvParams)]),
+    "codd_conv2d_multi": (_i, [C.POINTER(ConvParams), _i, _p]),
     "codd_chain_layer_size": (_ll, [_i, _i, _i]),
     "codd_chain_pack_layer": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "codd_conv_chain_check": (_i, [C.POINTER(ChainParams)]),
@@ -87,6 +88,7 @@ SIGNATURES = {
     "codd_se3_gn_scratch": (_ll, [_i, _i, _i, _i]),
     "codd_se3_gn_step_heads": (_i, [_p, XsView, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f, _p, _p, _p]),
     "codd_cvx_upsample": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
+    "codd_cvx_upsample_se3_weight": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p]),
     "codd_disp_to_depth": (_i, [_p, _ll, _f, _p, _p]),
     "codd_splat": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f,
                         _p, _p, _p, _p]),

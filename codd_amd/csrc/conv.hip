@@ -18,6 +18,7 @@
 
 CONV_ALL_GROUPS(CONV_DECLARE)
 CONVQ_ALL(CONVQ_DECLARE)
+CONVQ_MULTI(CONVQM_DECLARE)
 
 
 __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int ntaps,
@@ -171,17 +172,8 @@ extern "C" int codd_conv2d_check(const codd_conv_params* pp) {
   return codd_conv2d_bf16(pp, nullptr, 1);
 }
 
-extern "C" int codd_conv2d(const codd_conv_params* pp, void* stream) {
-  if (!pp) return CODD_EINVAL;
-  if (pp->layout == 2) {
-    const codd_conv_params& q = *pp;
-    if (!q.xs || (!q.out && !q.xso) || !q.wpacked || q.C0 <= 0 || q.C1 < 0 || q.B < 1 || q.Cout < 1 || q.kh < 1 || q.kw < 1 ||
-        q.pad_l < 0 || q.pad_t < 0)
-      return CODD_EINVAL;
-    if (q.store_mode && (q.kh != 1 || q.kw != 1 || q.res1.ptr || q.res2.ptr || q.post.ptr)) return CODD_EUNSUPPORTED;
-    return codd_conv2d_bf16(pp, stream, 0);
-  }
-  ConvK k;
+/* launch geometry of the exact-fp32 kernels (layouts 0 and 1) for ``pp`` */
+static int conv_fill(const codd_conv_params* pp, ConvK& k, size_t& lds, long long& grid, int& nw) {
   k.p = *pp;
   const codd_conv_params& p = k.p;
   if (!p.in0.ptr || !p.out || !p.wpacked || p.C0 <= 0 || p.C1 < 0 || (p.C1 > 0 && !p.in1.ptr)) return CODD_EINVAL;
@@ -193,7 +185,7 @@ extern "C" int codd_conv2d(const codd_conv_params* pp, void* stream) {
   k.nchunks = cdiv(k.cin, p.ck);
   k.ntaps = p.kh * p.kw;
   const int xb = p.npb >= 2 ? 2 : 1, rpw = p.npb / xb;
-  const int nw = p.nw ? p.nw : 4;
+  nw = p.nw ? p.nw : 4;
   if (nw != 4 && (!(nw == 9 || nw == 2 || nw == 8) || p.npb != 1)) return CODD_EUNSUPPORTED;
   k.th = nw * rpw;
   k.tw = 16 * xb;
@@ -216,7 +208,7 @@ extern "C" int codd_conv2d(const codd_conv_params* pp, void* stream) {
   const size_t hwb = (size_t)p.Hin * p.Win * sizeof(float);
   k.vec_ok = (p.Win % 4 == 0) && ((uintptr_t)p.in0.ptr % 16 == 0) && (hwb % 16 == 0) &&
              (p.C1 == 0 || (uintptr_t)p.in1.ptr % 16 == 0);
-  size_t lds = ((size_t)k.wchunk + (size_t)p.ck * k.chs) * sizeof(float);
+  lds = ((size_t)k.wchunk + (size_t)p.ck * k.chs) * sizeof(float);
   if (p.layout == 1) {  // quad layout: unpadded weights, input tile [cq][y][x][4]
     if (!(p.ck == 16 || p.ck == 32) || p.sx > 2 || !k.vec_ok) return CODD_EUNSUPPORTED;
     k.wchunk = k.ntaps * p.ck * 16 * p.mb;
@@ -225,8 +217,28 @@ extern "C" int codd_conv2d(const codd_conv_params* pp, void* stream) {
     return CODD_EINVAL;
   }
   if (lds > 160 * 1024) return CODD_EUNSUPPORTED;
-  long long grid = (long long)k.tiles_x * k.tiles_y * k.ncog * p.B;
+  grid = (long long)k.tiles_x * k.tiles_y * k.ncog * p.B;
   if (grid <= 0 || grid > 0x7fffffffLL) return CODD_EINVAL;
+  return CODD_OK;
+}
+
+extern "C" int codd_conv2d(const codd_conv_params* pp, void* stream) {
+  if (!pp) return CODD_EINVAL;
+  if (pp->layout == 2) {
+    const codd_conv_params& q = *pp;
+    if (!q.xs || (!q.out && !q.xso) || !q.wpacked || q.C0 <= 0 || q.C1 < 0 || q.B < 1 || q.Cout < 1 || q.kh < 1 || q.kw < 1 ||
+        q.pad_l < 0 || q.pad_t < 0)
+      return CODD_EINVAL;
+    if (q.store_mode && (q.kh != 1 || q.kw != 1 || q.res1.ptr || q.res2.ptr || q.post.ptr)) return CODD_EUNSUPPORTED;
+    return codd_conv2d_bf16(pp, stream, 0);
+  }
+  ConvK k;
+  size_t lds;
+  long long grid;
+  int nw;
+  const int rc = conv_fill(pp, k, lds, grid, nw);
+  if (rc != CODD_OK) return rc;
+  const codd_conv_params& p = k.p;
   hipStream_t s = (hipStream_t)stream;
   if (p.layout == 1) return launch_quad_any(k, nw, lds, (int)grid, s);
 #define CASEW(W, M) if (nw == W && p.mb == M) return launch_conv_nwx<W, M>(k, lds, (int)grid, s)
@@ -237,6 +249,53 @@ extern "C" int codd_conv2d(const codd_conv_params* pp, void* stream) {
   CASE(2, 1); CASE(2, 2); CASE(2, 4);
   CASE(4, 1); CASE(4, 2); CASE(4, 4);
 #undef CASE
+  return CODD_EUNSUPPORTED;
+}
+
+template <int NW, int NPB, int MB, int WREG, int QREG>
+static int launch_quad_multi(const ConvKN& kn, size_t lds, int grid, hipStream_t s) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_quad_multi_kernel<NW, NPB, MB, WREG, QREG>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  conv_quad_multi_kernel<NW, NPB, MB, WREG, QREG><<<grid, NW * 64, lds, s>>>(kn);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+/* n <= 4 independent quad-layout convolutions (layout 1, 4-wave workgroups, 4 x 16 tiles: npb = 1; the same mb = 1 | 2
+ * for all) as ONE launch; every job is validated as codd_conv2d would.  CODD_EUNSUPPORTED when a job does not fit the
+ * instantiated register classes -- the caller then launches the jobs one by one. */
+extern "C" int codd_conv2d_multi(const codd_conv_params* ps, int n, void* stream) {
+  if (!ps || n < 1 || n > CONVQ_MULTI_MAX) return CODD_EINVAL;
+  if (n == 1) return codd_conv2d(ps, stream);
+  ConvKN kn;
+  memset(&kn, 0, sizeof(kn));
+  size_t lds = 0;
+  long long total = 0;
+  int wr = 0, qr = 0;
+  for (int i = 0; i < n; ++i) {
+    size_t l;
+    long long g;
+    int nw;
+    if (ps[i].layout != 1) return CODD_EUNSUPPORTED;
+    const int rc = conv_fill(&ps[i], kn.k[i], l, g, nw);
+    if (rc != CODD_OK) return rc;
+    const codd_conv_params& p = kn.k[i].p;
+    if (nw != 4 || p.npb != 1 || p.mb != ps[0].mb || !(p.mb == 1 || p.mb == 2)) return CODD_EUNSUPPORTED;
+    const int w_ = cdiv(kn.k[i].wchunk >> 2, 256), q_ = cdiv((p.ck >> 2) * kn.k[i].upc, 256);
+    wr = w_ > wr ? w_ : wr;
+    qr = q_ > qr ? q_ : qr;
+    lds = l > lds ? l : lds;
+    kn.start[i] = (int)total;
+    total += g;
+  }
+  for (int i = n; i <= CONVQ_MULTI_MAX; ++i) kn.start[i] = (int)total;  // jobs past n own no workgroup
+  if (total > 0x7fffffffLL) return CODD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (ps[0].mb == 1 && wr <= 8 && qr <= 2) return launch_quad_multi<4, 1, 1, 8, 2>(kn, lds, (int)total, s);
+  if (ps[0].mb == 2 && wr <= 16 && qr <= 2) return launch_quad_multi<4, 1, 2, 16, 2>(kn, lds, (int)total, s);
   return CODD_EUNSUPPORTED;
 }
 

@@ -13,10 +13,11 @@
 // 16 lanes of an operand read are 32 bytes apart (2-way bank conflict, accepted).
 #include "conv_kernel.h"
 
+// body of the kernel for workgroup ``bid`` of the launch described by ``k`` (shared by the single- and the multi-job
+// entry points; always inlined with a compile-time-known ``k`` operand so that the kernel arguments stay scalar loads)
 template <int NW, int NPB, int MB, int WREG, int QREG>
-__global__ __launch_bounds__(NW * 64) void conv_quad_kernel(const ConvK k) {
+__device__ __forceinline__ void conv_quad_body(const ConvK& k, int bid, float* smem) {
   constexpr int NT = NW * 64;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* wl = smem;
   float* il = smem + k.wchunk;
   const codd_conv_params& p = k.p;
@@ -25,7 +26,6 @@ __global__ __launch_bounds__(NW * 64) void conv_quad_kernel(const ConvK k) {
   constexpr int XB = NPB >= 2 ? 2 : 1;
   constexpr int RPW = NPB / XB;
 
-  int bid = blockIdx.x;
   const int tx = bid % k.tiles_x; bid /= k.tiles_x;
   const int ty = bid % k.tiles_y; bid /= k.tiles_y;
   const int cog = bid % k.ncog;
@@ -180,6 +180,30 @@ __global__ __launch_bounds__(NW * 64) void conv_quad_kernel(const ConvK k) {
   }
 }
 
+template <int NW, int NPB, int MB, int WREG, int QREG>
+__global__ __launch_bounds__(NW * 64) void conv_quad_kernel(const ConvK k) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  conv_quad_body<NW, NPB, MB, WREG, QREG>(k, blockIdx.x, smem);
+}
+
+// Several INDEPENDENT convolutions (different tensors, shapes and channel counts; same tile / register class) as one
+// launch: workgroups [start[j], start[j + 1]) run job j.  For the launch-bound small layers of HRNet's resolution
+// branches (mmseg HRModule: the branches of a module do not depend on each other): one ~10 us launch instead of 2-4.
+constexpr int CONVQ_MULTI_MAX = 4;
+struct ConvKN {
+  ConvK k[CONVQ_MULTI_MAX];
+  int start[CONVQ_MULTI_MAX + 1];
+};
+template <int NW, int NPB, int MB, int WREG, int QREG>
+__global__ __launch_bounds__(NW * 64) void conv_quad_multi_kernel(const ConvKN kn) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int bid = blockIdx.x;
+  if (bid < kn.start[1]) conv_quad_body<NW, NPB, MB, WREG, QREG>(kn.k[0], bid, smem);
+  else if (bid < kn.start[2]) conv_quad_body<NW, NPB, MB, WREG, QREG>(kn.k[1], bid - kn.start[1], smem);
+  else if (bid < kn.start[3]) conv_quad_body<NW, NPB, MB, WREG, QREG>(kn.k[2], bid - kn.start[2], smem);
+  else conv_quad_body<NW, NPB, MB, WREG, QREG>(kn.k[3], bid - kn.start[3], smem);
+}
+
 // instantiations (X(NW, NPB, MB, WREG, QREG)): 4-wave workgroups with 4x16 / 4x32 / 8x32 tiles, 9-wave with 4x16
 #define CONVQ_GROUP_A(X) X(4, 1, 2, 8, 1) X(4, 1, 2, 16, 2) X(4, 1, 4, 12, 1) X(4, 1, 4, 16, 2) X(4, 1, 1, 8, 2)
 #define CONVQ_GROUP_B(X) X(4, 2, 2, 8, 2) X(4, 2, 2, 16, 2) X(4, 2, 4, 12, 2) X(4, 2, 4, 16, 2) X(4, 2, 1, 8, 2)
@@ -187,3 +211,7 @@ __global__ __launch_bounds__(NW * 64) void conv_quad_kernel(const ConvK k) {
 #define CONVQ_ALL(X) CONVQ_GROUP_A(X) CONVQ_GROUP_B(X) CONVQ_GROUP_C(X)
 #define CONVQ_DECLARE(NW, NPB, MB, WREG, QREG) extern template __global__ void conv_quad_kernel<NW, NPB, MB, WREG, QREG>(const ConvK);
 #define CONVQ_DEFINE(NW, NPB, MB, WREG, QREG) template __global__ void conv_quad_kernel<NW, NPB, MB, WREG, QREG>(const ConvK);
+// the multi-job kernel is instantiated for the small-layer class only: 4 x 16 tiles, 16 or 32 output channels per group
+#define CONVQ_MULTI(X) X(4, 1, 1, 8, 2) X(4, 1, 2, 16, 2)
+#define CONVQM_DECLARE(NW, NPB, MB, WREG, QREG) extern template __global__ void conv_quad_multi_kernel<NW, NPB, MB, WREG, QREG>(const ConvKN);
+#define CONVQM_DEFINE(NW, NPB, MB, WREG, QREG) template __global__ void conv_quad_multi_kernel<NW, NPB, MB, WREG, QREG>(const ConvKN);

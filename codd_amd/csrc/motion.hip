@@ -928,6 +928,62 @@ __global__ __launch_bounds__(256) void cvx_upsample_kernel(const float* __restri
   }
 }
 
+// upsample_se3 (mode 1) and the convex up-sampling of the 3-channel confidence (mode 2) of the SAME mask in one pass
+// (reference raft3d.py:267-273 applies both after the last update): the 19.9 MB mask and its soft-max are read / formed once.
+__global__ __launch_bounds__(256) void cvx_upsample_se3w_kernel(const float* __restrict__ T, const float* __restrict__ wgt,
+                                                                const float* __restrict__ mask, int h, int w,
+                                                                float* __restrict__ Tout, float* __restrict__ wout) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int wave = (threadIdx.x >> 6) + 4 * (blockIdx.z & 3);
+  const int y = blockIdx.y, b = blockIdx.z >> 2;
+  if (x >= w) return;
+  const int N = h * w;
+  float nb[9][9];  // 6 twist components | 3 confidence channels of the 9 neighbours
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+    const bool in = (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w;
+    V3 tau = V3{0, 0, 0}, phi = V3{0, 0, 0};
+    if (in) { const SE3T Tn = se3_load(T + ((size_t)b * N + yy * w + xx) * 7); se3_log(Tn, &tau, &phi); }
+    nb[k][0] = tau.x; nb[k][1] = tau.y; nb[k][2] = tau.z; nb[k][3] = phi.x; nb[k][4] = phi.y; nb[k][5] = phi.z;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) nb[k][6 + c] = in ? wgt[((size_t)b * 3 + c) * N + yy * w + xx] : 0.f;
+  }
+  const float* mb = mask + (size_t)b * 576 * N + (size_t)y * w + x;
+  const int H8 = 8 * h, W8 = 8 * w;
+  for (int s = wave * 4; s < wave * 4 + 4; ++s) {
+    float m[9], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { m[k] = mb[(size_t)(k * 64 + s) * N]; mx = fmaxf(mx, m[k]); }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { m[k] = expf(m[k] - mx); den += m[k]; }
+    float acc[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const float wk = m[k] / den;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) acc[c] += wk * nb[k][c];
+    }
+    const int oy = 8 * y + (s >> 3), ox = 8 * x + (s & 7);
+    const SE3T To = se3_exp(V3{acc[0], acc[1], acc[2]}, V3{acc[3], acc[4], acc[5]});
+    se3_store(Tout + ((size_t)b * H8 * W8 + (size_t)oy * W8 + ox) * 7, To);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) wout[((size_t)b * 3 + c) * H8 * W8 + (size_t)oy * W8 + ox] = acc[6 + c];
+  }
+}
+
+extern "C" int codd_cvx_upsample_se3_weight(const float* T, const float* weight, const float* mask, int B, int h, int w,
+                                            float* T_out, float* weight_out, void* stream) {
+  if (!T || !weight || !mask || !T_out || !weight_out || B < 1 || h < 1 || w < 1) return CODD_EINVAL;
+  cvx_upsample_se3w_kernel<<<dim3(cdiv(w, 64), h, 4 * B), 256, 0, (hipStream_t)stream>>>(T, weight, mask, h, w, T_out,
+                                                                                         weight_out);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
 extern "C" int codd_cvx_upsample(const float* data, const float* mask, int B, int h, int w, int dim, int mode,
                                  float* out, void* stream) {
   if (!data || !mask || !out) return CODD_EINVAL;

@@ -144,9 +144,24 @@ class HRModule(nn.Module):
                 x = blk.run(x)
             return x
 
-        ys = [on(i, lambda i=i: branch(i)) for i in range(nb)]
-        if fk is not None:
-            fk.join()
+        nblk = len(self.branches[0])
+        if fk is None and nb > 1 and ops.MULTI_CONV and ops.CONV_PRECISION == "fp32" and not ops.use_chain(*xs[0].shape[2:]):
+            # step s of every branch (conv1 / conv2 of block s // 2) is independent of the other branches: one
+            # multi-job launch per step (ops.conv2d_multi) instead of one ~10 us launch per branch and step
+            ys, blockin = list(xs), list(xs)
+            for st in range(2 * nblk):
+                jobs = []
+                for i in range(nb):
+                    blk = self.branches[i][st // 2]
+                    conv, bn = (blk.conv1, blk.bn1) if st % 2 == 0 else (blk.conv2, blk.bn2)
+                    jobs.append(dict(x=ys[i], pc=packed_cbn(conv, bn), pad=1, act="relu", res1=blockin[i] if st % 2 else None))
+                ys = ops.conv2d_multi(jobs)
+                if st % 2:
+                    blockin = list(ys)
+        else:
+            ys = [on(i, lambda i=i: branch(i)) for i in range(nb)]
+            if fk is not None:
+                fk.join()
         xs = ys
 
         def fuse(i):

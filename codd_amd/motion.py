@@ -408,11 +408,10 @@ class RAFT3D(ops.RuntimeState, nn.Module):
                 weight = ops.se3_gn_step_heads(T, hid, *self.update_block.head_matrix(), xyz, d1, K8, radius=32)
             else:
                 ops.se3_gn_step(T, ae, xyz, delta, weight, d1, K8, radius=32)
-        T_up = ops.cvx_upsample(T, mask, 1)
+        T_up, outputs["weight"] = ops.cvx_upsample_se3_weight(T, weight.contiguous(), mask)  # one pass over the mask
         outputs["Ts"] = T_up
         # reference raft3d.py:268-270: the induced 2-D flow + inverse-depth change of the up-sampled field
         outputs["flow2d_est_induced"] = ops.induced_flow(T_up, depth_prev, [float(v) for v in K])
-        outputs["weight"] = ops.cvx_upsample(weight, mask, 2)
         state["raft_feat"] = fmap_curr
         ni = self._join("netinp", dev)
         state["raft_netinp"] = ni if ni is not None else self.context(image_curr)

@@ -525,6 +525,67 @@ def _db_cfg_ok(lib, p, c, sig):
     return True
 
 
+MULTI_CONV = _os.environ.get("CODD_MULTI_CONV", "1") == "1"  # (A/B switch of conv2d_multi)
+
+
+def _launch_conv_multi(lib, params, n, stream):
+    """Single choke point of the multi-job conv launches (bench.py wraps it with HIP events)."""
+    return lib.codd_conv2d_multi(params, n, stream)
+
+
+def conv2d_multi(jobs):
+    """Independent stride-1/2 convolutions -> list of outputs.  ``jobs``: dicts(x, pc[, stride, pad, act, res1]).  Under the
+    exact-fp32 precision the jobs whose rows are 16-byte aligned are launched up to four at a time by ONE
+    codd_conv2d_multi (quad layout, 4 x 16 tiles, 16 output channels per workgroup: the launch-bound small layers of
+    HRNet's branches); everything else goes through conv2d one by one."""
+    lib = _abi.load()
+    outs = [None] * len(jobs)
+    group = []
+    if MULTI_CONV and CONV_PRECISION == "fp32" and len(jobs) > 1:
+        for idx, j in enumerate(jobs):
+            x, pc = j["x"], j["pc"]
+            if (isinstance(x, torch.Tensor) and x.shape[3] % 4 == 0 and x.data_ptr() % 16 == 0 and not pc.deconv
+                    and pc.cin >= 16 and j.get("stride", 1) in (1, 2)):
+                group.append(idx)
+    for k0 in range(0, len(group), 4):
+        ids = group[k0:k0 + 4]
+        if len(ids) < 2:
+            break
+        arr = (ConvParams * len(ids))()
+        keep = []
+        for slot, idx in enumerate(ids):
+            j = jobs[idx]
+            x, pc = j["x"], j["pc"]
+            B, C0, Hin, Win = x.shape
+            st, pad = j.get("stride", 1), j.get("pad", 0)
+            Hout = (Hin + 2 * pad - (pc.kh - 1) - 1) // st + 1
+            Wout = (Win + 2 * pad - (pc.kw - 1) - 1) // st + 1
+            out = torch.empty(B, pc.cout, Hout, Wout, device=x.device, dtype=torch.float32)
+            ck = 32 if pc.cin > 16 else 16
+            p = arr[slot]
+            p.in0, p.C0, p.C1, p.B, p.Hin, p.Win = _view(x), C0, 0, B, Hin, Win
+            p.bias = None if pc.bias is None else pc.bias.data_ptr()
+            p.res1 = _view(j.get("res1"))
+            p.out, p.out_ctot, p.out_coff = out.data_ptr(), pc.cout, 0
+            p.Cout, p.Hout, p.Wout = pc.cout, Hout, Wout
+            p.kh, p.kw, p.sy, p.sx, p.pad_t, p.pad_l, p.dil_y, p.dil_x = pc.kh, pc.kw, st, st, pad, pad, 1, 1
+            p.act = ACT[j.get("act", "none")]
+            p.mb, p.npb, p.nw, p.ck, p.layout = 1, 1, 4, ck, 1
+            p.wpacked = pc.packed(ck, 1, 1).data_ptr()
+            keep.append(out)
+        rc = _launch_conv_multi(lib, arr, len(ids), _stream())
+        if rc == 0:
+            for idx, out in zip(ids, keep):
+                outs[idx] = out
+        elif rc != -2:
+            _abi.check(rc, "codd_conv2d_multi")
+    for idx, j in enumerate(jobs):
+        if outs[idx] is None:
+            outs[idx] = conv2d(j["x"], j["pc"], stride=j.get("stride", 1), pad=j.get("pad", 0), act=j.get("act", "none"),
+                               res1=j.get("res1"))
+    return outs
+
+
 def _cfg_ok(lib, p, c):
     """Does the library accept split-bf16 configuration ``c`` for the layer described by ``p``? (nothing is launched)"""
     p.npb, p.nw, p.ck, p.mb, p.layout, p.pgw, p.cgw = c[:7]
@@ -1096,6 +1157,16 @@ def cvx_upsample(data, mask, mode):
     _abi.check(lib.codd_cvx_upsample(data.data_ptr(), mask.data_ptr(), B, h, w, D, mode, out.data_ptr(), _stream()),
                "cvx_upsample")
     return out
+
+
+def cvx_upsample_se3_weight(T, weight, mask):
+    """cvx_upsample(T, mask, 1) and cvx_upsample(weight, mask, 2) in one launch (the mask is read once)."""
+    lib = _abi.load()
+    B, h, w, _ = T.shape
+    To, wo = _f32(B, 8 * h, 8 * w, 7, like=T), _f32(B, 3, 8 * h, 8 * w, like=T)
+    _abi.check(lib.codd_cvx_upsample_se3_weight(T.data_ptr(), weight.data_ptr(), mask.data_ptr(), B, h, w, To.data_ptr(),
+                                                wo.data_ptr(), _stream()), "cvx_upsample_se3_weight")
+    return To, wo
 
 
 def disp_to_depth(disp, bf):

@@ -115,6 +115,10 @@ typedef struct {
 } codd_conv_params;
 
 int codd_conv2d(const codd_conv_params* p, void* stream);
+/* n <= 4 INDEPENDENT convolutions as one launch (exact-fp32 quad layout, layout = 1, npb = 1, nw = 4, one common mb of
+ * 1 | 2): the resolution branches of an mmseg HRModule (configs/models/codd.py:44-74) are launch-bound ~10 us layers
+ * that do not depend on each other.  CODD_EUNSUPPORTED when a job does not fit that class (launch them one by one). */
+int codd_conv2d_multi(const codd_conv_params* p, int n, void* stream);
 /* layout 2 only: CODD_OK if codd_conv2d would accept this launch configuration (tile, chunk depth, wave grid: LDS
  * and register-staging limits of the instantiated kernels), CODD_EUNSUPPORTED otherwise.  Launches nothing and reads
  * no pointer field: callers probe candidate configurations before packing weights for them. */
@@ -306,6 +310,10 @@ int codd_se3_gn_step_heads(float* T, codd_xs_view hidden, const void* head_w, co
  * mode 2: data [B,dim,h,w] -> out [B,dim,8h,8w]              (weight, raft3d.py:271-273) */
 int codd_cvx_upsample(const float* data, const float* mask, int B, int h, int w, int dim, int mode,
                       float* out, void* stream);
+/* upsample_se3 (mode 1) of T [B,h,w,7] and the convex up-sampling (mode 2) of weight [B,3,h,w] with the same mask in one
+ * pass (raft3d.py:267-273): T_out [B,8h,8w,7], weight_out [B,3,8h,8w]. */
+int codd_cvx_upsample_se3_weight(const float* T, const float* weight, const float* mask, int B, int h, int w,
+                                 float* T_out, float* weight_out, void* stream);
 
 /* disparity -> depth (motion.py:154-165): depth = clip(bf / (disp + 1e-5), 0, 210). */
 int codd_disp_to_depth(const float* disp, long long n, float bf, float* depth, void* stream);

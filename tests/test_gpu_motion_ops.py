@@ -109,6 +109,10 @@ def test_cvx_upsample():
     ref = om.cvx_upsample(wgt.permute(0, 2, 3, 1), mask).permute(0, 3, 1, 2)
     got = ops.cvx_upsample(wgt.to(DEV), mask.to(DEV), 2).cpu()
     assert (got - ref).abs().max().item() < 1e-5
+    # both with one pass over the mask (what RAFT3D.forward launches after the last update)
+    To, wo = ops.cvx_upsample_se3_weight(T.to(DEV), wgt.to(DEV), mask.to(DEV))
+    assert (To.cpu() - om.upsample_se3(T, mask)).abs().max().item() < 1e-5
+    assert (wo.cpu() - ref).abs().max().item() < 1e-5
 
 
 @pytest.mark.parametrize("ds,radius,C", [(1, 2.0, 6), (4, 4.0, 32)])

@@ -540,3 +540,37 @@ def test_conv_chain_matches_torch():
             assert err < 2e-5, (name, tile, err)
             assert (big[:, :3] == 7.0).all() and (big[:, 3 + cs:] == 7.0).all(), (name, tile)
         assert ntile >= 3, (name, ntile)
+
+
+def test_conv2d_multi_equals_separate_launches():
+    """codd_conv2d_multi: up to four independent convolutions (different maps, channel counts, strides; residual +
+    ReLU epilogues) as ONE launch -- HRNet's resolution branches -- against torch; a job whose rows are not 16-byte
+    aligned (18 x 30 map) silently takes the single-launch path."""
+    from codd_amd import ops
+    shapes = [(18, 48, 80), (36, 24, 40), (72, 12, 20), (144, 18, 30)]
+    prev = ops.set_conv_precision("fp32")
+    try:
+        jobs, refs = [], []
+        for n, (c, h, w) in enumerate(shapes):
+            x, res = rnd(1, c, h, w, seed=n), rnd(1, c, h, w, seed=10 + n)
+            wt, b = rnd(c, c, 3, 3, seed=20 + n) / (3.0 * c ** 0.5), rnd(c, seed=30 + n) * 0.1
+            refs.append(F.relu(F.conv2d(x, wt, b, padding=1) + res))
+            jobs.append(dict(x=x.to(dev()), pc=ops.PackedConv(wt.to(dev()), b.to(dev())), pad=1, act="relu", res1=res.to(dev())))
+        # + a strided job (HRNet transition shape)
+        x = rnd(1, 36, 24, 40, seed=50)
+        wt, b = rnd(72, 36, 3, 3, seed=51) / 18.0, rnd(72, seed=52) * 0.1
+        refs.append(F.conv2d(x, wt, b, stride=2, padding=1))
+        jobs.append(dict(x=x.to(dev()), pc=ops.PackedConv(wt.to(dev()), b.to(dev())), stride=2, pad=1))
+        calls = []
+        orig = ops._launch_conv_multi
+        ops._launch_conv_multi = lambda lib, p, n, s: (calls.append(n), orig(lib, p, n, s))[1]
+        try:
+            outs = ops.conv2d_multi(jobs)
+        finally:
+            ops._launch_conv_multi = orig
+        assert calls == [4], calls  # four aligned jobs in one launch, the 18 x 30 one on its own
+        for o, r in zip(outs, refs):
+            assert o.shape == r.shape
+            assert (o.cpu() - r).abs().max().item() < 5e-5 * max(1.0, r.abs().max().item())
+    finally:
+        ops.set_conv_precision(prev)
