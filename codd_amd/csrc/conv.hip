@@ -12,13 +12,14 @@
 // channels and the matching weight chunk are staged in LDS per chunk; channel stride of the
 // LDS image is padded to 16 (mod 32) floats so that the two ci-groups of a 32-lane half hit
 // disjoint banks.
-#include "conv_quad_kernel.h"
+#include "conv_quad_persist.h"
 #include <stdio.h>
 #include <stdlib.h>
 
 CONV_ALL_GROUPS(CONV_DECLARE)
 CONVQ_ALL(CONVQ_DECLARE)
 CONVQ_MULTI(CONVQM_DECLARE)
+CONVQP_ALL(CONVQP_DECLARE)
 
 
 __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int ntaps,
@@ -163,6 +164,39 @@ static int launch_quad_any(const ConvK& k, int nw, size_t lds, int grid, hipStre
   return CODD_EUNSUPPORTED;
 }
 
+template <int NPB, int MB, int WREG, int QREG>
+static int launch_qp(const ConvK& k, size_t lds, int ntiles, hipStream_t s) {
+  auto kern = conv_quad_persist_kernel<NPB, MB, WREG, QREG>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  // grid = the workgroups the chip keeps resident (LDS, registers, 32 waves per CU), every one walks its share of the tiles
+  static size_t cached_lds = 0;  // (per instantiation; the occupancy query is a host call worth caching)
+  static int cached_per_cu = 0;
+  if (cached_per_cu == 0 || cached_lds != lds) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    cached_per_cu = per_cu;
+    cached_lds = lds;
+  }
+  int grid = 256 * cached_per_cu;
+  if (grid > ntiles) grid = ntiles;
+  kern<<<grid, 256, lds, s>>>(k, ntiles);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+// layout 3: persistent quad-layout kernel (conv_quad_persist.h)
+static int launch_quad_persist(const ConvK& k, size_t lds, int ntiles, hipStream_t s) {
+  const codd_conv_params& p = k.p;
+  const int wr = cdiv(k.wchunk >> 2, 256), qr = cdiv((p.ck >> 2) * k.upc, 256);
+#define QP(N, M, R, QQ) if (p.npb == N && p.mb == M && wr <= R && qr <= QQ) return launch_qp<N, M, R, QQ>(k, lds, ntiles, s);
+  CONVQP_ALL(QP)
+#undef QP
+  return CODD_EUNSUPPORTED;
+}
+
 /* staging limits the host heuristics must respect: <= 16 float4 of weights and <= 8 float4 of input
  * per thread and chunk (codd_conv2d returns CODD_EUNSUPPORTED otherwise) */
 int codd_conv2d_bf16(const codd_conv_params* pp, void* stream, int dry_run);  // conv_bf16.hip
@@ -209,8 +243,10 @@ static int conv_fill(const codd_conv_params* pp, ConvK& k, size_t& lds, long lon
   k.vec_ok = (p.Win % 4 == 0) && ((uintptr_t)p.in0.ptr % 16 == 0) && (hwb % 16 == 0) &&
              (p.C1 == 0 || (uintptr_t)p.in1.ptr % 16 == 0);
   lds = ((size_t)k.wchunk + (size_t)p.ck * k.chs) * sizeof(float);
-  if (p.layout == 1) {  // quad layout: unpadded weights, input tile [cq][y][x][4]
+  if (p.layout == 1 || p.layout == 3) {  // quad layout: unpadded weights, input tile [cq][y][x][4]
     if (!(p.ck == 16 || p.ck == 32) || p.sx > 2 || !k.vec_ok) return CODD_EUNSUPPORTED;
+    if (p.layout == 3 && (k.nchunks != 1 || cdiv(p.store_mode ? 4 * p.Cout : p.Cout, 16 * p.mb) != 1 || nw != 4 || p.mb > 2))
+      return CODD_EUNSUPPORTED;  // persistent variant: the whole weight tensor is one chunk and one channel group
     k.wchunk = k.ntaps * p.ck * 16 * p.mb;
     lds = ((size_t)k.wchunk + (size_t)p.ck * k.thi * k.twp) * sizeof(float);
   } else if (p.layout != 0) {
@@ -241,6 +277,7 @@ extern "C" int codd_conv2d(const codd_conv_params* pp, void* stream) {
   const codd_conv_params& p = k.p;
   hipStream_t s = (hipStream_t)stream;
   if (p.layout == 1) return launch_quad_any(k, nw, lds, (int)grid, s);
+  if (p.layout == 3) return launch_quad_persist(k, lds, (int)grid, s);
 #define CASEW(W, M) if (nw == W && p.mb == M) return launch_conv_nwx<W, M>(k, lds, (int)grid, s)
   CASEW(9, 1); CASEW(9, 2); CASEW(9, 4); CASEW(2, 1); CASEW(2, 2); CASEW(2, 4); CASEW(8, 1); CASEW(8, 2); CASEW(8, 4);
 #undef CASEW

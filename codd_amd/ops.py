@@ -120,7 +120,7 @@ class PackedConv:
 
     def _pack_key(self, c):
         lay = c[4] if len(c) > 4 else 0
-        return (c[3] if len(c) > 3 else self.mb, c[2], 20 + c[7] if lay == 2 else lay)
+        return (c[3] if len(c) > 3 else self.mb, c[2], 20 + c[7] if lay == 2 else (1 if lay == 3 else lay))
 
     def drop_unused_packs(self):
         """Free the packed-weight variants no tuned configuration refers to (after autotuning)."""
@@ -493,7 +493,7 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
     mb = cfg[3] if len(cfg) > 3 else pc.mb
     layout = cfg[4] if len(cfg) > 4 else 0
     p.terms = 0
-    p.wpacked = pc.packed(ck, mb, layout).data_ptr()
+    p.wpacked = pc.packed(ck, mb, 1 if layout == 3 else layout).data_ptr()  # (layout 3 = layout 1 weights, persistent kernel)
     p.mb, p.npb, p.nw, p.ck, p.layout = mb, npb, nw, ck, layout
     rc = _launch_conv(lib, p, _stream())
     if rc == -2:
@@ -526,6 +526,11 @@ def _db_cfg_ok(lib, p, c, sig):
 
 
 MULTI_CONV = _os.environ.get("CODD_MULTI_CONV", "1") == "1"  # (A/B switch of conv2d_multi)
+# tuner candidates on the persistent quad kernel (layout 3: weights resident in LDS, workgroups walk the tiles).  OFF:
+# measured on MI355X (tools/time_persist.py, profiles/r03_persist_times.log) it LOSES to the per-tile kernel on every
+# big HITNet layer it was written for (16->16 3x3 at 576x960: 59.8 vs 50.5 us; 32->32 at 288x480: 54.4 vs 47.3) --
+# three small workgroups per CU overlap their staging better than one or two persistent ones with a register prefetch
+PERSIST_CONV = _os.environ.get("CODD_PERSIST_CONV", "0") == "1"
 
 
 def _launch_conv_multi(lib, params, n, stream):
@@ -732,6 +737,14 @@ def _autotune(lib, p, pc, default, with_time=False):
                 for ck in (16, 32):
                     if ck <= max(16, cin_pad):
                         cands.append((npb, nw, ck, mb, 1))
+        # persistent quad kernel (layout 3): the whole weight tensor is one chunk and one channel group
+        if PERSIST_CONV and cin_pad <= 32 and not pc.deconv:
+            ck = 16 if cin_pad <= 16 else 32
+            for mb in (1, 2):
+                if pc.cout_eff <= 16 * mb:
+                    for npb in (1, 2, 4):
+                        cands.append((npb, 4, ck, mb, 3))
+                    break
     stream = _stream()
     # the timed launches write into a scratch copy of the output buffer: the real one may alias an operand
     # (in-place accumulation "out = conv(x) + out"), which repeated launches would accumulate over and over
@@ -743,7 +756,7 @@ def _autotune(lib, p, pc, default, with_time=False):
     best, best_t, t_default = default, float("inf"), None
     for (npb, nw, ck, mb, layout) in [default] + cands:  # the heuristic is timed twice (first = warm-up of clocks / caches)
         try:
-            p.wpacked = pc.packed(ck, mb, layout).data_ptr()
+            p.wpacked = pc.packed(ck, mb, 1 if layout == 3 else layout).data_ptr()
         except Exception:
             continue
         p.mb, p.npb, p.nw, p.ck, p.layout = mb, npb, nw, ck, layout

@@ -90,7 +90,9 @@ typedef struct {
   int nw;  /* waves (= 16-pixel tile rows) per workgroup: 0 or 4 (default), or 2 / 8 / 9 (npb 1 only) */
   int ck;  /* input channels staged per LDS chunk (multiple of 4) */
   int layout; /* 0: weights packed by codd_conv2d_pack_weights; 1: quad layout (codd_conv2d_pack_weights_quad;
-                 ck 16 or 32, x-stride <= 2, 16-byte aligned rows); 2: split-bf16 kernel (weights packed by
+                 ck 16 or 32, x-stride <= 2, 16-byte aligned rows); 3: layout 1 on the PERSISTENT kernel (whole weight
+                 tensor = one chunk and one channel group: Cin <= ck, Cout <= 16 * mb, mb <= 2, nw 4: workgroups keep the
+                 weights in LDS and walk the tiles, prefetching the next tile's input); 2: split-bf16 kernel (weights packed by
                  codd_conv2d_pack_weights_bf16 for (mb, ck, terms); here nw = tile rows, npb = 16-pixel units per
                  tile row (1 | 2), ck a multiple of 8) */
   int terms;  /* layout 2: 1 = bf16 operands, 3 = split-bf16 (hi/lo) operands */

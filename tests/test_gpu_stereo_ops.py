@@ -574,3 +574,45 @@ def test_conv2d_multi_equals_separate_launches():
             assert (o.cpu() - r).abs().max().item() < 5e-5 * max(1.0, r.abs().max().item())
     finally:
         ops.set_conv_precision(prev)
+
+
+def test_persistent_quad_kernel_matches_torch():
+    """layout 3 (conv_quad_persist_kernel: weights resident in LDS, workgroups walk the tiles and prefetch the next
+    tile's input) on the layer class it serves -- cin <= 32, cout <= 32: every tile shape, two concatenated inputs,
+    batch 2, residual + activation epilogue, maps that are not multiples of the tile, far more tiles than workgroups."""
+    from codd_amd import ops
+    from codd_amd.ops import Slice
+    prev = ops.set_conv_precision("fp32")
+    try:
+        for (c0, c1, cout, k, H, W, B) in [(32, 0, 32, 3, 70, 100, 2), (16, 0, 16, 3, 130, 260, 1), (16, 8, 16, 3, 37, 52, 1),
+                                           (32, 0, 16, 1, 64, 96, 1), (24, 0, 24, 3, 40, 64, 2)]:
+            cin = c0 + c1
+            x = rnd(B, cin, H, W, seed=cin + H)
+            w, b = rnd(cout, cin, k, k, seed=1) / (cin * k * k) ** 0.5, rnd(cout, seed=2) * 0.1
+            res = rnd(B, cout, H, W, seed=3)
+            ref = F.leaky_relu(F.conv2d(x, w, b, padding=k // 2) + res, 0.2)
+            xd, resd = x.to(dev()), res.to(dev())
+            pc = ops.PackedConv(w.to(dev()), b.to(dev()))
+            key = (H, W, B, 1, 1, 1, 1, k // 2, c1 > 0, 0)
+            ck = 16 if cin <= 16 else 32
+            n = 0
+            for mb in (1, 2):
+                if cout > 16 * mb:
+                    continue
+                for npb in (1, 2, 4):
+                    pc.tuned[key] = (npb, 4, ck, mb, 3)
+                    out = torch.full((B, cout + 2, H, W), 5.0, device=dev())
+                    import warnings
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("error")  # a rejected configuration would fall back with a warning
+                        if c1:
+                            ops.conv2d(Slice(xd, 0, c0), pc, x2=Slice(xd, c0, c1), pad=k // 2, act="lrelu", res1=resd, out=Slice(out, 1, cout))
+                        else:
+                            ops.conv2d(xd, pc, pad=k // 2, act="lrelu", res1=resd, out=Slice(out, 1, cout))
+                    assert tuple(pc.tuned[key]) == (npb, 4, ck, mb, 3)
+                    assert (out[:, 1:1 + cout].cpu() - ref).abs().max().item() < 5e-5, (cin, cout, npb, mb)
+                    assert (out[:, 0] == 5.0).all() and (out[:, -1] == 5.0).all()
+                    n += 1
+            assert n >= 3
+    finally:
+        ops.set_conv_precision(prev)
