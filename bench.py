@@ -66,7 +66,12 @@ def _hbm_specs():
         B, h, w, D = a[2], a[3], a[4], a[5]
         return 4 * B * h * w * (576 + D + 64 * D)
 
+    def cvx2(a):  # T, weight, mask, B, h, w, ...: mask read once, SE3 field (7) + confidence (3) in and up-sampled out
+        B, h, w = a[3], a[4], a[5]
+        return 4 * B * h * w * (576 + 10 + 64 * 10)
+
     return {"codd_tile_costvol_argmin": ("costvol_argmin (S3+S4)", costvol), "codd_tile_warp_cost": ("tile_warp (S6)", tile_warp),
+            "codd_cvx_upsample_se3_weight": ("cvx_upsample SE3 + confidence, one pass (M8)", cvx2),
             "codd_raft_geometry_lookup_xs": ("corr_lookup + geometry (M4+M5)", lookup),
             "codd_raft_geometry_lookup": ("corr_lookup + geometry (M4+M5)", lookup),
             "codd_splat": ("splat (M9: project+count+reserve+fill+gather)", splat), "codd_cvx_upsample": ("cvx_upsample (M8)", cvx)}

@@ -69,3 +69,27 @@ def test_rank_core_pinning_partitions_the_host():
     finally:
         os.sched_setaffinity(0, before)
         torch.set_num_threads(max(1, min(8, len(before))))
+
+
+def test_hbm_algorithmic_bytes_match_survey_8d():
+    """bench.py's `roofline.hbm` basis: the algorithmic bytes of the HBM-bound kernels computed from their C-ABI
+    arguments must be SURVEY.md section 8(d)'s per-frame figures at 960x576 -- S3+S4 15.1 MB over the five levels,
+    S6 121 MB with both hypothesis sets sharing one read of the features, M9 call 1 37.6 MB in + 22.1 MB out."""
+    import bench
+    spec = {k: v[1] for k, v in bench._hbm_specs().items()}
+    # tile cost volume + arg-min, levels 16x ... 1x of a 576 x 960 image: args (L, R, B, C, Ht, Wt, Wr, D, ...)
+    tot = sum(spec["codd_tile_costvol_argmin"]((0, 0, 1, 16, 576 // (4 << l), 960 // (4 << l), 960 // (1 << l), 320 >> l))
+              for l in range(5))
+    assert abs(tot / 1e6 - 15.1) < 0.15, tot
+    # tile warp: level 1x..8x with two hypothesis sets, 16x with one; feature channels 16, 16, 24, 24, 32
+    # args (fl, fr, B, C, Ht, Wt, hyp0, hyp1, nhyp, ...)
+    tot = sum(spec["codd_tile_warp_cost"]((0, 0, 1, c, 144 >> l, 240 >> l, None, None, 1 if l == 4 else 2))
+              for l, c in enumerate((16, 16, 24, 24, 32)))
+    assert abs(tot / 1e6 - 121.0) < 2.5, tot  # (+ the 3-channel hypothesis reads SURVEY rounds away)
+    # splat call 1: 552 960 points x (1 + 7 + 9) words in, 10 x 552 960 words out
+    # args (T, depth, HT, WT, oy, ox, ds, featA, CA, featB, CB, with_flow, B, H, W, ...)
+    b = spec["codd_splat"]((0, 0, 576, 960, 0, 0, 1, 0, 3, 0, 3, 1, 1, 576, 960))
+    assert abs(b / 1e6 - (37.6 + 22.1)) < 0.2, b
+    # convex up-sampling of the SE3 field: 19.9 MB mask + 0.2 MB data + 13.3 MB out (x 7/6 for the stored quaternion)
+    b = spec["codd_cvx_upsample"]((0, 0, 1, 72, 120, 6, 1, 0))
+    assert abs(b / 1e6 - (19.9 + 0.2 + 13.3)) < 0.3, b
