@@ -337,16 +337,22 @@ def test_full_codd_kitti_aspect_matches_oracle(H, W, intr):
 
 @pytest.mark.parametrize("H,W,intr", [(384, 1280, (721.54, 721.54, 621.0, 187.5)), (512, 640, (320.0, 320.0, 320.0, 240.0))])
 def test_full_codd_runs_at_baseline_shapes(H, W, intr):
-    """BASELINE configs 4 / 5 padded shapes: the full path runs (graph replay) and stays finite."""
+    """BASELINE configs 3 / 4 padded shapes, iters = 16, heuristic (un-tuned) launch configurations: five frames by graph
+    replay must reproduce the eager launch schedule frame for frame (same kernels, same arguments: the captured graph
+    may not drop, reorder or alias anything at these non-square shapes).  Parity against the oracle at these shapes is
+    tests/test_gpu_headline_parity.py."""
     from codd_amd import synth
     from codd_amd.runtime import FrameRunner
     est, _ = _model(16)
     img, r_img, _ = synth.stereo_sequence(H, W, 3)
     metas = synth.default_metas(H, W, intrinsics=intr)
-    runner = FrameRunner(est, metas[0], use_graph=True)
+    rg, re = FrameRunner(est, metas[0], use_graph=True), FrameRunner(est, metas[0], use_graph=False)
     for f in range(5):
-        d = runner.step(img[:, f % 3].to(DEV).contiguous(), r_img[:, f % 3].to(DEV).contiguous())
-    assert d.shape == (1, 1, H, W) and torch.isfinite(d).all()
+        l, r = img[:, f % 3].to(DEV).contiguous(), r_img[:, f % 3].to(DEV).contiguous()
+        d, e = rg.step(l, r).clone(), re.step(l, r)
+        assert d.shape == (1, 1, H, W) and torch.isfinite(d).all()
+        assert (d - e).abs().max().item() < 1e-4, (f, (d - e).abs().max().item())
+    assert rg.graph is not None
 
 
 def test_tepe_metrics_kernel_matches_torch_reference():
