@@ -38,6 +38,8 @@ class ConsistentOnlineDynamicDepth(RuntimeState, nn.Module):
                 self.motion.prefetch(left_img, state)  # image-only work (+ correlation pyramid) overlaps the stereo network
             outputs = self.stereo.stereo_matching(left_img, right_img, img_metas, state)
             if self.motion is not None:
+                if self.fusion is not None and hasattr(self.fusion, "prefetch_key"):
+                    self.fusion.prefetch_key(outputs["left_feat"])  # key projection beside the motion stage
                 self.motion(state, outputs, img_metas=img_metas, train_mode=False)
             if self.fusion is not None:
                 self.fusion.memory_query(outputs, state, img_metas=img_metas)

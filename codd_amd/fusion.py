@@ -67,6 +67,20 @@ class Fusion(ops.RuntimeState, nn.Module):
             c = self.__dict__["_codd_forget_matrix"] = (ver, weff)
         return c[1]
 
+    def prefetch_key(self, left_feat):
+        """key_layer(left_feat) (reference fusion.py:74-80, 361) depends on the stereo network only: issued on a side
+        stream BEFORE the motion stage so that its four small launches run beside the update loop instead of between
+        the loop and the cue kernels; memory_query joins it."""
+        if ops.Fork.serial:
+            return
+        dev = left_feat.device
+        side = self.__dict__.get("_kside")
+        if side is None or side.device != dev:
+            side = self.__dict__["_kside"] = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self.__dict__["_pending"] = (left_feat, self._key(left_feat), side)
+
     def _key(self, x):
         """reference fusion.py:74-80."""
         k = self.key_layer
@@ -78,7 +92,12 @@ class Fusion(ops.RuntimeState, nn.Module):
     def memory_query(self, outputs, state, *args, **kwargs):
         """reference fusion.py:357-402."""
         left_feat, pred_curr = outputs["left_feat"], outputs["pred_disp"]
-        feat_curr = self._key(left_feat)
+        pend = self.__dict__.pop("_pending", None)
+        if pend is not None and pend[0] is left_feat:  # projected beside the motion stage (prefetch_key)
+            torch.cuda.current_stream(left_feat.device).wait_stream(pend[2])
+            feat_curr = pend[1]
+        else:
+            feat_curr = self._key(left_feat)
         if "memory" not in state:
             outputs["left_feat"] = feat_curr
             return
