@@ -96,53 +96,79 @@ __global__ __launch_bounds__(256) void tile_warp_kernel(const float* __restrict_
   const float* frb = fr + (size_t)b * C * H * W + (size_t)yy * W;
   const size_t chw = (size_t)H * W;
 
-  for (int hsel = 0; hsel < nhyp; ++hsel) {
-    const codd_view hv = hsel ? h1 : h0;
-    float* out = (hsel ? out1 : out0) + (size_t)b * 64 * thw + tpix;
+  // Both hypothesis sets in ONE pass over the channels (they share the left-feature load), every gather of a channel
+  // issued unconditionally (clamped address, masked value) and two channels per trip: the loop used to be a chain of
+  // C dependent L2 round trips per hypothesis set (~27 us at every coarse level whatever its size).
+  int f0[2][4];
+  float a[2][4];
+  unsigned okm[2] = {0u, 0u};  // bit ix * 4 + q: tap q of sub-pixel ix lies inside the row
+#pragma unroll
+  for (int hsel = 0; hsel < 2; ++hsel) {
+    const codd_view hv = (hsel && nhyp == 2) ? h1 : h0;
     const float* hp = hv.ptr + ((size_t)b * hv.ctot + hv.coff) * thw + tpix;
     const float d = hp[0], dx = hp[thw], dy = hp[2 * thw];
-    float fea[4] = {0.f, 0.f, 0.f, 0.f};
-    float cv[3][4] = {{0.f}};
-    int f0[4];
-    float a[4];
 #pragma unroll
     for (int ix = 0; ix < 4; ++ix) {
       const float delta = d + (ix - 1.5f) * dx + (iy - 1.5f) * dy;
       const float xs = (float)(4 * tx + ix) - delta;  // k = 0
       const float fl0 = floorf(xs);
-      a[ix] = xs - fl0;
+      a[hsel][ix] = xs - fl0;
       // clamp far-away samples so that the int conversion is defined; all 4 taps are then OOB
-      f0[ix] = (int)fminf(fmaxf(fl0, -4.f), (float)W + 4.f);
+      f0[hsel][ix] = (int)fminf(fmaxf(fl0, -4.f), (float)W + 4.f);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if ((unsigned)(f0[hsel][ix] - 1 + q) < (unsigned)W) okm[hsel] |= 1u << (ix * 4 + q);
     }
-    for (int c = 0; c < C; ++c) {
-      const float4 l4 = *(const float4*)(flb + c * chw);
-      const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
-      const float* rr = frb + c * chw;
+  }
+  float fea[4] = {0.f, 0.f, 0.f, 0.f};
+  float cv[2][3][4] = {{{0.f}}};
+#pragma unroll 2
+  for (int c = 0; c < C; ++c) {
+    const float4 l4 = *(const float4*)(flb + c * chw);
+    const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
+    const float* rr = frb + c * chw;
+    float t[2][4][4];
 #pragma unroll
-      for (int ix = 0; ix < 4; ++ix) {
-        float t[4];
+    for (int hsel = 0; hsel < 2; ++hsel) {
+      if (hsel < nhyp) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int xi = f0[ix] - 1 + q;
-          t[q] = ((unsigned)xi < (unsigned)W) ? rr[xi] : 0.f;
+        for (int ix = 0; ix < 4; ++ix)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int xi = min(max(f0[hsel][ix] - 1 + q, 0), W - 1);
+            t[hsel][ix][q] = rr[xi];
+          }
+      }
+    }
+#pragma unroll
+    for (int ix = 0; ix < 4; ++ix) fea[ix] += fabsf(lv[ix]);
+#pragma unroll
+    for (int hsel = 0; hsel < 2; ++hsel) {
+      if (hsel < nhyp) {
+#pragma unroll
+        for (int ix = 0; ix < 4; ++ix) {
+          float tq[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) tq[q] = (okm[hsel] >> (ix * 4 + q)) & 1u ? t[hsel][ix][q] : 0.f;
+          const float w1 = a[hsel][ix], w0 = 1.f - a[hsel][ix];
+          // k = -1: xs+1 -> taps (f+1, f+2); k = 0: (f, f+1); k = +1: (f-1, f)
+          cv[hsel][0][ix] += fabsf(lv[ix] - (w0 * tq[2] + w1 * tq[3]));
+          cv[hsel][1][ix] += fabsf(lv[ix] - (w0 * tq[1] + w1 * tq[2]));
+          cv[hsel][2][ix] += fabsf(lv[ix] - (w0 * tq[0] + w1 * tq[1]));
         }
-        const float w1 = a[ix], w0 = 1.f - a[ix];
-        // k = -1: xs+1 -> taps (f+1, f+2); k = 0: (f, f+1); k = +1: (f-1, f)
-        cv[0][ix] += fabsf(lv[ix] - (w0 * t[2] + w1 * t[3]));
-        cv[1][ix] += fabsf(lv[ix] - (w0 * t[1] + w1 * t[2]));
-        cv[2][ix] += fabsf(lv[ix] - (w0 * t[0] + w1 * t[1]));
-        if (hsel == 0) fea[ix] += fabsf(lv[ix]);
       }
     }
+  }
 #pragma unroll
-    for (int ix = 0; ix < 4; ++ix) {
-      const int ch = iy * 4 + ix;
-      if (hsel == 0) {
-        out0[(size_t)b * 64 * thw + tpix + (size_t)ch * thw] = fea[ix];
-        if (nhyp == 2) out1[(size_t)b * 64 * thw + tpix + (size_t)ch * thw] = fea[ix];
-      }
+  for (int ix = 0; ix < 4; ++ix) {
+    const int ch = iy * 4 + ix;
+    const size_t o = (size_t)b * 64 * thw + tpix;
+    out0[o + (size_t)ch * thw] = fea[ix];
+    if (nhyp == 2) out1[o + (size_t)ch * thw] = fea[ix];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) out[(size_t)(16 + k * 16 + ch) * thw] = cv[k][ix];
+    for (int k = 0; k < 3; ++k) {
+      out0[o + (size_t)(16 + k * 16 + ch) * thw] = cv[0][k][ix];
+      if (nhyp == 2) out1[o + (size_t)(16 + k * 16 + ch) * thw] = cv[1][k][ix];
     }
   }
 }
