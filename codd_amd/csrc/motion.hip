@@ -231,33 +231,50 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
   const float* vol = (lvl == 0 ? l0 : lvl == 1 ? l1 : lvl == 2 ? l2 : l3) + (size_t)b * N * h2 * w2;
   const float inv = 1.f / (float)(1 << lvl);
   const int tx = lane & 7, ty = lane >> 3;
+  // three unrolled phases over the wave's PPW pixels -- all pose / depth loads, then all volume gathers, then the
+  // bilinear blends -- instead of PPW dependent (load -> project -> gather -> blend) chains one after the other: the
+  // kernel is a latency chain, two L2 / HBM round trips per wave instead of 2 * PPW
+  float x0[PPW], y0[PPW];
+  bool live[PPW];
+#pragma unroll
   for (int q = 0; q < PPW; ++q) {
-    const int pi = wave * PPW + q, n = n0 + pi;
-    if (n >= N) break;
+    const int n = n0 + wave * PPW + q;
+    live[q] = n < N;
+    const int nn = live[q] ? n : N - 1;
     float px, py;
     if (coords) {
-      const float* cp = coords + ((size_t)b * N + n) * cstride;
+      const float* cp = coords + ((size_t)b * N + nn) * cstride;
       px = cp[0]; py = cp[1];
     } else {  // every lane recomputes the projection of its wave's pixel (reference raft3d.py:225-227)
-      const int yy = n / w, xx = n - yy * w;
-      const SE3T Ti = se3_load(gm.T + ((size_t)b * N + n) * 7);
-      const V3 pp = project(se3_act(Ti, inv_project(gm.d1[(size_t)b * N + n], xx, yy, gm.fx, gm.fy, gm.cx, gm.cy)), gm.fx,
+      const int yy = nn / w, xx = nn - yy * w;
+      const SE3T Ti = se3_load(gm.T + ((size_t)b * N + nn) * 7);
+      const V3 pp = project(se3_act(Ti, inv_project(gm.d1[(size_t)b * N + nn], xx, yy, gm.fx, gm.fy, gm.cx, gm.cy)), gm.fx,
                             gm.fy, gm.cx, gm.cy);
       px = pp.x; py = pp.y;
     }
-    const float x0 = px * inv, y0 = py * inv;
-    float fx = floorf(x0), fy = floorf(y0);
-    const float dx = x0 - fx, dy = y0 - fy;
+    x0[q] = px * inv; y0[q] = py * inv;
+  }
+  float v[PPW], dxq[PPW], dyq[PPW];
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) {
+    const int nn = live[q] ? n0 + wave * PPW + q : N - 1;
+    float fx = floorf(x0[q]), fy = floorf(y0[q]);
+    dxq[q] = x0[q] - fx; dyq[q] = y0[q] - fy;
     // keep the int conversion defined for wild coordinates; everything is out of range then
     fx = fminf(fmaxf(fx, -16.f), (float)w2 + 16.f);
     fy = fminf(fmaxf(fy, -16.f), (float)h2 + 16.f);
     const int ix = (int)fx - 3 + tx, iy = (int)fy - 3 + ty;
-    float v = 0.f;
-    if ((unsigned)ix < (unsigned)w2 && (unsigned)iy < (unsigned)h2 && x0 == x0 && y0 == y0)
-      v = vol[(size_t)n * h2 * w2 + (size_t)iy * w2 + ix];
-    const float vx = __shfl_down(v, 1, 64), vy = __shfl_down(v, 8, 64), vxy = __shfl_down(v, 9, 64);
-    if (tx < 7 && ty < 7) {
-      const float r = ((1.f - dx) * (1.f - dy)) * v + (dx * (1.f - dy)) * vx + ((1.f - dx) * dy) * vy + (dx * dy) * vxy;
+    const bool in = (unsigned)ix < (unsigned)w2 && (unsigned)iy < (unsigned)h2 && x0[q] == x0[q] && y0[q] == y0[q];
+    const float t = vol[(size_t)nn * h2 * w2 + (size_t)(in ? iy : 0) * w2 + (in ? ix : 0)];  // unconditional, masked
+    v[q] = in ? t : 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) {
+    const int pi = wave * PPW + q;
+    const float dx = dxq[q], dy = dyq[q];
+    const float vx = __shfl_down(v[q], 1, 64), vy = __shfl_down(v[q], 8, 64), vxy = __shfl_down(v[q], 9, 64);
+    if (live[q] && tx < 7 && ty < 7) {
+      const float r = ((1.f - dx) * (1.f - dy)) * v[q] + (dx * (1.f - dy)) * vx + ((1.f - dx) * dy) * vy + (dx * dy) * vxy;
       tile[tx * 7 + ty][pi] = r;  // channel = i*7 + j, i = x offset, j = y offset
     }
   }
