@@ -511,7 +511,13 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
           if (p.res2.ptr) v += *(const f32x4*)(view_ptr(p.res2, b, co, hwout) + pix);
           v = convb_act(v, p.act, co);
           if (p.post.ptr) v += *(const f32x4*)(view_ptr(p.post, b, co, hwout) + pix);
+#if defined(CONVB_NT_STORE)
+          __builtin_nontemporal_store(v, (f32x4*)op);
+#elif defined(CONVB_SC1_STORE)
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(op), "v"(v) : "memory");
+#else
           *(f32x4*)op = v;
+#endif
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
