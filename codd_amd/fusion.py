@@ -93,8 +93,9 @@ class Fusion(ops.RuntimeState, nn.Module):
         """reference fusion.py:357-402."""
         left_feat, pred_curr = outputs["left_feat"], outputs["pred_disp"]
         pend = self.__dict__.pop("_pending", None)
-        if pend is not None and pend[0] is left_feat:  # projected beside the motion stage (prefetch_key)
+        if pend is not None:  # projected beside the motion stage (prefetch_key): always join the side stream
             torch.cuda.current_stream(left_feat.device).wait_stream(pend[2])
+        if pend is not None and pend[0] is left_feat:
             feat_curr = pend[1]
         else:
             feat_curr = self._key(left_feat)
