@@ -456,9 +456,10 @@ extern "C" int codd_raft_geometry(const float* T, const float* depth1, const flo
 __global__ void se3_gn_prep_kernel(const float* __restrict__ ae, int ae_c, const float* __restrict__ xyz,
                                    const float* __restrict__ delta, const float* __restrict__ wgt,
                                    const float* __restrict__ d1, int h, int w, float fx, float fy, float cx, float cy,
-                                   float* __restrict__ jd) {
+                                   float* __restrict__ jd, int* __restrict__ cnt, int ntiles) {
   const int N = h * w;
   const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (j < ntiles) cnt[b * ntiles + j] = 0;  // arrival counters of the builder launched next (ntiles <= N)
   if (j >= N) return;
   const int yj = j / w, xj = j - yj * w;
   const float* aeb = ae + (size_t)b * ae_c * N;
@@ -501,9 +502,12 @@ __global__ __launch_bounds__(64) void gn_heads_prep_kernel(const codd_xs_view hs
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ xyz, const float* __restrict__ d1,
                                                           int h, int w, float fx, float fy, float cx, float cy,
-                                                          float* __restrict__ jd, float* __restrict__ wout) {
+                                                          float* __restrict__ jd, float* __restrict__ wout,
+                                                          int* __restrict__ cnt, int ntiles) {
   const int N = h * w;
   const int lane = threadIdx.x, px = lane & 15, g = lane >> 4, b = blockIdx.y;
+  if (lane == 0)  // arrival counters of the builder launched next
+    for (int i = blockIdx.x; i < ntiles; i += gridDim.x) cnt[b * ntiles + i] = 0;
   const int n = blockIdx.x * 16 + px;
   const bool ok = n < N;
   const int j = ok ? n : N - 1;
@@ -614,10 +618,18 @@ extern "C" int codd_gn_stats(unsigned long long* out, int reset) {  // dev build
   return CODD_OK;
 }
 #endif
+static __device__ __forceinline__ void gn_solve_tile(float* __restrict__ T, const float (*sums)[64], int lane, int b,
+                                                     int tx0, int ty0, int h, int w, float lm, float ep);
+// FUSE: the LAST workgroup of a tile to deliver its partial (device-scope counter cnt[b][tile], zeroed by the record
+// packing kernel of the same step) adds the tile's G partials in index order and solves -- no separate solve launch.
+// T is then read (every workgroup of the tile, before its partial is counted) and written (the last one) by this
+// kernel: only ever for the workgroup's own tile.
+template <bool FUSE>
 __global__ __launch_bounds__(64 * GN_WAVES) void se3_gn_build_kernel(
-    const float* __restrict__ T, const float* __restrict__ jd, int h, int w, float fx, float fy, float cx, float cy,
-    int radius, int tiles_x, int ntiles, int q4, int gmax, float* __restrict__ part) {
+    float* T, const float* __restrict__ jd, int h, int w, float fx, float fy, float cx, float cy,
+    int radius, int tiles_x, int ntiles, int q4, int gmax, float* part, int* cnt, float lm, float ep) {
   __shared__ float red[GN_WAVES][27][64];
+  __shared__ int s_last;
   const int N = h * w;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -728,38 +740,46 @@ __global__ __launch_bounds__(64 * GN_WAVES) void se3_gn_build_kernel(
   for (int k = 0; k < 27; ++k) red[wave][k][lane] = Hs[k];
   __syncthreads();
   float* pp = part + (((size_t)b * ntiles + tile) * gmax + g) * 27 * 64 + lane;
-  for (int k = wave; k < 27; k += GN_WAVES)
-    pp[k * 64] = ((red[0][k][lane] + red[1][k][lane]) + red[2][k][lane]) + red[3][k][lane];
-}
-
-// One workgroup per tile: 14 waves add the tile's G partials (fixed order -> deterministic), wave 0 damps, solves
-// (Cholesky, fp64) and retracts its 64 pixels.
-__global__ __launch_bounds__(64 * GN_SOLVE_WAVES) void se3_gn_solve_kernel(
-    float* __restrict__ T, const float* __restrict__ part, int h, int w, int radius, int tiles_x, int ntiles, int q4,
-    int gmax, float lm, float ep) {
-  __shared__ float sums[27][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = blockIdx.x, b = blockIdx.y;
-  const int tx0 = (tile % tiles_x) * 8, ty0 = (tile / tiles_x) * 8;
-  {
-    const int ylo = max(ty0 - radius, 0), yhi = min(ty0 + 7 + radius, h - 1);
-    const int xlo = max(tx0 - radius, 0), xhi = min(tx0 + 7 + radius, w - 1);
-    const int G = gn_groups((yhi - ylo + 1) * (xhi - xlo + 1), q4, gmax);
+  if constexpr (!FUSE) {
+    for (int k = wave; k < 27; k += GN_WAVES)
+      pp[k * 64] = ((red[0][k][lane] + red[1][k][lane]) + red[2][k][lane]) + red[3][k][lane];
+  } else {
+    // Device-scope hand-over WITHOUT fences (an agent-scope fence writes back / invalidates the whole L2 of the XCD --
+    // measured: +280 us per step, every other workgroup loses its cached neighbour records): the partials are written
+    // through (relaxed agent-scope stores = sc1), each wave waits for its own stores, the workgroup's arrival is
+    // counted after a barrier, and the last workgroup reads the partials with sc1 loads.
+    for (int k = wave; k < 27; k += GN_WAVES)
+      __hip_atomic_store(pp + k * 64, ((red[0][k][lane] + red[1][k][lane]) + red[2][k][lane]) + red[3][k][lane],
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+      s_last = __hip_atomic_fetch_add(cnt + b * ntiles + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1;
+    __syncthreads();
+    if (!s_last) return;
+    float (*sums)[64] = red[0];
     const float* p = part + (((size_t)b * ntiles + tile) * gmax) * 27 * 64 + lane;
-    for (int k = wave; k < 27; k += GN_SOLVE_WAVES) {
+#define GN_LD(q) __hip_atomic_load(p + ((size_t)(q) * 27 + k) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+    for (int k = wave; k < 27; k += GN_WAVES) {
       float s = 0.f;
-      int g = 0;
-      for (; g + 4 <= G; g += 4) {  // four loads in flight, added in index order
-        const float v0 = p[((size_t)g * 27 + k) * 64], v1 = p[((size_t)(g + 1) * 27 + k) * 64];
-        const float v2 = p[((size_t)(g + 2) * 27 + k) * 64], v3 = p[((size_t)(g + 3) * 27 + k) * 64];
+      int gg = 0;
+      for (; gg + 4 <= G; gg += 4) {  // four loads in flight, added in index order (as se3_gn_solve_kernel)
+        const float v0 = GN_LD(gg), v1 = GN_LD(gg + 1), v2 = GN_LD(gg + 2), v3 = GN_LD(gg + 3);
         s = (((s + v0) + v1) + v2) + v3;
       }
-      for (; g < G; ++g) s += p[((size_t)g * 27 + k) * 64];
+      for (; gg < G; ++gg) s += GN_LD(gg);
       sums[k][lane] = s;
     }
+#undef GN_LD
+    __syncthreads();
+    if (wave == 0) gn_solve_tile(T, sums, lane, b, tx0, ty0, h, w, lm, ep);
   }
-  __syncthreads();
-  if (wave != 0) return;
+}
+
+// Damp, solve (Cholesky, fp64) and retract the 64 pixels of one tile from its summed normal equations sums[27][64]
+// (one wave; lane = pixel).
+static __device__ __forceinline__ void gn_solve_tile(float* __restrict__ T, const float (*sums)[64], int lane, int b,
+                                                     int tx0, int ty0, int h, int w, float lm, float ep) {
   const int xi = tx0 + (lane & 7), yi = ty0 + (lane >> 3);
   if (xi >= w || yi >= h) return;
   const int N = h * w, i = yi * w + xi;
@@ -817,6 +837,37 @@ __global__ __launch_bounds__(64 * GN_SOLVE_WAVES) void se3_gn_solve_kernel(
   }
 }
 
+// One workgroup per tile: 14 waves add the tile's G partials (fixed order -> deterministic), wave 0 damps, solves
+// (Cholesky, fp64) and retracts its 64 pixels.  (The separate-launch form: CODD_GN_FUSED_SOLVE=0.)
+__global__ __launch_bounds__(64 * GN_SOLVE_WAVES) void se3_gn_solve_kernel(
+    float* __restrict__ T, const float* __restrict__ part, int h, int w, int radius, int tiles_x, int ntiles, int q4,
+    int gmax, float lm, float ep) {
+  __shared__ float sums[27][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x, b = blockIdx.y;
+  const int tx0 = (tile % tiles_x) * 8, ty0 = (tile / tiles_x) * 8;
+  {
+    const int ylo = max(ty0 - radius, 0), yhi = min(ty0 + 7 + radius, h - 1);
+    const int xlo = max(tx0 - radius, 0), xhi = min(tx0 + 7 + radius, w - 1);
+    const int G = gn_groups((yhi - ylo + 1) * (xhi - xlo + 1), q4, gmax);
+    const float* p = part + (((size_t)b * ntiles + tile) * gmax) * 27 * 64 + lane;
+    for (int k = wave; k < 27; k += GN_SOLVE_WAVES) {
+      float s = 0.f;
+      int g = 0;
+      for (; g + 4 <= G; g += 4) {  // four loads in flight, added in index order
+        const float v0 = p[((size_t)g * 27 + k) * 64], v1 = p[((size_t)(g + 1) * 27 + k) * 64];
+        const float v2 = p[((size_t)(g + 2) * 27 + k) * 64], v3 = p[((size_t)(g + 3) * 27 + k) * 64];
+        s = (((s + v0) + v1) + v2) + v3;
+      }
+      for (; g < G; ++g) s += p[((size_t)g * 27 + k) * 64];
+      sums[k][lane] = s;
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  gn_solve_tile(T, sums, lane, b, tx0, ty0, h, w, lm, ep);
+}
+
 // Neighbours per workgroup (4 waves): small enough that the launch is several dispatch rounds of equal-sized
 // waves (dynamic balance over the 256 CUs), large enough that a wave's set-up (its 32 + 12 per-pixel registers) and
 // the per-workgroup partial (6.9 KB) stay in the noise.
@@ -831,7 +882,17 @@ static inline int gn_gmax(int radius) {
 
 extern "C" long long codd_se3_gn_scratch(int B, int h, int w, int radius) {
   const int ntiles = cdiv(w, 8) * cdiv(h, 8);
-  return (long long)B * ntiles * gn_gmax(radius) * 27 * 64 + (long long)B * h * w * GN_JS;
+  return (long long)B * ntiles * gn_gmax(radius) * 27 * 64 + (long long)B * h * w * GN_JS + (long long)B * ntiles;
+}
+// [partials | neighbour records | per-tile arrival counters]
+static inline int* gn_counters(float* Hb, int B, int h, int w, int radius) {
+  const int ntiles = cdiv(w, 8) * cdiv(h, 8);
+  return (int*)(Hb + (size_t)B * ntiles * gn_gmax(radius) * 27 * 64 + (size_t)B * h * w * GN_JS);
+}
+static inline bool gn_fused_solve() {
+  // dev A/B, OFF: measured 85.2-86.4 against 86.1-87.3 frames/s for the separate solve launch (DESIGN finding 24)
+  static const bool f = getenv("CODD_GN_FUSED_SOLVE") && atoi(getenv("CODD_GN_FUSED_SOLVE")) == 1;
+  return f;
 }
 
 static int gn_build_solve(float* T, int B, int h, int w, float fx, float fy, float cx, float cy, int radius, float lm,
@@ -840,8 +901,15 @@ static int gn_build_solve(float* T, int B, int h, int w, float fx, float fy, flo
   const int q4 = gn_q4(), gmax = gn_gmax(radius);
   float* part = Hb;
   const float* jd = Hb + (size_t)B * ntiles * gmax * 27 * 64;
-  se3_gn_build_kernel<<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, s>>>(T, jd, h, w, fx, fy, cx, cy, radius, tiles_x,
-                                                                      ntiles, q4, gmax, part);
+  int* cnt = gn_counters(Hb, B, h, w, radius);  // zeroed by the record packing kernel launched just before
+  if (gn_fused_solve()) {
+    se3_gn_build_kernel<true><<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, s>>>(T, jd, h, w, fx, fy, cx, cy, radius, tiles_x,
+                                                                              ntiles, q4, gmax, part, cnt, lm, ep);
+    CODD_LAUNCH_CHECK();
+    return CODD_OK;
+  }
+  se3_gn_build_kernel<false><<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, s>>>(T, jd, h, w, fx, fy, cx, cy, radius, tiles_x,
+                                                                             ntiles, q4, gmax, part, cnt, lm, ep);
   CODD_LAUNCH_CHECK();
   se3_gn_solve_kernel<<<dim3(ntiles, B), 64 * GN_SOLVE_WAVES, 0, s>>>(T, part, h, w, radius, tiles_x, ntiles, q4, gmax, lm, ep);
   CODD_LAUNCH_CHECK();
@@ -857,7 +925,7 @@ extern "C" int codd_se3_gn_step(float* T, const float* ae, int ae_c, const float
   float* jd = Hb + (size_t)B * ntiles * gn_gmax(radius) * 27 * 64;
   hipStream_t s = (hipStream_t)stream;
   se3_gn_prep_kernel<<<dim3(cdiv(h * w, 128), B), 128, 0, s>>>(ae, ae_c, xyz, delta, weight, depth1, h, w, fx, fy, cx,
-                                                             cy, jd);
+                                                             cy, jd, gn_counters(Hb, B, h, w, radius), ntiles);
   CODD_LAUNCH_CHECK();
   return gn_build_solve(T, B, h, w, fx, fy, cx, cy, radius, lm, ep, Hb, s);
 }
@@ -873,7 +941,7 @@ extern "C" int codd_se3_gn_step_heads(float* T, codd_xs_view hidden, const void*
   float* jd = Hb + (size_t)B * ntiles * gn_gmax(radius) * 27 * 64;
   hipStream_t s = (hipStream_t)stream;
   gn_heads_prep_kernel<<<dim3(cdiv(h * w, 16), B), 64, 0, s>>>(hidden, (const uint4*)head_w, head_b, xyz, depth1, h, w, fx, fy, cx, cy,
-                                                               jd, weight_out);
+                                                               jd, weight_out, gn_counters(Hb, B, h, w, radius), ntiles);
   CODD_LAUNCH_CHECK();
   return gn_build_solve(T, B, h, w, fx, fy, cx, cy, radius, lm, ep, Hb, s);
 }

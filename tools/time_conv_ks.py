@@ -15,6 +15,7 @@ LAYERS = [  # cin, cout, k, pad, dil, H, W, xs_out
     (256, 256, 3, 1, 1, 72, 120, True), (196, 256, 3, 1, 1, 72, 120, True), (128, 768, 3, 1, 1, 72, 120, True),
     (256, 384, 1, 0, 1, 72, 120, False), (128, 384, 1, 0, 1, 72, 120, False), (9, 128, 7, 3, 1, 72, 120, True),
     (64, 64, 3, 1, 1, 288, 480, False), (96, 96, 3, 1, 1, 144, 240, False), (128, 128, 3, 1, 1, 72, 120, False),
+    (384, 384, 1, 0, 1, 72, 120, False),  # [12] the merged encoder heads
 ]
 
 
@@ -76,7 +77,7 @@ def main():
         fam = {}
         for t, c, err in sorted(res, key=lambda r: r[0]):
             f = "ks2" if c[8] == 2 else ("8w" if c[5] * c[6] == 8 else "4w")
-            if fam.setdefault(f, 0) < 3:
+            if fam.setdefault(f, 0) < (int(os.environ.get('TOPN', 3))):
                 fam[f] += 1
                 print(f"   {f:4s} {t:7.1f} us {gflop / t * 1e3:6.1f} TF  (xb,th,ck,mb,_,pgw,cgw,terms,ks)={c} err {err:.1e}")
         bad = [r for r in res if not r[2] < 1e-4]
