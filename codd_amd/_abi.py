@@ -34,7 +34,7 @@ class ConvParams(C.Structure):
         ("xs", C.c_void_p), ("xs_c8", C.c_int), ("xs_hp", C.c_int), ("xs_wp", C.c_int),
         ("xs_bt", C.c_int), ("xs_bl", C.c_int), ("xs_o8", C.c_int),
         ("xso", C.c_void_p), ("xso_c8", C.c_int), ("xso_hp", C.c_int), ("xso_wp", C.c_int), ("xso_bt", C.c_int),
-        ("xso_bl", C.c_int), ("xso_o8", C.c_int), ("xso_terms", C.c_int), ("ksplit", C.c_int),
+        ("xso_bl", C.c_int), ("xso_o8", C.c_int), ("xso_terms", C.c_int), ("ksplit", C.c_int), ("dil2", C.c_int), ("gate", C.c_int),
     ]
 
 
@@ -120,7 +120,7 @@ SIGNATURES = {
     "codd_fusion_blend": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 6  # CODD_ABI_VERSION of include/codd_hip.h
+ABI_VERSION = 7  # CODD_ABI_VERSION of include/codd_hip.h
 _lib = None
 MISSING = []
 

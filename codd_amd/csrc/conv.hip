@@ -260,6 +260,7 @@ static int conv_fill(const codd_conv_params* pp, ConvK& k, size_t& lds, long lon
 
 extern "C" int codd_conv2d(const codd_conv_params* pp, void* stream) {
   if (!pp) return CODD_EINVAL;
+  if (pp->layout != 2 && (pp->dil2 || pp->gate)) return CODD_EUNSUPPORTED;  // dual tap sets / gate epilogues: layout 2 only
   if (pp->layout == 2) {
     const codd_conv_params& q = *pp;
     if (!q.xs || (!q.out && !q.xso) || !q.wpacked || q.C0 <= 0 || q.C1 < 0 || q.B < 1 || q.Cout < 1 || q.kh < 1 || q.kw < 1 ||

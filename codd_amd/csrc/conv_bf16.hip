@@ -75,7 +75,7 @@ int codd_conv2d_bf16(const codd_conv_params* pp, void* stream, int dry_run) {
 #define X(PGW, CGW, A, B, KS)                                                                    \
   if (p.pgw == PGW && p.cgw == CGW && a == A && bb == B && ks == KS)                             \
     return dry_run ? CODD_OK                                                                     \
-           : p.xso ? (p.terms == 3 ? launch_b<PGW, CGW, A, B, 3, 1, KS>(k, lds, (int)grid, s)    \
+           : (p.xso || p.gate) ? (p.terms == 3 ? launch_b<PGW, CGW, A, B, 3, 1, KS>(k, lds, (int)grid, s)    \
                                    : launch_b<PGW, CGW, A, B, 1, 1, KS>(k, lds, (int)grid, s))   \
                    : (p.terms == 3 ? launch_b<PGW, CGW, A, B, 3, 0, KS>(k, lds, (int)grid, s)    \
                                    : launch_b<PGW, CGW, A, B, 1, 0, KS>(k, lds, (int)grid, s));

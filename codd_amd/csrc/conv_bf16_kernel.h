@@ -53,6 +53,7 @@ struct ConvB {
   int nco;                        // output channels per workgroup = 16 * mb
   int wslots;                     // slots of one (channel group, chunk) weight image = planes * wplane16
   int tiles_x, tiles_y, ncog, cout_eff;
+  int khe;                        // tap rows of one tap set (kh, or kh / 2 with a dual tap set)
 };
 
 constexpr int CONVB_NWP = 4;  // producer waves per workgroup
@@ -86,7 +87,11 @@ static inline int convb_geometry(const codd_conv_params* pp, ConvB& k, size_t& l
   k.nchunks = cdiv(k.cin, p.ck);
   k.nk = cdiv((long long)k.ntaps * k.noct, 4);
   k.th = p.nw; k.xb = p.npb; k.pu = k.th * k.xb; k.tw = 16 * k.xb;
-  k.thi = (k.th - 1) * p.sy + (p.kh - 1) * p.dil_y + 1;
+  // dual tap set (dil2 > 0): kh counts the rows of both sets; the halo is that of the larger dilation (dil_y, dil_x)
+  if (p.dil2 < 0 || (p.dil2 > 0 && ((p.kh & 1) || !(p.kh / 2 & 1) || !(p.kw & 1) || p.dil2 > p.dil_y || p.dil2 > p.dil_x)))
+    return CODD_EINVAL;
+  k.khe = p.dil2 > 0 ? p.kh / 2 : p.kh;
+  k.thi = (k.th - 1) * p.sy + (k.khe - 1) * p.dil_y + 1;
   k.twi = (k.tw - 1) * p.sx + (p.kw - 1) * p.dil_x + 1;
   k.npix = k.thi * k.twi;
   k.os16 = ((k.npix + 15) / 16) * 16;
@@ -114,10 +119,26 @@ static inline int convb_geometry(const codd_conv_params* pp, ConvB& k, size_t& l
   // the split input must hold every halo tile (codd_split_bf16_dims gives a sufficient size)
   if (need_xs && (!p.xs || p.xs_o8 < 0 || p.xs_c8 < p.xs_o8 + k.nchunks * k.noct || p.xs_bt < p.pad_t ||
                   p.xs_bl < p.pad_l || p.xs_hp < p.xs_bt + p.Hin || p.xs_wp < p.xs_bl + p.Win ||
-                  p.xs_hp < p.xs_bt - p.pad_t + (k.tiles_y * k.th - 1) * p.sy + (p.kh - 1) * p.dil_y + 1 ||
+                  p.xs_hp < p.xs_bt - p.pad_t + (k.tiles_y * k.th - 1) * p.sy + (k.khe - 1) * p.dil_y + 1 ||
                   p.xs_wp < p.xs_bl - p.pad_l + (k.tiles_x * k.tw - 1) * p.sx + (p.kw - 1) * p.dil_x + 1))
     return CODD_EINVAL;
-  if (need_xs && p.xso) {  // split-record output: plain conv only; the tensor must hold the image inside its borders
+  if (p.gate < 0 || p.gate > 3) return CODD_EINVAL;
+  if (need_xs && p.gate) {  // ConvGRU gate epilogues (include/codd_hip.h): operands are channel-quad fp32 tensors
+    const int G = p.gate == 2 ? k.cout_eff / 3 : k.cout_eff;
+    auto c4ok = [](const codd_view& v, int need) {
+      return v.ptr && !((uintptr_t)v.ptr & 15) && !(v.ctot & 3) && !(v.coff & 3) && v.coff >= 0 && v.coff + need <= v.ctot;
+    };
+    if (p.store_mode || (G & 15) || (p.gate == 2 && 3 * G != k.cout_eff)) return CODD_EUNSUPPORTED;
+    if (!p.out || ((uintptr_t)p.out & 15) || (p.out_ctot & 3) || (p.out_coff & 3) ||
+        p.out_coff + (p.gate == 2 ? 2 * G : G) > p.out_ctot || (p.bias && ((uintptr_t)p.bias & 15)))
+      return CODD_EINVAL;
+    if (p.gate == 1 && (p.xso || p.res1.ptr || p.res2.ptr || p.post.ptr)) return CODD_EUNSUPPORTED;
+    if (p.gate == 2 && (!p.xso || !c4ok(p.res1, 3 * G) || !c4ok(p.res2, 2 * G) || !c4ok(p.post, G))) return CODD_EINVAL;
+    if (p.gate == 3 && (!p.xso || !c4ok(p.res1, 2 * G) || !c4ok(p.post, G) || p.res2.ptr)) return CODD_EINVAL;
+    if (p.xso && (!(p.xso_terms == 1 || p.xso_terms == 3) || p.xso_o8 < 0 || p.xso_bt < 0 || p.xso_bl < 0 ||
+                  p.xso_c8 < p.xso_o8 + cdiv(G, 8) || p.xso_hp < p.xso_bt + p.Hout || p.xso_wp < p.xso_bl + p.Wout))
+      return CODD_EINVAL;
+  } else if (need_xs && p.xso) {  // split-record output: plain conv only; the tensor must hold the image inside its borders
     if (p.store_mode || p.res1.ptr || p.res2.ptr || p.post.ptr || p.act == CODD_ACT_RELU_CH0) return CODD_EUNSUPPORTED;
     if (p.bias && ((uintptr_t)p.bias & 15)) return CODD_EINVAL;
     if (!(p.xso_terms == 1 || p.xso_terms == 3) || p.xso_o8 < 0 || p.xso_bt < 0 || p.xso_bl < 0 ||
@@ -229,7 +250,11 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
       int off = 0;
       if (e < k.nk * 4 && tap < k.ntaps) {
         const int ky = tap / p.kw, kx = tap - ky * p.kw;
-        off = oct * k.os16 + ky * p.dil_y * k.twi + kx * p.dil_x;
+        if (p.dil2 > 0 && ky < k.khe)  // the small-dilation tap set, centred inside the halo of the large one
+          off = oct * k.os16 + ((k.khe >> 1) * (p.dil_y - p.dil2) + ky * p.dil2) * k.twi +
+                (p.kw >> 1) * (p.dil_x - p.dil2) + kx * p.dil2;
+        else
+          off = oct * k.os16 + (ky - (p.dil2 > 0 ? k.khe : 0)) * p.dil_y * k.twi + kx * p.dil_x;
       }
       etab[e] = off;
     }
@@ -461,7 +486,50 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += co0 + r < k.cout_eff ? p.bias[co0 + r] : 0.f;
         }
-        v = convb_act(v, p.act, 1);  // (CODD_ACT_RELU_CH0 is a per-channel activation of fp32 outputs only)
+        int rco = co0;  // first channel of the lane's record half
+        if (p.gate) {
+          // ConvGRU gate epilogues on channel-quad fp32 tensors: a lane's 4 channels of one pixel are ONE 16-byte
+          // access, 16 lanes j = 256 contiguous bytes.  The 16-channel tile (and with it every branch) is wave-uniform.
+          const int hw_ = p.Hout * p.Wout, pix_ = oy * p.Wout + ox;
+          auto c4 = [&](const float* base, int ctot, int c) {
+            return (f32x4*)(base + (((size_t)b * (ctot >> 2) + (c >> 2)) * hw_ + pix_) * 4);
+          };
+          const bool live = inb && co0 < k.cout_eff;
+          const int ctile = co0 & ~15;
+          if (p.gate == 1) {
+            if (live) *c4(p.out, p.out_ctot, p.out_coff + co0) = v;
+            continue;
+          }
+          const int G = p.gate == 2 ? k.cout_eff / 3 : k.cout_eff;
+          if (p.gate == 2) {
+            if (live) v += *c4(p.res1.ptr, p.res1.ctot, p.res1.coff + co0);
+            if (ctile >= 2 * G) {  // q's input stream
+              if (live) *c4(p.out, p.out_ctot, p.out_coff + co0 - G) = v;
+              continue;
+            }
+            if (live) v += *c4(p.res2.ptr, p.res2.ctot, p.res2.coff + co0);
+            v = convb_act_slow(v, CODD_ACT_SIGMOID);
+            if (ctile < G) {  // z
+              if (live) *c4(p.out, p.out_ctot, p.out_coff + co0) = v;
+              continue;
+            }
+            rco = co0 - G;  // r * h -> records
+            if (live) v *= *c4(p.post.ptr, p.post.ctot, p.post.coff + rco);
+          } else {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f}, h = z;
+            if (live) {
+              v += *c4(p.res1.ptr, p.res1.ctot, p.res1.coff + G + co0);
+              z = *c4(p.res1.ptr, p.res1.ctot, p.res1.coff + co0);
+              h = *c4(p.post.ptr, p.post.ctot, p.post.coff + co0);
+            }
+            v = convb_act_slow(v, CODD_ACT_TANH);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (1.f - z[r]) * h[r] + z[r] * v[r];
+            if (live) *c4(p.out, p.out_ctot, p.out_coff + co0) = v;
+          }
+        } else {
+          v = convb_act(v, p.act, 1);  // (CODD_ACT_RELU_CH0 is a per-channel activation of fp32 outputs only)
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = co0 + r < k.cout_eff ? v[r] : 0.f;  // channel padding of the octet stays 0
         unsigned hi2[2], lo2[2];
@@ -476,7 +544,7 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
         const unsigned s0 = odd ? hi2[0] : lo2[0], s1 = odd ? hi2[1] : lo2[1];
         const unsigned r0 = __shfl_xor(s0, 16, 64), r1 = __shfl_xor(s1, 16, 64);
         const uint4 rec = odd ? make_uint4(r0, r1, lo2[0], lo2[1]) : make_uint4(hi2[0], hi2[1], r0, r1);
-        const int oct = (co0 >> 3) + p.xso_o8;  // both lanes of the pair: same octet (co0 differs by 4)
+        const int oct = (rco >> 3) + p.xso_o8;  // both lanes of the pair: same octet (co0 differs by 4)
         if (inb && (co0 & ~7) < k.cout_eff && (!odd || p.xso_terms == 3))
           xo[(size_t)(odd ? p.xso_c8 * orec : 0) + ((size_t)oct * p.xso_hp + oy + p.xso_bt) * p.xso_wp + ox + p.xso_bl] = rec;
       }

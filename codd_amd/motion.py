@@ -24,6 +24,8 @@ from .stereo import cv, packed
 BF_DEFAULT = 1050 * 0.2  # reference motion.py:45
 MERGE_ENC_HEADS = os.environ.get("CODD_MERGE_ENC_HEADS", "1") == "1"  # (A/B switch; see BasicUpdateBlock.run)
 FUSE_NORM_RECORDS = os.environ.get("CODD_FUSE_NORM_RECORDS", "1") == "1"  # (A/B switch; see ResidualBlock.run)
+# ConvGRU gates as convolution epilogues + each conv*1 / conv*2 pair as ONE dual-tap-set launch (BasicUpdateBlock.run)
+FUSE_GATES = os.environ.get("CODD_FUSE_GATES", "1") == "1"
 
 def packed_cat(mods):
     """One PackedConv whose output channels are the concatenation of several same-shape convs; cached on the first
@@ -51,6 +53,23 @@ def packed_cat_in(mods):
         w = torch.cat([m.weight.detach() for m in mods], 1)
         b = sum(m.bias.detach() for m in mods)
         ent = cache[key] = (ver, ops.PackedConv(w, b), tuple(mods))
+    return ent[1]
+
+
+def packed_dual(pairs):
+    """One PackedConv holding TWO tap sets over the same input (ops.conv_gate, dil2): ``pairs`` = [(conv_a1, conv_a2),
+    (conv_b1, conv_b2), ...]; output channels are the concatenation a | b | ..., the weight rows of every conv*1
+    (small dilation) come first, then those of conv*2: [cout, cin, 2k, k]; biases added.  conv1(x) + conv2(x) in one
+    launch.  Cached like packed_cat."""
+    mods = [m for pr in pairs for m in pr]
+    ver = tuple((m.weight.data_ptr(), m.weight._version, m.bias._version) for m in mods)
+    cache = mods[0].__dict__.setdefault("_codd_packed_cat", {})
+    key = ("dual",) + tuple(id(m) for m in mods)
+    ent = cache.get(key)
+    if ent is None or ent[0] != ver:
+        w = torch.cat([torch.cat([a.weight.detach(), b.weight.detach()], 2) for a, b in pairs], 0)
+        bias = torch.cat([a.bias.detach() + b.bias.detach() for a, b in pairs], 0)
+        ent = cache[key] = (ver, ops.PackedConv(w, bias), tuple(mods))
     return ent[1]
 
 
@@ -151,9 +170,40 @@ class BasicUpdateBlock(ops.RuntimeState, nn.Module):
         g = self.gru
         fk = self._forks(net.device)[1]
         ns = self._split(net)
+        if self._gates_fused(net) and getattr(self, "_fused_now", False):
+            # ONE launch: the 3x3 and the dilated 3x3 z|r convolutions as two tap sets over one input tile, result in
+            # the channel-quad layout the gate epilogue of the merged encoder-head convolution reads
+            B, _, h, w = net.shape
+            t12 = ops.c4_buffer((id(self), "t12"), B, 256, h, w, net.device)
+            pc = packed_dual(((g.convz1, g.convz2), (g.convr1, g.convr2)))
+            fk.run(0, lambda: ops.conv_gate(pc, ns, 1, pad=4, dil=4, dil2=1, out=t12))
+            return t12, None
         t2 = fk.run(0, lambda: ops.conv2d(net, packed_cat((g.convz2, g.convr2)), pad=4, dil=4, xs=ns))
         t1 = fk.run(1, lambda: ops.conv2d(net, packed_cat((g.convz1, g.convr1)), pad=1, xs=ns))
         return t1, t2
+
+    def _gates_fused(self, net):
+        return FUSE_GATES and MERGE_ENC_HEADS and ops.CONV_PRECISION in ("split", "bf16")
+
+    def _h4(self, net):
+        """The hidden state in the channel-quad layout (ops.C4Tensor) of the gate epilogues: written by the q-gate
+        epilogue together with the records; only the initial state (context network output) needs a copy."""
+        c = getattr(self, "_h4c", None)
+        if c is None or c[0] is not net:
+            B, _, h, w = net.shape
+            c = self._h4c = (net, ops.to_c4(net, ops.c4_buffer((id(self), "h4"), B, 128, h, w, net.device)))
+        return c[1]
+
+    def _ctx4(self, inp):
+        """The context stream in the channel-quad layout of the gate epilogues: one copy per frame (the same tensor
+        object enters all updates of a frame)."""
+        if isinstance(inp, ops.C4Tensor):
+            return inp
+        c = getattr(self, "_ctx4c", None)
+        if c is None or c[0] is not inp:
+            B, C, h, w = inp.shape
+            c = self._ctx4c = (inp, ops.to_c4(inp, ops.c4_buffer((id(self), "ctx4"), B, C, h, w, inp.device)))
+        return c[1]
 
     def _split(self, t):
         """The split-bf16 form (border 4: serves the 3x3 and the dilated 3x3 convolutions) of the hidden state, shared
@@ -189,6 +239,11 @@ class BasicUpdateBlock(ops.RuntimeState, nn.Module):
         previous update (``prefetch_next``); returns (net, mask, ae, delta, weight, zr_next)."""
         g = self.gru
         fk, fkz = self._forks(net.device)
+        # gates as convolution epilogues: only the record-input form of the call (the hot path, RAFT3D.forward); a
+        # call with explicit corr / minfo tensors returns the fp32 NCHW state and keeps the separate gate kernels
+        self._fused_now = corr is None and self._gates_fused(net)
+        if zr is not None and (zr[1] is None) != self._fused_now:
+            zr = None  # (forked by a call of the other form)
 
         # conv -> conv links: the producer writes its result as split-bf16 records straight into the consumer's input
         # tensor (persistent, zero-bordered: ops.split_buffer), so neither an fp32 tensor nor a re-layout pass exists
@@ -229,6 +284,22 @@ class BasicUpdateBlock(ops.RuntimeState, nn.Module):
             cv(self.corr_enc[0], corr, act="relu", xs=cin, xs_out=sb("corr_enc0", 256, 1))
             cv(self.corr_enc[2], None, act="relu", xs=sb("corr_enc0", 256, 1), xs_out=enc, xs_out_coff=0)
             fk.join()
+            if self._fused_now:
+                # gates as epilogues: the merged 1x1 convolution adds the context stream (``inp`` = its channel-quad
+                # copy, RAFT3D.forward) and the z|r convolutions' result and writes z, r * h (records) and q's input
+                # stream; the dual-tap-set q convolution ends in the state update -- 4 launches per update less
+                B, _, h, w = net.shape
+                h4 = self._h4(net)
+                zq = ops.c4_buffer((id(self), "zq"), B, 256, h, w, net.device)
+                rs, hb = sb("rh", 128, 4), sb("net", 128, 4)
+                fkz.join()
+                ops.conv_gate(packed_cat_in((self.corr_enc[4], self.flow_enc[2])), enc, 2, out=zq, res1=self._ctx4(inp), res2=t1,
+                              post=h4, xs_out=rs)
+                ops.conv_gate(packed_dual(((g.convq1, g.convq2),)), rs, 3, pad=4, dil=4, dil2=1, out=h4, res1=zq, post=h4,
+                              xs_out=hb)
+                net = self._h4c[0]  # (the fp32 NCHW state is not kept: h4 / hb ARE the state; same token object)
+                self._xs = (net, hb)
+                return self._heads(net, need_mask, prefetch_next, fuse_heads, sb, fk)
             inp = ops.conv2d(None, packed_cat_in((self.corr_enc[4], self.flow_enc[2])), xs=enc, res1=inp)
             cor = mot = None
         else:
@@ -250,6 +321,9 @@ class BasicUpdateBlock(ops.RuntimeState, nn.Module):
             fk.join()
             net = ops.gru_gate_q_xs(q1, q2, inp, cor, mot, z, net, hb)
             self._xs = (net, hb)
+        return self._heads(net, need_mask, prefetch_next, fuse_heads, sb, fk)
+
+    def _heads(self, net, need_mask, prefetch_next, fuse_heads, sb, fk):
         zr_next = None
         # the four 3x3 head convs share their input: one 768/1024-channel conv; the mask head (576
         # up-sampling weights) is only consumed after the last iteration (raft3d.py:267-273)
@@ -259,7 +333,9 @@ class BasicUpdateBlock(ops.RuntimeState, nn.Module):
             hid = ops.conv2d(net, packed_cat(heads), pad=1, act="relu")
             sl = lambda i: Slice(hid, 256 * i, 256)
         else:  # the 768 / 1024 hidden channels only ever exist as the four 1x1 heads' split-form input
-            ops.conv2d(net, packed_cat(heads), pad=1, act="relu", xs=self._split(net), xs_out=hs)
+            # (fused gates: ``net`` is only the state's identity token, its fp32 values are the INITIAL state)
+            ops.conv2d(None if self._fused_now else net, packed_cat(heads), pad=1, act="relu",
+                       xs=self._split(net), xs_out=hs)
             sl = lambda i: None
         if prefetch_next:
             # forked AFTER the head convolution is enqueued: the side streams wait for it, so the next update's z|r

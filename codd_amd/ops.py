@@ -15,7 +15,7 @@ class RuntimeState:
     """Mixin of the plug-in modules that keep launch-time objects (side streams, fork helpers, pending prefetches,
     captured frame graphs) in their ``__dict__``: those are neither picklable nor copyable and are rebuilt on demand,
     so they are left out of the module's pickled / deep-copied state."""
-    _RUNTIME_KEYS = ("_side", "_pending", "_nowait", "_fk", "_xs", "_runners", "_kside")
+    _RUNTIME_KEYS = ("_side", "_pending", "_nowait", "_fk", "_xs", "_runners", "_kside", "_h4c", "_ctx4c", "_fused_now")
 
     def __getstate__(self):
         state = self.__dict__.copy()
@@ -589,6 +589,97 @@ def conv2d_multi(jobs):
             outs[idx] = conv2d(j["x"], j["pc"], stride=j.get("stride", 1), pad=j.get("pad", 0), act=j.get("act", "none"),
                                res1=j.get("res1"))
     return outs
+
+
+class C4Tensor:
+    """A channel-quad fp32 activation [B][C/4][H*W][4] (include/codd_hip.h, codd_conv_params.gate): the private layout of
+    the ConvGRU's gate operands -- a lane of the split-bf16 kernel's record-form accumulator holds 4 consecutive
+    channels of one pixel, i.e. one 16-byte access here."""
+    __slots__ = ("buf", "B", "C", "H", "W")
+
+    def __init__(self, buf, B, C, H, W):
+        self.buf, self.B, self.C, self.H, self.W = buf, B, C, H, W
+
+    def view(self, coff=0):
+        return _abi.View(self.buf.data_ptr(), self.C, coff)
+
+    def nchw(self):
+        """-> a new fp32 NCHW tensor (tests / the hand-over to code outside the update block)."""
+        return self.buf.view(self.B, self.C // 4, self.H * self.W, 4).permute(0, 1, 3, 2).reshape(
+            self.B, self.C, self.H, self.W).contiguous()
+
+
+_C4_BUFFERS = {}
+
+
+def c4_buffer(key, B, C, H, W, device):
+    """A persistent C4Tensor per call site (``key``) and shape."""
+    assert C % 4 == 0
+    k = (key, B, C, H, W, str(device))
+    t = _C4_BUFFERS.get(k)
+    if t is None:
+        t = _C4_BUFFERS[k] = C4Tensor(torch.zeros(B * C * H * W, device=device, dtype=torch.float32), B, C, H, W)
+    return t
+
+
+def to_c4(x, out):
+    """fp32 NCHW tensor -> the C4Tensor ``out`` (one strided copy)."""
+    B, C, H, W = x.shape
+    assert (out.B, out.C, out.H, out.W) == (B, C, H, W)
+    out.buf.view(B, C // 4, H * W, 4).copy_(x.reshape(B, C // 4, 4, H * W).permute(0, 1, 3, 2))
+    return out
+
+
+def conv_gate(pc, xs, gate, pad=0, dil=1, dil2=0, out=None, out_coff=0, res1=None, res2=None, post=None, xs_out=None,
+              xs_coff=0):
+    """A stride-1 'same' convolution of the split tensor ``xs`` on the split-bf16 kernel with a ConvGRU gate epilogue
+    (include/codd_hip.h, codd_conv_params.gate / dil2): ``gate`` 1 = plain result into the C4Tensor ``out``;
+    2 = z | r*h | q-input of the merged gate-input convolution; 3 = the hidden-state update.  ``dil2``: the weights
+    hold two tap sets ([cout, cin, 2*k, k]: dilation dil2 rows first, then dilation dil), both over one input tile.
+    out / res1 / res2 / post are C4Tensors, xs_out a SplitTensor."""
+    lib = _abi.load()
+    terms = _TERMS.get(CONV_PRECISION, 0)
+    if not terms:
+        raise _abi.CoddHipError("gate-epilogue convolutions need the 'split' or 'bf16' conv precision")
+    _require_gpu(xs.buf)
+    B, H, W = xs.B, xs.H, xs.W
+    p = ConvParams()
+    p.C0, p.C1, p.B, p.Hin, p.Win = pc.cin, 0, B, H, W
+    p.bias = None if pc.bias is None else pc.bias.data_ptr()
+    p.Cout, p.Hout, p.Wout = pc.cout, H, W
+    p.kh, p.kw, p.sy, p.sx, p.pad_t, p.pad_l, p.dil_y, p.dil_x = pc.kh, pc.kw, 1, 1, pad, pad, dil, dil
+    p.dil2, p.gate, p.terms, p.layout = dil2, gate, terms, 2
+    p.out, p.out_ctot, p.out_coff = out.buf.data_ptr(), out.C, out_coff
+    for name, t in (("res1", res1), ("res2", res2), ("post", post)):
+        if t is not None:
+            setattr(p, name, t.view())
+    p.xs, p.xs_c8, p.xs_hp, p.xs_wp = xs.buf.data_ptr(), xs.c8, xs.hp, xs.wp
+    p.xs_bt, p.xs_bl, p.xs_o8 = xs.bt, xs.bl, xs_coff // 8
+    if xs_out is not None:
+        p.xso, p.xso_c8, p.xso_hp, p.xso_wp = xs_out.buf.data_ptr(), xs_out.c8, xs_out.hp, xs_out.wp
+        p.xso_bt, p.xso_bl, p.xso_o8, p.xso_terms = xs_out.bt, xs_out.bl, 0, xs_out.terms
+    key = ("gate", gate, H, W, B, pad, dil, dil2, terms)
+    cfg = pc.tuned.get(key)
+    if cfg is None:
+        sig = "g%d,b%d|%d,%d,%d,%d|%d,%d,%d,%d,%d,%d" % (gate, terms, pc.cout, pc.cin, pc.kh, pc.kw, H, W, B, pad, dil, dil2)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if _AUTOTUNE and sig in TUNE_DB and _db_cfg_ok(lib, p, TUNE_DB[sig], sig):
+            cfg = tuple(TUNE_DB[sig])
+        else:
+            cands = [c for c in _bf16_candidates(pc, H, W, B, pc.kh * pc.kw, terms) if _cfg_ok(lib, p, c)]
+            if not cands:
+                raise _abi.CoddHipError("no split-bf16 launch configuration for gate conv %dx%d %d->%d" % (
+                    pc.kh, pc.kw, pc.cin, pc.cout))
+            if _AUTOTUNE and not capturing:
+                cfg, _ = _autotune_b(lib, p, pc, cands, None, None)  # (times into a scratch ``out``: in-place gates are safe)
+                TUNE_DB[sig] = cfg
+            else:
+                cfg = cands[0]
+        if not capturing or not _AUTOTUNE:
+            pc.tuned[key] = cfg
+    _set_cfg(p, pc, cfg)
+    _abi.check(_launch_conv(lib, p, _stream()), "codd_conv2d (gate %d)" % gate)
+    return out
 
 
 def _cfg_ok(lib, p, c):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CODD_ABI_VERSION 6
+#define CODD_ABI_VERSION 7
 
 #define CODD_OK 0
 #define CODD_EINVAL (-1)
@@ -114,6 +114,24 @@ typedef struct {
    * that take alternate k-steps of every chunk and add their partial sums through LDS before the epilogue (two
    * independent MFMA streams per SIMD: one wave's LDS / barrier stalls are filled by the other) */
   int ksplit;
+  /* layout 2: TWO tap sets over one input tile (the ConvGRU's conv*1 + conv*2 pairs, blocks/gru.py:12-33: a 3x3 and a
+   * dilated 3x3 convolution of the same tensor whose results are only ever used summed).  dil2 > 0: kh = 2 * kh0 weight
+   * rows; rows [0, kh0) are the taps of a kh0 x kw convolution with dilation dil2 (both axes), rows [kh0, kh) those of
+   * one with dilation (dil_y, dil_x) >= dil2; both are centred on the same pixel and (pad_t, pad_l) belongs to the
+   * larger one.  One launch, one read of the input tile, one accumulator.  0: plain convolution. */
+  int dil2;
+  /* layout 2: ConvGRU gate epilogues on channel-quad fp32 tensors ("c4": [B][C/4][H*W][4], private to the update
+   * block).  Views name c4 tensors here (ctot = their channel count, coff a multiple of 4); `act` is ignored.
+   *   0  none
+   *   1  out_c4[co] = acc + bias                                                      (no xso)
+   *   2  Cout = 3G:  s = acc + bias + res1_c4[co]
+   *        co in [0, G):   out_c4[co]     = sigmoid(s + res2_c4[co])                                 (z)
+   *        co in [G, 2G):  xso[co - G]    = sigmoid(s + res2_c4[co]) * post_c4[co - G]   (records)   (r * h)
+   *        co in [2G, 3G): out_c4[co - G] = s                                                        (q's input stream)
+   *   3  Cout = G:   q = tanh(acc + bias + res1_c4[G + co]),  z = res1_c4[co],  h = post_c4[co]:
+   *        h' = (1 - z) h + z q  ->  out_c4[co] (may be the post tensor: in place) and xso[co] (records)
+   * (reference blocks/gru.py:17-34 with the gate inputs summed by the producer, raft3d.py:92-106). */
+  int gate;
 } codd_conv_params;
 
 int codd_conv2d(const codd_conv_params* p, void* stream);

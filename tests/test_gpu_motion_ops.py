@@ -901,3 +901,101 @@ def test_fused_forget_branch_equals_cues_plus_head_convolutions(patch):
     got = ops.fusion_forget(pc, pw, flow, conf, fus.forget_matrix(), patch=patch).cpu()
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() < 2e-5, (got - ref).abs().max().item()
+
+
+def _records_of(st):
+    """SplitTensor -> fp32 NCHW of its image interior (hi + lo planes)."""
+    planes = 2 if st.terms == 3 else 1
+    rec = st.buf.view(torch.bfloat16).view(st.B, planes, st.c8, st.hp, st.wp, 8).float().sum(1)
+    img = rec[:, :, st.bt:st.bt + st.H, st.bl:st.bl + st.W]            # [B, c8, H, W, 8]
+    return img.permute(0, 1, 4, 2, 3).reshape(st.B, st.c8 * 8, st.H, st.W)[:, :st.C]
+
+
+@pytest.mark.parametrize("hw", [(23, 37), (72, 120)])
+def test_gate_epilogue_convolutions_against_torch(hw):
+    """codd_conv_params.gate / dil2 (ops.conv_gate): the dual-tap-set z|r convolution into a channel-quad tensor, the
+    merged gate-input 1x1 convolution ending in the z / r*h / q-input epilogue, and the dual-tap-set q convolution
+    ending in the state update -- against torch fp32 convolutions + the ConvGRU formulas (blocks/gru.py:17-34)."""
+    from codd_amd import ops
+    from codd_amd.motion import packed_dual
+    B, (h, w) = 1, hw
+    net = torch.tanh(rnd(B, 128, h, w, seed=1))
+    ctx = torch.relu(rnd(B, 384, h, w, seed=2))
+    enc = torch.relu(rnd(B, 384, h, w, seed=3))
+    mk = lambda cout, cin, k, s: (rnd(cout, cin, k, k, seed=s) / (cin * k * k) ** 0.5, rnd(cout, seed=s + 50) * 0.1)
+    (wz1, bz1), (wz2, bz2), (wr1, br1), (wr2, br2) = mk(128, 128, 3, 11), mk(128, 128, 3, 12), mk(128, 128, 3, 13), mk(128, 128, 3, 14)
+    (wq1, bq1), (wq2, bq2), (wm, bm) = mk(128, 128, 3, 15), mk(128, 128, 3, 16), mk(384, 384, 1, 17)
+    conv = lambda x, wt, b, d: F.conv2d(x, wt, b, padding=d, dilation=d)
+    t12_ref = torch.cat([conv(net, wz1, bz1, 1) + conv(net, wz2, bz2, 4), conv(net, wr1, br1, 1) + conv(net, wr2, br2, 4)], 1)
+    s = F.conv2d(enc, wm, bm) + ctx
+    z_ref = torch.sigmoid(s[:, :128] + t12_ref[:, :128])
+    rh_ref = torch.sigmoid(s[:, 128:256] + t12_ref[:, 128:]) * net
+    q_ref = torch.tanh(conv(rh_ref, wq1, bq1, 1) + conv(rh_ref, wq2, bq2, 4) + s[:, 256:])
+    h_ref = (1 - z_ref) * net + z_ref * q_ref
+
+    class M:  # stand-ins for nn.Conv2d as packed_dual reads them
+        def __init__(self, wt, b):
+            self.weight, self.bias = wt.to(DEV), b.to(DEV)
+    key = ("gate_test", h, w)
+    ns = ops.split_input(net.to(DEV), border=4)
+    es = ops.split_input(enc.to(DEV), border=0)
+    assert ns is not None and es is not None, "needs the split / bf16 conv precision (the default)"
+    t12 = ops.c4_buffer((key, "t12"), B, 256, h, w, DEV)
+    ops.conv_gate(packed_dual(((M(wz1, bz1), M(wz2, bz2)), (M(wr1, br1), M(wr2, br2)))), ns, 1, pad=4, dil=4, dil2=1, out=t12)
+    assert rel(t12.nchw().cpu(), t12_ref) < 2e-5
+    ctx4 = ops.to_c4(ctx.to(DEV), ops.c4_buffer((key, "ctx"), B, 384, h, w, DEV))
+    h4 = ops.to_c4(net.to(DEV), ops.c4_buffer((key, "h4"), B, 128, h, w, DEV))
+    assert torch.equal(h4.nchw().cpu(), net)
+    zq = ops.c4_buffer((key, "zq"), B, 256, h, w, DEV)
+    rs = ops.split_buffer((key, "rh"), B, 128, h, w, 4, DEV)
+    hb = ops.split_buffer((key, "net"), B, 128, h, w, 4, DEV)
+    pm = ops.PackedConv(wm.to(DEV), bm.to(DEV))
+    ops.conv_gate(pm, es, 2, out=zq, res1=ctx4, res2=t12, post=h4, xs_out=rs)
+    got = zq.nchw().cpu()
+    assert rel(got[:, :128], z_ref) < 2e-5 and rel(got[:, 128:], s[:, 256:]) < 2e-5
+    assert rel(_records_of(rs).cpu(), rh_ref) < 2e-5
+    ops.conv_gate(packed_dual(((M(wq1, bq1), M(wq2, bq2)),)), rs, 3, pad=4, dil=4, dil2=1, out=h4, res1=zq, post=h4, xs_out=hb)
+    assert rel(h4.nchw().cpu(), h_ref) < 5e-5
+    assert rel(_records_of(hb).cpu(), h_ref) < 5e-5
+    # the borders of the persistent record tensors stay zero
+    full = hb.buf.view(torch.bfloat16).view(B, -1, hb.c8, hb.hp, hb.wp, 8).float()
+    assert full[:, :, :, :hb.bt].abs().max().item() == 0 and full[:, :, :, :, :hb.bl].abs().max().item() == 0
+
+
+def test_update_block_with_fused_gates_equals_gate_kernels():
+    """BasicUpdateBlock.run with the gates as convolution epilogues (CODD_FUSE_GATES) against the same block with the
+    separate gate kernels and conv*1 / conv*2 launches: three chained updates, hidden state and head outputs."""
+    from codd_amd import motion, ops
+    B, h, w = 1, 24, 40
+    torch.manual_seed(3)
+    outs = {}
+    for fused in (False, True):
+        prev = motion.FUSE_GATES
+        motion.FUSE_GATES = fused
+        try:
+            ub = motion.BasicUpdateBlock().to(DEV).eval()
+            g = torch.Generator().manual_seed(5)
+            with torch.no_grad():
+                for p_ in ub.parameters():
+                    p_.copy_((torch.randn(p_.shape, generator=g) * (0.5 / max(1, p_[0].numel()) ** 0.5)).to(DEV))
+            net = torch.tanh(rnd(B, 128, h, w, seed=1)).to(DEV)
+            inp = torch.relu(rnd(B, 384, h, w, seed=2)).to(DEV)
+            cxs, mxs = ub.input_buffers(net)
+            assert cxs is not None
+            zr, res = None, []
+            for it in range(3):
+                corr, minfo = rnd(B, 196, h, w, seed=10 + it).to(DEV), rnd(B, 9, h, w, seed=20 + it).to(DEV)
+                ops.split_input(corr, border=1, out=cxs)
+                ops.split_input(minfo, border=3, out=mxs)
+                net, mask, ae, delta, weight, zr, hid = ub.run(net, inp, None, None, need_mask=it == 2, zr=zr,
+                                                               prefetch_next=it < 2, fuse_heads=True)
+                torch.cuda.synchronize()
+                res.append((_records_of(ub._xs[1]).cpu(), _records_of(hid).cpu(), None if mask is None else mask.cpu()))
+            outs[fused] = res
+        finally:
+            motion.FUSE_GATES = prev
+    for it, (a, b) in enumerate(zip(outs[False], outs[True])):
+        assert rel(b[0], a[0]) < 1e-4, it       # hidden state
+        assert rel(b[1], a[1]) < 1e-4, it       # head hidden channels
+        if a[2] is not None:
+            assert rel(b[2], a[2]) < 1e-4

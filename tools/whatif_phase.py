@@ -1,0 +1,80 @@
+"""Dev tool: where the frame's wall time goes -- the frame rate with whole phases REMOVED (cached results are returned
+instead; outputs are wrong on purpose, only the time matters).  python tools/whatif_phase.py"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from codd_amd import configs, ops, synth  # noqa: E402
+from codd_amd.registry import build_estimator  # noqa: E402
+from codd_amd.runtime import FrameRunner  # noqa: E402
+
+H, W = 576, 960
+ops.enable_autotune(True, shipped=True)
+est = build_estimator(configs.codd()).eval()
+synth.load_synthetic_weights(est, 1.4)
+est = est.cuda()
+img, r_img, _ = synth.stereo_sequence(H, W, 6)
+img, r_img = img.cuda(), r_img.cuda()
+metas = synth.default_metas(H, W, img_shape=(540, 960, 3))
+
+
+def fps(tag, n=100):
+    est.invalidate_packed() if False else None
+    est.__dict__.pop("_runners", None)
+    r = FrameRunner(est, metas[0], use_graph=True)
+    for i in range(30):
+        r.step(img[:, i % 6].contiguous(), r_img[:, i % 6].contiguous())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        r.step(img[:, i % 6].contiguous(), r_img[:, i % 6].contiguous())
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n * 1e3
+    print(f"{tag:64s} {dt:7.3f} ms/frame  {1e3 / dt:6.1f} frames/s", flush=True)
+
+
+fps("baseline")
+r3 = est.motion.raft3d
+cache = {}
+
+
+def cached(name, fn):
+    def w(*a, **k):
+        if name not in cache:
+            cache[name] = fn(*a, **k)
+        return cache[name]
+    return w
+
+
+orig_ctx, orig_fnet = r3.context, r3.fnet.forward
+r3.context = cached("ctx", orig_ctx)
+fps("without the context network (HRNet)")
+r3.fnet.forward = cached("fnet", orig_fnet)
+fps("without context network + feature encoder")
+orig_ap = ops.allpairs_corr
+ops.allpairs_corr = cached("ap", orig_ap)
+fps("without context network + feature encoder + all-pairs")
+r3.context, r3.fnet.forward, ops.allpairs_corr = orig_ctx, orig_fnet, orig_ap
+cache.clear()
+
+orig_iters = est.motion.iters
+for it in (8, 4):
+    est.motion.iters = it
+    fps(f"update iterations {orig_iters} -> {it}")
+est.motion.iters = orig_iters
+
+orig_sm = est.stereo.stereo_matching
+est.stereo.stereo_matching = cached("stereo", orig_sm)
+fps("without the stereo network (cached outputs)")
+r3.context = cached("ctx", orig_ctx)
+fps("without stereo network + context network")
+est.stereo.stereo_matching, r3.context = orig_sm, orig_ctx
+cache.clear()
+
+orig_mq = est.fusion.memory_query
+est.fusion.memory_query = cached("mq", orig_mq)
+fps("without fusion.memory_query")
+est.fusion.memory_query = orig_mq
