@@ -1,4 +1,5 @@
 #pragma once
+#include <stdlib.h>
 // Split-bf16 convolution kernel: implicit GEMM on v_mfma_f32_16x16x32_bf16 (16x the rate of the f32-input MFMA).
 //
 // Numerics.  TERMS = 3 ("split-bf16", the fp32-grade path): every fp32 operand x is split into two bf16 numbers
@@ -108,6 +109,11 @@ static inline int convb_geometry(const codd_conv_params* pp, ConvB& k, size_t& l
   // ring of (weights + input) buffers + entry table: three deep when that fits the 160 KiB of a CU, else two
   const size_t per = ((size_t)k.wslots + (size_t)k.ibuf16) * 16, tab = ((size_t)k.nk + 2) * 16;
   k.nring = (k.nchunks >= 3 && 3 * per + tab <= 160 * 1024) ? 3 : 2;
+  {  // dev experiment: a two-deep ring where that lets TWO 8-wave workgroups share a CU
+    static const int ring2 = getenv("CODD_CONVB_RING2") ? atoi(getenv("CODD_CONVB_RING2")) : 0;
+    if (ring2 && k.nring == 3 && (p.pgw * p.cgw * (p.ksplit == 2 ? 2 : 1) + CONVB_NWP) <= 8 && 2 * (2 * per + tab) <= 160 * 1024)
+      k.nring = 2;
+  }
   lds = k.nring * per + tab;
   if (lds > 160 * 1024) return CODD_EUNSUPPORTED;
   if (p.ksplit < 0 || p.ksplit > 2) return CODD_EINVAL;

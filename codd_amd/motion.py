@@ -344,7 +344,9 @@ class BasicUpdateBlock(ops.RuntimeState, nn.Module):
             zr_next = self.zr_convs(net)
         if hs is not None and fuse_heads:
             # the ae / delta / weight 1x1 heads run inside the Gauss-Newton record packing (ops.se3_gn_step_heads)
-            mask = cv(self.mask[2], None, xs=hs, xs_coff=768) if need_mask else None
+            # the mask head's 1x1 convolution is only read after the loop (cvx_upsample): beside the Gauss-Newton step,
+            # joined by the caller (RAFT3D.forward)
+            mask = fk.run(1, lambda: cv(self.mask[2], None, xs=hs, xs_coff=768)) if need_mask else None
             return net, mask, None, None, None, zr_next, hs
         delta = fk.run(0, lambda: cv(self.delta[2], sl(1), xs=hs, xs_coff=256))
         weight = fk.run(1, lambda: cv(self.weight[2], sl(2), act="sigmoid", xs=hs, xs_coff=512))
@@ -484,6 +486,7 @@ class RAFT3D(ops.RuntimeState, nn.Module):
                 weight = ops.se3_gn_step_heads(T, hid, *self.update_block.head_matrix(), xyz, d1, K8, radius=32)
             else:
                 ops.se3_gn_step(T, ae, xyz, delta, weight, d1, K8, radius=32)
+        self.update_block._forks(dev)[0].join()  # the mask head's 1x1 convolution (forked beside the last Gauss-Newton step)
         T_up, outputs["weight"] = ops.cvx_upsample_se3_weight(T, weight.contiguous(), mask)  # one pass over the mask
         outputs["Ts"] = T_up
         # reference raft3d.py:268-270: the induced 2-D flow + inverse-depth change of the up-sampled field

@@ -66,14 +66,6 @@ for it in (8, 4):
     fps(f"update iterations {orig_iters} -> {it}")
 est.motion.iters = orig_iters
 
-orig_sm = est.stereo.stereo_matching
-est.stereo.stereo_matching = cached("stereo", orig_sm)
-fps("without the stereo network (cached outputs)")
-r3.context = cached("ctx", orig_ctx)
-fps("without stereo network + context network")
-est.stereo.stereo_matching, r3.context = orig_sm, orig_ctx
-cache.clear()
-
 orig_mq = est.fusion.memory_query
 est.fusion.memory_query = cached("mq", orig_mq)
 fps("without fusion.memory_query")
