@@ -14,6 +14,10 @@ class View(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("ctot", C.c_int), ("coff", C.c_int)]
 
 
+class HrTerm(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("h", C.c_int), ("w", C.c_int)]
+
+
 class XsView(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("c8", C.c_int), ("hp", C.c_int), ("wp", C.c_int), ("bt", C.c_int),
                 ("bl", C.c_int), ("o8", C.c_int), ("terms", C.c_int)]
@@ -95,6 +99,7 @@ SIGNATURES = {
     "codd_splat_scratch": (_ll, [_i, _i, _i, _f]),
     "codd_resize_bilinear": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p]),
     "codd_add_relu": (_i, [_p, _p, _ll, _i, _p, _p]),
+    "codd_hr_fuse_sum": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "codd_copy_many": (_i, [_p, _p, _p, _i, _p]),
     "codd_gru_gate_zr": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "codd_gru_gate_q": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p]),

@@ -1420,6 +1420,64 @@ extern "C" int codd_resize_bilinear(const float* in, int B, int C, int Hi, int W
   return CODD_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// HRModule fuse layer, the summation part (mmseg HRModule.forward; configs/models/codd.py:44-74): output branch i is
+//   relu( sum_j t_ij ),  t_ij = x_i (j == i) | the strided-conv chain of x_j (j < i, already at the target size) |
+//                               bilinear_up(conv1x1(x_j)) (j > i, align_corners = False)
+// summed in j order.  One launch per output branch instead of one resize / add launch per term.
+// ------------------------------------------------------------------------------------------------
+struct HrTerms {
+  const float* ptr[CODD_HR_MAX_TERMS];
+  int h[CODD_HR_MAX_TERMS], w[CODD_HR_MAX_TERMS];
+  int n;
+};
+__global__ void hr_fuse_sum_kernel(const HrTerms tm, int C, int Ho, int Wo, int relu, float* __restrict__ out,
+                                   long long total) {
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int x = (int)(e % Wo);
+  long long t = e / Wo;
+  const int y = (int)(t % Ho);
+  const long long bc = t / Ho;  // b * C + c
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < CODD_HR_MAX_TERMS; ++k) {
+    if (k >= tm.n) break;
+    const int Hi = tm.h[k], Wi = tm.w[k];
+    const float* p = tm.ptr[k] + (size_t)bc * Hi * Wi;
+    float v;
+    if (Hi == Ho && Wi == Wo) {
+      v = p[(size_t)y * Wo + x];
+    } else {  // as resize_bilinear_kernel, align_corners = False
+      const float sy = fmaxf(((float)Hi / (float)Ho) * ((float)y + 0.5f) - 0.5f, 0.f);
+      const float sx = fmaxf(((float)Wi / (float)Wo) * ((float)x + 0.5f) - 0.5f, 0.f);
+      const int y0 = min((int)sy, Hi - 1), x0 = min((int)sx, Wi - 1);
+      const int y1 = min(y0 + 1, Hi - 1), x1 = min(x0 + 1, Wi - 1);
+      const float ly = sy - (float)y0, lx = sx - (float)x0;
+      v = (1.f - ly) * ((1.f - lx) * p[y0 * Wi + x0] + lx * p[y0 * Wi + x1]) +
+          ly * ((1.f - lx) * p[y1 * Wi + x0] + lx * p[y1 * Wi + x1]);
+    }
+    acc = k == 0 ? v : acc + v;
+  }
+  out[e] = relu ? fmaxf(acc, 0.f) : acc;
+}
+
+extern "C" int codd_hr_fuse_sum(const codd_hr_term* terms, int n, int B, int C, int H, int W, int relu, float* out,
+                                void* stream) {
+  if (!terms || n < 1 || n > CODD_HR_MAX_TERMS || !out || B < 1 || C < 1 || H < 1 || W < 1) return CODD_EINVAL;
+  HrTerms tm;
+  memset(&tm, 0, sizeof(tm));
+  for (int k = 0; k < n; ++k) {
+    if (!terms[k].ptr || terms[k].h < 1 || terms[k].w < 1 || terms[k].h > H || terms[k].w > W) return CODD_EINVAL;
+    tm.ptr[k] = terms[k].ptr; tm.h[k] = terms[k].h; tm.w[k] = terms[k].w;
+  }
+  tm.n = n;
+  const long long total = (long long)B * C * H * W;
+  hr_fuse_sum_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(tm, C, H, W, relu, out, total);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
 __global__ void add_relu_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, int relu,
                                 float* __restrict__ y) {
   long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;

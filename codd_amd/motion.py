@@ -26,6 +26,10 @@ MERGE_ENC_HEADS = os.environ.get("CODD_MERGE_ENC_HEADS", "1") == "1"  # (A/B swi
 FUSE_NORM_RECORDS = os.environ.get("CODD_FUSE_NORM_RECORDS", "1") == "1"  # (A/B switch; see ResidualBlock.run)
 # ConvGRU gates as convolution epilogues + each conv*1 / conv*2 pair as ONE dual-tap-set launch (BasicUpdateBlock.run)
 FUSE_GATES = os.environ.get("CODD_FUSE_GATES", "1") == "1"
+# side streams inside the update block (A/B switches): the flow encoder / mask head beside the correlation encoder, and
+# the next update's z|r convolution beside the Gauss-Newton step
+LOOP_FORK_ENC = os.environ.get("CODD_LOOP_FORK_ENC", "1") == "1"
+LOOP_FORK_ZR = os.environ.get("CODD_LOOP_FORK_ZR", "1") == "1"
 
 def packed_cat(mods):
     """One PackedConv whose output channels are the concatenation of several same-shape convs; cached on the first
@@ -227,6 +231,7 @@ class BasicUpdateBlock(ops.RuntimeState, nn.Module):
     def _forks(self, dev):
         if getattr(self, "_fk", None) is None or self._fk[0].dev != dev:
             self._fk = (ops.Fork(dev, 3), ops.Fork(dev, 2))
+            self._fk[0].inline, self._fk[1].inline = not LOOP_FORK_ENC, not LOOP_FORK_ZR
         return self._fk
 
     def run(self, net, inp, corr, minfo, need_mask, zr=None, prefetch_next=False, fuse_heads=False):

@@ -1346,6 +1346,22 @@ def add_relu(a, b=None, relu=True, out=None):
     return out
 
 
+def hr_fuse_sum(terms, out_hw, relu=True):
+    """relu(sum of ``terms`` in order) at size ``out_hw``; a smaller term is bilinearly up-sampled on the fly
+    (align_corners False) -- the summation of an HRModule fuse layer in ONE launch (codd_hr_fuse_sum)."""
+    lib = _abi.load()
+    B, Cc = terms[0].shape[:2]
+    H, W = out_hw
+    arr = (_abi.HrTerm * len(terms))()
+    for k, t in enumerate(terms):
+        _require_gpu(t)
+        assert t.is_contiguous() and t.dtype == torch.float32 and t.shape[:2] == (B, Cc)
+        arr[k].ptr, arr[k].h, arr[k].w = t.data_ptr(), t.shape[2], t.shape[3]
+    out = torch.empty(B, Cc, H, W, device=terms[0].device, dtype=torch.float32)
+    _abi.check(lib.codd_hr_fuse_sum(arr, len(terms), B, Cc, H, W, int(relu), out.data_ptr(), _stream()), "hr_fuse_sum")
+    return out
+
+
 def copy_many(pairs):
     """dst.copy_(src) for up to 8 (dst, src) pairs of contiguous fp32 tensors in one kernel launch (a kernel node under
     graph capture: see runtime.FrameRunner._capture); pairs that do not meet the 16-byte rules fall back to one
@@ -1430,9 +1446,10 @@ class Fork:
         self.dev = device
         self.streams = [torch.cuda.Stream(device=device) for _ in range(n)]
         self.used = []
+        self.inline = False  # this fork only: run the branches on the caller's stream (A/B switches of call sites)
 
     def run(self, i, fn, *a, **k):
-        if Fork.serial:
+        if Fork.serial or self.inline:
             return fn(*a, **k)
         cur = torch.cuda.current_stream(self.dev)
         s = self.streams[i]

@@ -12,6 +12,8 @@ Differences from the reference's op schedule (results identical up to fp32 round
   * the tile cost volume is never materialised (fused arg-min), TileWarping's three offsets,
     the PixelUnshuffle and the ||fea_l||_1 feature are one kernel, for both hypothesis sets.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -153,8 +155,11 @@ class HITUNet(nn.Module):
 _LEVELS = ("16x", "8x", "4x", "2x", "1x")
 
 
+FORK_INIT_LEVELS = os.environ.get("CODD_FORK_INIT", "0") == "1"  # (A/B switch; TileInitialization.forward)
+
+
 @register
-class TileInitialization(nn.Module):
+class TileInitialization(ops.RuntimeState, nn.Module):
     """reference initialization.py:48-230."""
 
     def __init__(self, max_disp, fea_c=[16, 16, 24, 24, 32]):
@@ -171,8 +176,8 @@ class TileInitialization(nn.Module):
         """-> [None, hyps]: the cost volumes are not materialised at inference (the reference only
         consumes them in the training loss, hitnet.py:84-85).  hyps[l] is a 16-channel Slice at
         the head of the aug-hypothesis buffer TilePropagation consumes (32 ch at 1/16, else 64)."""
-        hyps = []
-        for lvl, name in enumerate(_LEVELS):
+        def level(lvl):
+            name = _LEVELS[lvl]
             fl, fr = fea_l[lvl], fea_r[lvl]
             tc = getattr(self, f"tile_conv{name}")
             pc0, pc1 = packed(tc[0]), packed(tc[2])
@@ -186,7 +191,19 @@ class TileInitialization(nn.Module):
             ops.tile_costvol_argmin(tl, tr, self.maxdisp // (16 >> lvl), cost, Slice(aug, 0, 3))
             feat = tl if lvl < 2 else fea_l[lvl - 2]
             cv(getattr(self, f"tile_fea_dscrpt{name}")[0], cost, x2=feat, act="lrelu", out=Slice(aug, 3, 13))
-            hyps.append(Slice(aug, 0, 16))
+            return Slice(aug, 0, 16)
+
+        # the five scales are independent 6-launch chains (the four coarse ones ~10 us launches that leave the chip
+        # idle): the coarse scales on side streams beside the finest one
+        n = len(_LEVELS)
+        if FORK_INIT_LEVELS and not ops.Fork.serial:
+            fk = self.__dict__.get("_fk")
+            if fk is None or fk.dev != fea_l[0].device:
+                fk = self.__dict__["_fk"] = ops.Fork(fea_l[0].device, n - 1)
+            hyps = [fk.run(lvl, level, lvl) for lvl in range(n - 1)] + [level(n - 1)]
+            fk.join()
+        else:
+            hyps = [level(lvl) for lvl in range(n)]
         return [None, hyps]
 
 

@@ -371,6 +371,15 @@ int codd_resize_bilinear(const float* in, int B, int C, int Hi, int Wi, int Ho, 
 
 /* y = relu?(a + b) elementwise (HRNet fuse sums), n floats. */
 int codd_add_relu(const float* a, const float* b, long long n, int relu, float* y, void* stream);
+/* HRModule fuse layer, summation (mmseg HRModule.forward as built by configs/models/codd.py:44-74):
+ * out[B,C,H,W] = relu?( sum_k term_k ) in index order; a term [B,C,h,w] smaller than (H, W) is bilinearly up-sampled
+ * (align_corners = False) on the fly -- one launch per output branch instead of one resize / add launch per term. */
+#define CODD_HR_MAX_TERMS 4
+typedef struct {
+  const float* ptr;
+  int h, w;
+} codd_hr_term;
+int codd_hr_fuse_sum(const codd_hr_term* terms, int n, int B, int C, int H, int W, int relu, float* out, void* stream);
 
 /* dst[k][0..n[k]) = src[k][0..n[k]) for k < count <= 8 in ONE launch (the recurrent-state write-back at the end of a
  * captured frame); every n[k] a multiple of 4, every pointer 16-byte aligned. */

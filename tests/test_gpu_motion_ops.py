@@ -999,3 +999,45 @@ def test_update_block_with_fused_gates_equals_gate_kernels():
         assert rel(b[1], a[1]) < 1e-4, it       # head hidden channels
         if a[2] is not None:
             assert rel(b[2], a[2]) < 1e-4
+
+
+def test_hr_fuse_sum_against_torch():
+    """codd_hr_fuse_sum: relu(x_i + same-size terms + bilinearly up-sampled smaller terms), summed in order."""
+    from codd_amd import ops
+    B, Cc, H, W = 2, 18, 36, 60
+    a, b = rnd(B, Cc, H, W, seed=1), rnd(B, Cc, H, W, seed=2)
+    c, d = rnd(B, Cc, H // 2, W // 2, seed=3), rnd(B, Cc, 9, 15, seed=4)
+    up = lambda t: F.interpolate(t, size=(H, W), mode="bilinear", align_corners=False)
+    ref = F.relu(((a + up(c)) + b) + up(d))
+    got = ops.hr_fuse_sum([t.to(DEV) for t in (a, c, b, d)], (H, W), relu=True).cpu()
+    assert (got - ref).abs().max().item() < 1e-5
+    ref2 = a + up(d)
+    got2 = ops.hr_fuse_sum([a.to(DEV), d.to(DEV)], (H, W), relu=False).cpu()
+    assert (got2 - ref2).abs().max().item() < 1e-5
+
+
+def test_hrmodule_fused_sum_equals_per_term_launches():
+    """HRModule.run with the fuse layers as multi-job convolutions + one summation launch per branch against the
+    per-term resize / add launches (CODD_HR_FUSE_SUM=0), 4 branches incl. the odd-width 1/32 map."""
+    from codd_amd import hrnet, ops
+    torch.manual_seed(7)
+    mod = hrnet.HRModule((18, 36, 72, 144), 1).to(DEV).eval()
+    with torch.no_grad():
+        for m in mod.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.1)
+    xs = [torch.relu(rnd(1, c, 144 >> k, 240 >> k, seed=k)).to(DEV) for k, c in enumerate((18, 36, 72, 144))]
+    outs = {}
+    prev = ops.set_conv_precision("fp32")
+    try:
+        for fused in (False, True):
+            keep = hrnet.FUSE_SUM
+            hrnet.FUSE_SUM = fused
+            try:
+                outs[fused] = [o.cpu() for o in mod.run(xs)]
+            finally:
+                hrnet.FUSE_SUM = keep
+    finally:
+        ops.set_conv_precision(prev)
+    for a, b in zip(outs[False], outs[True]):
+        assert a.shape == b.shape and (a - b).abs().max().item() < 1e-4 * max(1.0, a.abs().max().item())
