@@ -26,6 +26,11 @@ MERGE_ENC_HEADS = os.environ.get("CODD_MERGE_ENC_HEADS", "1") == "1"  # (A/B swi
 FUSE_NORM_RECORDS = os.environ.get("CODD_FUSE_NORM_RECORDS", "1") == "1"  # (A/B switch; see ResidualBlock.run)
 # ConvGRU gates as convolution epilogues + each conv*1 / conv*2 pair as ONE dual-tap-set launch (BasicUpdateBlock.run)
 FUSE_GATES = os.environ.get("CODD_FUSE_GATES", "1") == "1"
+# the feature encoder runs on a side stream beside the stereo network: small-footprint launch configurations (A/B)
+FNET_CORESIDENT = os.environ.get("CODD_FNET_CORESIDENT", "0") == "1"
+# the flow encoder's 7x7 convolution beside the correlation encoder's first 3x3: 1 = small-footprint configurations for
+# the former, 2 = for both (A/B)
+ENC_CORESIDENT = int(os.environ.get("CODD_ENC_CORESIDENT", "0"))
 # side streams inside the update block (A/B switches): the flow encoder / mask head beside the correlation encoder, and
 # the next update's z|r convolution beside the Gauss-Newton step
 LOOP_FORK_ENC = os.environ.get("CODD_LOOP_FORK_ENC", "1") == "1"
@@ -122,6 +127,10 @@ class BasicEncoder(nn.Module):
         self.conv2 = nn.Conv2d(128, output_dim, 1)
 
     def forward(self, x):
+        with ops.coresident(FNET_CORESIDENT):
+            return self._forward(x)
+
+    def _forward(self, x):
         t = cv(self.conv1, x)
         B, C, H, W = t.shape
         xs = ops.split_buffer((id(self), "stem"), B, C, H, W, 1, x.device) if FUSE_NORM_RECORDS else None
@@ -285,8 +294,12 @@ class BasicUpdateBlock(ops.RuntimeState, nn.Module):
             # tensor [corr_enc[2] out 256 | flow_enc[0] out 128] and ONE 1x1 convolution with the input-concatenated
             # weights (+ res1 = inp) produces inp + cor + mot -- one launch and two 13 MB tensors less per update,
             # and the gate kernels read one stream instead of three
-            fk.run(2, lambda: cv(self.flow_enc[0], minfo, act="relu", xs=min_, xs_out=enc, xs_out_coff=256))
-            cv(self.corr_enc[0], corr, act="relu", xs=cin, xs_out=sb("corr_enc0", 256, 1))
+            def flow7():
+                with ops.coresident(ENC_CORESIDENT in (1, 2)):
+                    cv(self.flow_enc[0], minfo, act="relu", xs=min_, xs_out=enc, xs_out_coff=256)
+            fk.run(2, flow7)
+            with ops.coresident(ENC_CORESIDENT == 2):
+                cv(self.corr_enc[0], corr, act="relu", xs=cin, xs_out=sb("corr_enc0", 256, 1))
             cv(self.corr_enc[2], None, act="relu", xs=sb("corr_enc0", 256, 1), xs_out=enc, xs_out_coff=0)
             fk.join()
             if self._fused_now:
