@@ -30,7 +30,7 @@ FUSE_GATES = os.environ.get("CODD_FUSE_GATES", "1") == "1"
 FNET_CORESIDENT = os.environ.get("CODD_FNET_CORESIDENT", "0") == "1"
 # the flow encoder's 7x7 convolution beside the correlation encoder's first 3x3: 1 = small-footprint configurations for
 # the former, 2 = for both (A/B)
-ENC_CORESIDENT = int(os.environ.get("CODD_ENC_CORESIDENT", "0"))
+ENC_CORESIDENT = int(os.environ.get("CODD_ENC_CORESIDENT", "1"))
 # side streams inside the update block (A/B switches): the flow encoder / mask head beside the correlation encoder, and
 # the next update's z|r convolution beside the Gauss-Newton step
 LOOP_FORK_ENC = os.environ.get("CODD_LOOP_FORK_ENC", "1") == "1"
