@@ -1,6 +1,7 @@
 // HITNetMF non-convolution kernels: tile cost volume + arg-min, slanted-plane local correlation,
 // hypothesis plane up-sampling and selection.  All HBM/LDS-bound fp32 work (no MFMA).
 #include "common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------
 // Tile cost volume + first arg-min (reference initialization.py:18-45,167-183), never materialised.
@@ -61,16 +62,122 @@ __global__ __launch_bounds__(256) void costvol_argmin_kernel(const float* __rest
   }
 }
 
+// D % 4 == 0 (every level of the benchmarked configurations): a lane owns FOUR consecutive disparities, so the right
+// window is read as aligned 16-byte LDS vectors (4 values per ds_read_b128 instead of 1 per ds_read_b32) and a wave
+// keeps the left features of its 4 consecutive tiles in one vector -- the scalar form issues 2 LDS reads per
+// |l - r| term and is LDS-issue bound (68 us at the finest level).  Same arithmetic per (tile, d): the channel sum is
+// sequential, the first minimum wins.
+template <int TPB>
+__global__ __launch_bounds__(256) void costvol_argmin4_kernel(const float* __restrict__ L, const float* __restrict__ R,
+                                                              int C, int Ht, int Wt, int Wr, int D, float* cost,
+                                                              int cost_ctot, int cost_coff, float* disp, int disp_ctot,
+                                                              int disp_coff, int zero_dxdy) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int xt0 = blockIdx.x * TPB, y = blockIdx.y, b = blockIdx.z;
+  const int win = D + 4 * (TPB - 1);  // window length per channel (multiple of 4)
+  const int base = 4 * xt0 - (D - 1); // image x of window element 0
+  float* rl = sm;                     // [C][win]
+  float* ll = sm + C * win;           // [C][TPB]
+  // TPB tiles share one staged window: D + 4 (TPB - 1) columns for 4 TPB new ones -- 16 tiles re-read every right
+  // feature 6x at the finest level (D = 320), 64 tiles 2.2x
+  const float* Rb = R + ((size_t)b * C * Ht + y) * Wr;
+  for (int c = wave; c < C; c += 4) {
+    const float* rc = Rb + (size_t)c * Ht * Wr;
+    for (int i = lane; i < win; i += 64) {
+      const int gx = base + i;
+      rl[c * win + i] = (gx >= 0 && gx < Wr) ? rc[gx] : 0.f;
+    }
+  }
+  const float* Lb = L + ((size_t)b * C * Ht + y) * Wt;
+  for (int e = tid; e < C * TPB; e += 256) {
+    const int c = e / TPB, i = e - c * TPB, gx = xt0 + i;
+    ll[e] = gx < Wt ? Lb[(size_t)c * Ht * Wt + gx] : 0.f;
+  }
+  __syncthreads();
+  for (int t0 = 4 * wave; t0 < TPB && xt0 + t0 < Wt; t0 += 16) {  // this wave's tiles: t0 .. t0 + 3
+    float best[4];
+    int bi[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { best[q] = INFINITY; bi[q] = 0x7fffffff; }
+    for (int d0 = 4 * lane; d0 < D; d0 += 256) {
+      float s[4][4];  // [tile][k]: disparity d0 + k
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[q][k] = 0.f;
+      // window index of R~[4*xt - d] = 4*t + (D-1) - d; d = d0 + 3 .. d0 sit at 4*t + D - 4 - d0 .. + 3 (aligned)
+      const int o = 4 * t0 + D - 4 - d0;
+      for (int c = 0; c < C; ++c) {
+        const float4 l4 = *(const float4*)(ll + c * TPB + t0);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 r4 = *(const float4*)(rl + c * win + o + 4 * q);
+          s[q][3] += fabsf(lv[q] - r4.x);
+          s[q][2] += fabsf(lv[q] - r4.y);
+          s[q][1] += fabsf(lv[q] - r4.z);
+          s[q][0] += fabsf(lv[q] - r4.w);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (s[q][k] < best[q]) { best[q] = s[q][k]; bi[q] = d0 + k; }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float bb = best[q];
+      int ii = bi[q];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(bb, off, 64);
+        const int oi = __shfl_xor(ii, off, 64);
+        if (ob < bb || (ob == bb && oi < ii)) { bb = ob; ii = oi; }
+      }
+      const int xt = xt0 + t0 + q;
+      if (lane == 0 && xt < Wt) {
+        const size_t hw = (size_t)Ht * Wt, pix = (size_t)y * Wt + xt;
+        cost[((size_t)b * cost_ctot + cost_coff) * hw + pix] = bb;
+        float* dp = disp + ((size_t)b * disp_ctot + disp_coff) * hw + pix;
+        dp[0] = (float)ii;
+        if (zero_dxdy) { dp[hw] = 0.f; dp[2 * hw] = 0.f; }
+      }
+    }
+  }
+}
+
 extern "C" int codd_tile_costvol_argmin(const float* L, const float* R, int B, int C, int Ht, int Wt, int Wr, int D,
                                         float* cost, int cost_ctot, int cost_coff, float* disp, int disp_ctot,
                                         int disp_coff, int zero_dxdy, void* stream) {
   if (!L || !R || !cost || !disp || B < 1 || C < 1 || D < 1 || Ht < 1 || Wt < 1) return CODD_EINVAL;
+  static const int dev_tpb = getenv("CODD_COSTVOL_TPB") ? atoi(getenv("CODD_COSTVOL_TPB")) : 0;  // dev A/B: 1 = scalar form
+  hipStream_t st = (hipStream_t)stream;
+  if ((D & 3) == 0 && dev_tpb != 1) {
+    // tiles per workgroup: 16.  More tiles share more of the staged window (64 tiles re-read a right feature 2.2x
+    // instead of 6x at D = 320) but measured SLOWER at the finest level -- 40.5 (16) / 43.8 (32) / 55.2 us (64): the
+    // kernel is a stage-then-scan latency chain per workgroup, and more, smaller workgroups overlap it better
+    int tpb = (dev_tpb == 16 || dev_tpb == 32 || dev_tpb == 64) ? dev_tpb : 16;
+    for (;; tpb >>= 1) {
+      const int win = D + 4 * (tpb - 1);
+      const size_t lds = (size_t)(C * win + C * tpb) * sizeof(float);
+      if (lds > 64 * 1024) { if (tpb == 16) return CODD_EUNSUPPORTED; continue; }
+      dim3 grid(cdiv(Wt, tpb), Ht, B);
+#define CV_LAUNCH(T) costvol_argmin4_kernel<T><<<grid, 256, lds, st>>>(L, R, C, Ht, Wt, Wr, D, cost, cost_ctot, cost_coff, disp, disp_ctot, disp_coff, zero_dxdy)
+      if (tpb == 64) CV_LAUNCH(64); else if (tpb == 32) CV_LAUNCH(32); else CV_LAUNCH(16);
+#undef CV_LAUNCH
+      break;
+    }
+    CODD_LAUNCH_CHECK();
+    return CODD_OK;
+  }
   const int win = D + 4 * (CV_TPB - 1);
   size_t lds = (size_t)(C * win + C * CV_TPB) * sizeof(float);
   if (lds > 64 * 1024) return CODD_EUNSUPPORTED;
   dim3 grid(cdiv(Wt, CV_TPB), Ht, B);
-  costvol_argmin_kernel<<<grid, 256, lds, (hipStream_t)stream>>>(L, R, C, Ht, Wt, Wr, D, cost, cost_ctot, cost_coff,
-                                                                 disp, disp_ctot, disp_coff, zero_dxdy);
+  costvol_argmin_kernel<<<grid, 256, lds, st>>>(L, R, C, Ht, Wt, Wr, D, cost, cost_ctot, cost_coff,
+                                                disp, disp_ctot, disp_coff, zero_dxdy);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }
