@@ -255,6 +255,11 @@ static int conv_fill(const codd_conv_params* pp, ConvK& k, size_t& lds, long lon
   if (lds > 160 * 1024) return CODD_EUNSUPPORTED;
   grid = (long long)k.tiles_x * k.tiles_y * k.ncog * p.B;
   if (grid <= 0 || grid > 0x7fffffffLL) return CODD_EINVAL;
+  // XCD-contiguous tile walk for launches of several rounds (the large HITNet maps): dev switch CODD_CONV_XCD=0|1,
+  // minimum grid CODD_CONV_XCD_MIN
+  static const int xcd_on = getenv("CODD_CONV_XCD") ? atoi(getenv("CODD_CONV_XCD")) : 1;
+  static const int xcd_min = getenv("CODD_CONV_XCD_MIN") ? atoi(getenv("CODD_CONV_XCD_MIN")) : 1;
+  k.xcd = xcd_on && grid >= xcd_min;
   return CODD_OK;
 }
 

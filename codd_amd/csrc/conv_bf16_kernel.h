@@ -55,6 +55,8 @@ struct ConvB {
   int wslots;                     // slots of one (channel group, chunk) weight image = planes * wplane16
   int tiles_x, tiles_y, ncog, cout_eff;
   int khe;                        // tap rows of one tap set (kh, or kh / 2 with a dual tap set)
+  int xcd;                        // 1: XCD-contiguous work-item walk (workgroup b, placed on XCD b % 8, takes a
+                                  // contiguous range of tiles of one channel group: conv_kernel.h conv_xcd_item)
 };
 
 constexpr int CONVB_NWP = 4;  // producer waves per workgroup
@@ -153,6 +155,11 @@ static inline int convb_geometry(const codd_conv_params* pp, ConvB& k, size_t& l
   }
   grid = (long long)k.tiles_x * k.tiles_y * k.ncog * p.B;
   if (grid <= 0 || grid > 0x7fffffffLL) return CODD_EINVAL;
+  {  // dev switch CODD_CONVB_XCD=0|1 (minimum grid CODD_CONVB_XCD_MIN)
+    static const int xcd_on = getenv("CODD_CONVB_XCD") ? atoi(getenv("CODD_CONVB_XCD")) : 0;
+    static const int xcd_min = getenv("CODD_CONVB_XCD_MIN") ? atoi(getenv("CODD_CONVB_XCD_MIN")) : 16;
+    k.xcd = xcd_on && grid >= xcd_min;
+  }
   return CODD_OK;
 }
 
@@ -230,12 +237,10 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   int bid = blockIdx.x;
-#ifdef CONVB_XCD
-  {  // dev experiment: consecutive work items on ONE XCD (workgroup b runs on XCD b % 8)
+  if (k.xcd) {  // consecutive work items on ONE XCD (workgroup b runs on XCD b % 8)
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-#endif
 #ifdef CONVB_COG_FAST
   const int cog = bid % k.ncog; bid /= k.ncog;
   const int tx = bid % k.tiles_x; bid /= k.tiles_x;

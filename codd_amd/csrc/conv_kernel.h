@@ -33,7 +33,16 @@ struct ConvK {
   int upc;     // float4 units per channel = thi * twp4
   int nunits;  // ck * upc
   int vec_ok;  // 16-byte global loads allowed (Win % 4 == 0 and 16-byte aligned bases)
+  int xcd;     // 1: workgroup b (which the dispatcher places on XCD b % 8) takes work item conv_xcd_item(b): every XCD
+               // walks ONE contiguous range of tiles, so the halo rows neighbouring tiles share are re-read from that
+               // XCD's own L2 instead of being fetched by up to 8 L2s
 };
+
+// work item of workgroup ``bid`` under the XCD-contiguous mapping: XCD x = bid % 8 owns items [start_x, start_x + n_x)
+__device__ __forceinline__ int conv_xcd_item(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7, idx = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+}
 
 __device__ __forceinline__ const float* view_ptr(const codd_view& v, int b, int c, int hw) {
   return v.ptr + ((size_t)b * v.ctot + v.coff + c) * (size_t)hw;
@@ -56,7 +65,7 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(const ConvK k) {
   constexpr int XB = NPB >= 2 ? 2 : 1;  // 16-pixel blocks along x in the tile
   constexpr int RPW = NPB / XB;         // tile rows per wave
 
-  int bid = blockIdx.x;
+  int bid = k.xcd ? conv_xcd_item(blockIdx.x, gridDim.x) : blockIdx.x;
   const int tx = bid % k.tiles_x; bid /= k.tiles_x;
   const int ty = bid % k.tiles_y; bid /= k.tiles_y;
   const int cog = bid % k.ncog;

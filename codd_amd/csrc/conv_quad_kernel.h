@@ -183,7 +183,7 @@ __device__ __forceinline__ void conv_quad_body(const ConvK& k, int bid, float* s
 template <int NW, int NPB, int MB, int WREG, int QREG>
 __global__ __launch_bounds__(NW * 64) void conv_quad_kernel(const ConvK k) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  conv_quad_body<NW, NPB, MB, WREG, QREG>(k, blockIdx.x, smem);
+  conv_quad_body<NW, NPB, MB, WREG, QREG>(k, k.xcd ? conv_xcd_item(blockIdx.x, gridDim.x) : blockIdx.x, smem);
 }
 
 // Several INDEPENDENT convolutions (different tensors, shapes and channel counts; same tile / register class) as one
