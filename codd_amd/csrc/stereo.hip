@@ -189,15 +189,30 @@ extern "C" int codd_tile_costvol_argmin(const float* L, const float* R, int B, i
 // right row serve all three.  Lanes are consecutive tiles -> the 64 output channels are written
 // fully coalesced; the left row is read as float4.
 // ------------------------------------------------------------------------------------------------
+// STAGE: the workgroup first copies the right feature row (C x W floats, coalesced 16-byte loads) into LDS and gathers
+// from there: the 16 taps per channel and hypothesis set are 4-byte gathers 16 bytes apart between neighbouring lanes,
+// i.e. a quarter of every fetched line is used and the texture addresser sees 32 scattered loads per channel; from
+// LDS they cost a ds_read each.  A workgroup covers (up to) a whole tile row, so the row is read once.
+template <bool STAGE>
 __global__ __launch_bounds__(256) void tile_warp_kernel(const float* __restrict__ fl, const float* __restrict__ fr,
                                                         int C, int Ht, int Wt, codd_view h0, codd_view h1, int nhyp,
                                                         float* out0, float* out1) {
-  const int tx = blockIdx.x * blockDim.x + threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float srow[];  // STAGE: [C][W]
+  const int txr = blockIdx.x * blockDim.x + threadIdx.x;
   const int yy = blockIdx.y;  // feature row
   const int b = blockIdx.z;
-  if (tx >= Wt) return;
+  if (!STAGE && txr >= Wt) return;
+  const bool live = txr < Wt;
+  const int tx = live ? txr : Wt - 1;
   const int ty = yy >> 2, iy = yy & 3;
   const int H = 4 * Ht, W = 4 * Wt;
+  if (STAGE) {
+    const float4* src = (const float4*)(fr + (size_t)b * C * H * W + (size_t)yy * W);
+    const int w4 = W >> 2, chw4 = (H * W) >> 2;
+    for (int c = 0; c < C; ++c)
+      for (int x4 = threadIdx.x; x4 < w4; x4 += blockDim.x) ((float4*)srow)[c * w4 + x4] = src[(size_t)c * chw4 + x4];
+    __syncthreads();
+  }
   const size_t thw = (size_t)Ht * Wt, tpix = (size_t)ty * Wt + tx;
   const float* flb = fl + (size_t)b * C * H * W + (size_t)yy * W + 4 * tx;
   const float* frb = fr + (size_t)b * C * H * W + (size_t)yy * W;
@@ -243,7 +258,7 @@ __global__ __launch_bounds__(256) void tile_warp_kernel(const float* __restrict_
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int xi = min(max(f0[hsel][ix] - 1 + q, 0), W - 1);
-            t[hsel][ix][q] = rr[xi];
+            t[hsel][ix][q] = STAGE ? srow[c * W + xi] : rr[xi];
           }
       }
     }
@@ -266,6 +281,7 @@ __global__ __launch_bounds__(256) void tile_warp_kernel(const float* __restrict_
       }
     }
   }
+  if (!live) return;
 #pragma unroll
   for (int ix = 0; ix < 4; ++ix) {
     const int ch = iy * 4 + ix;
@@ -284,9 +300,21 @@ extern "C" int codd_tile_warp_cost(const float* fl, const float* fr, int B, int 
                                    codd_view hyp1, int nhyp, float* out0, float* out1, void* stream) {
   if (!fl || !fr || !hyp0.ptr || !out0 || nhyp < 1 || nhyp > 2 || (nhyp == 2 && (!hyp1.ptr || !out1)))
     return CODD_EINVAL;
-  const int bx = Wt >= 64 ? 64 : 64;
+  static const int stage_on = getenv("CODD_TILE_WARP_STAGE") ? atoi(getenv("CODD_TILE_WARP_STAGE")) : 1;  // dev A/B
+  const size_t lds = (size_t)C * 4 * Wt * sizeof(float);
+  if (stage_on && lds <= 96 * 1024 && ((uintptr_t)fr & 15) == 0) {
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)tile_warp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return CODD_EUNSUPPORTED;
+    const int bx = Wt > 128 ? 256 : (Wt > 64 ? 128 : 64);
+    dim3 grid(cdiv(Wt, bx), 4 * Ht, B);
+    tile_warp_kernel<true><<<grid, bx, lds, (hipStream_t)stream>>>(fl, fr, C, Ht, Wt, hyp0, hyp1, nhyp, out0, out1);
+    CODD_LAUNCH_CHECK();
+    return CODD_OK;
+  }
+  const int bx = 64;
   dim3 grid(cdiv(Wt, bx), 4 * Ht, B);
-  tile_warp_kernel<<<grid, bx, 0, (hipStream_t)stream>>>(fl, fr, C, Ht, Wt, hyp0, hyp1, nhyp, out0, out1);
+  tile_warp_kernel<false><<<grid, bx, 0, (hipStream_t)stream>>>(fl, fr, C, Ht, Wt, hyp0, hyp1, nhyp, out0, out1);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }
