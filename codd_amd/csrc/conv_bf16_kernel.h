@@ -158,7 +158,7 @@ static inline int convb_geometry(const codd_conv_params* pp, ConvB& k, size_t& l
   {  // dev switch CODD_CONVB_XCD=0|1 (minimum grid CODD_CONVB_XCD_MIN)
     static const int xcd_on = getenv("CODD_CONVB_XCD") ? atoi(getenv("CODD_CONVB_XCD")) : 0;
     static const int xcd_min = getenv("CODD_CONVB_XCD_MIN") ? atoi(getenv("CODD_CONVB_XCD_MIN")) : 16;
-    k.xcd = xcd_on && grid >= xcd_min;
+    k.xcd = grid >= xcd_min ? xcd_on : 0;  // bit 0: XCD-contiguous walk, bit 1: channel group fastest
   }
   return CODD_OK;
 }
@@ -237,21 +237,22 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   int bid = blockIdx.x;
-  if (k.xcd) {  // consecutive work items on ONE XCD (workgroup b runs on XCD b % 8)
+  if (k.xcd & 1) {  // consecutive work items on ONE XCD (workgroup b runs on XCD b % 8)
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-#ifdef CONVB_COG_FAST
-  const int cog = bid % k.ncog; bid /= k.ncog;
-  const int tx = bid % k.tiles_x; bid /= k.tiles_x;
-  const int ty = bid % k.tiles_y;
-  const int b = bid / k.tiles_y;
-#else
-  const int tx = bid % k.tiles_x; bid /= k.tiles_x;
-  const int ty = bid % k.tiles_y; bid /= k.tiles_y;
-  const int cog = bid % k.ncog;
-  const int b = bid / k.ncog;
-#endif
+  int tx, ty, cog, b;
+  if (k.xcd & 2) {  // channel group fastest: the channel groups of one tile are neighbours (one XCD under the XCD walk)
+    cog = bid % k.ncog; bid /= k.ncog;
+    tx = bid % k.tiles_x; bid /= k.tiles_x;
+    ty = bid % k.tiles_y;
+    b = bid / k.tiles_y;
+  } else {
+    tx = bid % k.tiles_x; bid /= k.tiles_x;
+    ty = bid % k.tiles_y; bid /= k.tiles_y;
+    cog = bid % k.ncog;
+    b = bid / k.ncog;
+  }
 
   if (wave >= NWC) {
     // =============================== producers ===============================
