@@ -15,7 +15,7 @@ class RuntimeState:
     """Mixin of the plug-in modules that keep launch-time objects (side streams, fork helpers, pending prefetches,
     captured frame graphs) in their ``__dict__``: those are neither picklable nor copyable and are rebuilt on demand,
     so they are left out of the module's pickled / deep-copied state."""
-    _RUNTIME_KEYS = ("_side", "_pending", "_nowait", "_fk", "_xs", "_runners", "_kside", "_h4c", "_ctx4c", "_fused_now")
+    _RUNTIME_KEYS = ("_side", "_pending", "_nowait", "_fk", "_xs", "_runners", "_kside", "_h4c", "_ctx4c", "_fused_now", "_pipe")
 
     def __getstate__(self):
         state = self.__dict__.copy()

@@ -113,7 +113,9 @@ class HITUNet(nn.Module):
         self.merge2 = _merge(32, 16)
         self.merge1 = _merge(32, 16)
 
-    def forward(self, x):
+    def stages(self, x):
+        """Generator over the feature pyramid in production order (1/16, 1/8, 1/4, 1/2, 1/1): a consumer may use the
+        coarse scales while the decoder still runs (HITNetMF.stereo_matching, pipelined schedule)."""
         def seq(s, t):
             for m in s:
                 if isinstance(m, nn.Conv2d):
@@ -130,6 +132,12 @@ class HITUNet(nn.Module):
             t = cv(merge[2], t, act="lrelu")
             return cv(merge[4], t, act="lrelu")
 
+        yield from self._stages(x, seq, up_merge)
+
+    def forward(self, x):
+        return list(self.stages(x))
+
+    def _stages(self, x, seq, up_merge):
         x0 = seq(self.conv1, x)
         x1 = seq(self.down1, x0)
         x2 = seq(self.down2, x1)
@@ -144,11 +152,14 @@ class HITUNet(nn.Module):
             x4 = seq(self.down4[0], x3)
             x4 = cv(self.down4[1], x4, act="lrelu")
             x4 = cv(self.down4[3], x4, act="lrelu")
+        yield x4
         u4 = up_merge(self.up4, self.merge4, x3, x4)
+        yield u4
         u3 = up_merge(self.up3, self.merge3, x2, u4)
+        yield u3
         u2 = up_merge(self.up2, self.merge2, x1, u3)
-        u1 = up_merge(self.up1, self.merge1, x0, u2)
-        return [x4, u4, u3, u2, u1]
+        yield u2
+        yield up_merge(self.up1, self.merge1, x0, u2)
 
 
 # ------------------------------------------------------------------------------------- tile init
@@ -156,6 +167,22 @@ _LEVELS = ("16x", "8x", "4x", "2x", "1x")
 
 
 FORK_INIT_LEVELS = os.environ.get("CODD_FORK_INIT", "0") == "1"  # (A/B switch; TileInitialization.forward)
+STEREO_PIPE = os.environ.get("CODD_STEREO_PIPE", "1") == "1"  # (A/B: HITNetMF._stereo_matching_pipelined)
+FORK_INIT_FINE = int(os.environ.get("CODD_FORK_INIT_FINE", "3"))  # (A/B: this many of the finest scales on ONE side stream)
+
+
+class _LazyHyps(list):
+    """The per-scale hypotheses; entries [first_forked, ...) were produced on a side stream that is joined on first use."""
+
+    def __init__(self, items, first_forked, fork):
+        super().__init__(items)
+        self._first, self._fork = first_forked, fork
+
+    def __getitem__(self, i):
+        if self._fork is not None and isinstance(i, int) and i >= self._first:
+            self._fork.join()
+            self._fork = None
+        return super().__getitem__(i)
 
 
 @register
@@ -172,30 +199,43 @@ class TileInitialization(ops.RuntimeState, nn.Module):
         for name, c in zip(_LEVELS, (17, 17, 33, 25, 25)):
             setattr(self, f"tile_fea_dscrpt{name}", nn.Sequential(nn.Conv2d(c, 13, 1), _lrelu()))
 
+    def init_level(self, lvl, fl, fr, feat):
+        """One scale: tile features of both views, cost-volume arg-min, tile descriptor -> the 16-channel hypothesis
+        Slice at the head of the aug-hypothesis buffer (``feat``: fea_l[lvl - 2] for lvl >= 2)."""
+        name = _LEVELS[lvl]
+        tc = getattr(self, f"tile_conv{name}")
+        pc0, pc1 = packed(tc[0]), packed(tc[2])
+        tl = ops.conv2d(ops.conv2d(fl, pc0, stride=4, act="lrelu"), pc1, act="lrelu")
+        # right features: same weights, stride (4,1) on the image zero-padded 3 px on the right
+        tr = ops.conv2d(fr, pc0, stride=(4, 1), pad_tl=(0, 0, 0, 3), act="lrelu")
+        tr = ops.conv2d(tr, pc1, act="lrelu")
+        B, _, Ht, Wt = tl.shape
+        aug = torch.empty(B, 32 if lvl == 0 else 64, Ht, Wt, device=fl.device, dtype=torch.float32)
+        cost = torch.empty(B, 1, Ht, Wt, device=fl.device, dtype=torch.float32)
+        ops.tile_costvol_argmin(tl, tr, self.maxdisp // (16 >> lvl), cost, Slice(aug, 0, 3))
+        feat = tl if feat is None else feat
+        cv(getattr(self, f"tile_fea_dscrpt{name}")[0], cost, x2=feat, act="lrelu", out=Slice(aug, 3, 13))
+        return Slice(aug, 0, 16)
+
     def forward(self, fea_l, fea_r):
         """-> [None, hyps]: the cost volumes are not materialised at inference (the reference only
         consumes them in the training loss, hitnet.py:84-85).  hyps[l] is a 16-channel Slice at
         the head of the aug-hypothesis buffer TilePropagation consumes (32 ch at 1/16, else 64)."""
         def level(lvl):
-            name = _LEVELS[lvl]
-            fl, fr = fea_l[lvl], fea_r[lvl]
-            tc = getattr(self, f"tile_conv{name}")
-            pc0, pc1 = packed(tc[0]), packed(tc[2])
-            tl = ops.conv2d(ops.conv2d(fl, pc0, stride=4, act="lrelu"), pc1, act="lrelu")
-            # right features: same weights, stride (4,1) on the image zero-padded 3 px on the right
-            tr = ops.conv2d(fr, pc0, stride=(4, 1), pad_tl=(0, 0, 0, 3), act="lrelu")
-            tr = ops.conv2d(tr, pc1, act="lrelu")
-            B, _, Ht, Wt = tl.shape
-            aug = torch.empty(B, 32 if lvl == 0 else 64, Ht, Wt, device=fl.device, dtype=torch.float32)
-            cost = torch.empty(B, 1, Ht, Wt, device=fl.device, dtype=torch.float32)
-            ops.tile_costvol_argmin(tl, tr, self.maxdisp // (16 >> lvl), cost, Slice(aug, 0, 3))
-            feat = tl if lvl < 2 else fea_l[lvl - 2]
-            cv(getattr(self, f"tile_fea_dscrpt{name}")[0], cost, x2=feat, act="lrelu", out=Slice(aug, 3, 13))
-            return Slice(aug, 0, 16)
+            return self.init_level(lvl, fea_l[lvl], fea_r[lvl], None if lvl < 2 else fea_l[lvl - 2])
 
         # the five scales are independent 6-launch chains (the four coarse ones ~10 us launches that leave the chip
         # idle): the coarse scales on side streams beside the finest one
         n = len(_LEVELS)
+        if FORK_INIT_FINE and not ops.Fork.serial:
+            # ONE branch: the two finest scales (needed last by the coarse-to-fine propagation) on a side stream beside
+            # the coarse scales' initialisation AND their propagation steps (latency-bound ~10 us launches); joined
+            # when the propagation first asks for one of them
+            fk = self.__dict__.get("_fk")
+            if fk is None or fk.dev != fea_l[0].device:
+                fk = self.__dict__["_fk"] = ops.Fork(fea_l[0].device, 1)
+            fine = fk.run(0, lambda: [level(lvl) for lvl in range(n - FORK_INIT_FINE, n)])
+            return [None, _LazyHyps([level(lvl) for lvl in range(n - FORK_INIT_FINE)] + fine, n - FORK_INIT_FINE, fk)]
         if FORK_INIT_LEVELS and not ops.Fork.serial:
             fk = self.__dict__.get("_fk")
             if fk is None or fk.dev != fea_l[0].device:
@@ -380,7 +420,7 @@ class TilePropagation(nn.Module):
 
 
 @register
-class HITNetMF(nn.Module):
+class HITNetMF(ops.RuntimeState, nn.Module):
     """reference hitnet.py:13-122."""
 
     def __init__(self, backbone, initialization, propagation, loss=None):
@@ -394,9 +434,49 @@ class HITNetMF(nn.Module):
     def extract_feat(self, img):
         return self.backbone(img)
 
+    def _stereo_matching_pipelined(self, left_img, right_img):
+        """Two-stream schedule of the same launches: the coarse-to-fine propagation only needs scale i's features and
+        initialisation at step i, and the finest initialisation only the end of the U-Net decoder.  A side stream runs
+        decoder scales 1/4, 1/2, 1/1 and the finest initialisation; the caller's stream runs the coarse
+        initialisations and propagation steps (latency-bound ~10 us launches) beside it, waiting for the decoder
+        scale-by-scale (events) -- ONE branch, one join."""
+        B, dev = left_img.shape[0], left_img.device
+        ti, tu = self.tile_init, self.tile_update
+        g = self.backbone.stages(torch.cat([left_img, right_img], 0))
+        feas = [next(g), next(g)]  # 1/16, 1/8 (on the caller's stream)
+        L, R = (lambda i: feas[i][:B]), (lambda i: feas[i][B:])
+        rt = self.__dict__.get("_pipe")
+        if rt is None or rt[0].device != dev:
+            rt = self.__dict__["_pipe"] = (torch.cuda.Stream(device=dev), torch.cuda.Event(), torch.cuda.Event())
+        side, ev3, ev2 = rt
+        cur = torch.cuda.current_stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            feas.append(next(g)); ev3.record(side)
+            feas.append(next(g)); ev2.record(side)
+            feas.append(next(g))
+            hyp4 = ti.init_level(4, L(4), R(4), L(2))
+        hyp0, hyp1 = ti.init_level(0, L(0), R(0), None), ti.init_level(1, L(1), R(1), None)
+        h = tu.tile_update0(L(0), R(0), hyp0)[0]
+        h = tu.tile_update1(L(1), R(1), hyp1, h)[0]
+        cur.wait_event(ev3)
+        h = tu.tile_update2(L(2), R(2), ti.init_level(2, L(2), R(2), L(0)), h)[0]
+        cur.wait_event(ev2)
+        h = tu.tile_update3(L(3), R(3), ti.init_level(3, L(3), R(3), L(1)), h)[0]
+        cur.wait_stream(side)
+        h = tu.tile_update4(L(4), R(4), hyp4, h)[0]
+        r1 = tu.tile_update4_1(L(2), h)
+        r05 = tu.tile_update5(L(3), _up1(r1))
+        disp = tu.tile_update6(L(4), _up1(r05))
+        return dict(pred_disp=disp, left_feat=L(2), right_feat=R(2), left_img=left_img)
+
     def stereo_matching(self, left_img, right_img, img_metas=None, state=None):
         """reference hitnet.py:75-100 (eval branch) -> dict(pred_disp, left_feat, right_feat, left_img)."""
         B = left_img.shape[0]
+        if (STEREO_PIPE and not ops.Fork.serial and isinstance(self.backbone, HITUNet) and
+                isinstance(self.tile_init, TileInitialization) and isinstance(self.tile_update, TilePropagation)):
+            with ops.stage("stereo"):
+                return self._stereo_matching_pipelined(left_img, right_img)
         with ops.stage("stereo"):  # exact-fp32 convs: the disparity itself flows through these layers (ops.stage)
             pyr = self.extract_feat(torch.cat([left_img, right_img], 0))
             fea_l = [p[:B] for p in pyr]
