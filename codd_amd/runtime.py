@@ -265,6 +265,8 @@ class PipelinedRunner:
         cn = getattr(estimator.motion.raft3d, "cnet", None)
         if cn is not None and hasattr(cn[0], "fork"):
             cn[0].fork_branches = False
+        if estimator.stereo is not None:  # (same reason: no second stream inside the stereo network here)
+            estimator.stereo.fork_streams = False
         self.reset()
         self.graph = None
         self._static = None

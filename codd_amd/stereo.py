@@ -227,7 +227,7 @@ class TileInitialization(ops.RuntimeState, nn.Module):
         # the five scales are independent 6-launch chains (the four coarse ones ~10 us launches that leave the chip
         # idle): the coarse scales on side streams beside the finest one
         n = len(_LEVELS)
-        if FORK_INIT_FINE and not ops.Fork.serial:
+        if FORK_INIT_FINE and not ops.Fork.serial and getattr(self, "fork_streams", True):
             # ONE branch: the two finest scales (needed last by the coarse-to-fine propagation) on a side stream beside
             # the coarse scales' initialisation AND their propagation steps (latency-bound ~10 us launches); joined
             # when the propagation first asks for one of them
@@ -236,7 +236,7 @@ class TileInitialization(ops.RuntimeState, nn.Module):
                 fk = self.__dict__["_fk"] = ops.Fork(fea_l[0].device, 1)
             fine = fk.run(0, lambda: [level(lvl) for lvl in range(n - FORK_INIT_FINE, n)])
             return [None, _LazyHyps([level(lvl) for lvl in range(n - FORK_INIT_FINE)] + fine, n - FORK_INIT_FINE, fk)]
-        if FORK_INIT_LEVELS and not ops.Fork.serial:
+        if FORK_INIT_LEVELS and not ops.Fork.serial and getattr(self, "fork_streams", True):
             fk = self.__dict__.get("_fk")
             if fk is None or fk.dev != fea_l[0].device:
                 fk = self.__dict__["_fk"] = ops.Fork(fea_l[0].device, n - 1)
@@ -473,7 +473,7 @@ class HITNetMF(ops.RuntimeState, nn.Module):
     def stereo_matching(self, left_img, right_img, img_metas=None, state=None):
         """reference hitnet.py:75-100 (eval branch) -> dict(pred_disp, left_feat, right_feat, left_img)."""
         B = left_img.shape[0]
-        if (STEREO_PIPE and not ops.Fork.serial and isinstance(self.backbone, HITUNet) and
+        if (STEREO_PIPE and not ops.Fork.serial and getattr(self, "fork_streams", True) and isinstance(self.backbone, HITUNet) and
                 isinstance(self.tile_init, TileInitialization) and isinstance(self.tile_update, TilePropagation)):
             with ops.stage("stereo"):
                 return self._stereo_matching_pipelined(left_img, right_img)
@@ -481,6 +481,7 @@ class HITNetMF(ops.RuntimeState, nn.Module):
             pyr = self.extract_feat(torch.cat([left_img, right_img], 0))
             fea_l = [p[:B] for p in pyr]
             fea_r = [p[B:] for p in pyr]
+            self.tile_init.fork_streams = getattr(self, "fork_streams", True)
             _, init = self.tile_init(fea_l, fea_r)
             disp = self.tile_update(fea_l, fea_r, init)
         return dict(pred_disp=disp, left_feat=fea_l[2], right_feat=fea_r[2], left_img=left_img)
