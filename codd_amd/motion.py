@@ -28,6 +28,9 @@ FUSE_NORM_RECORDS = os.environ.get("CODD_FUSE_NORM_RECORDS", "1") == "1"  # (A/B
 FUSE_GATES = os.environ.get("CODD_FUSE_GATES", "1") == "1"
 # the feature encoder runs on a side stream beside the stereo network: small-footprint launch configurations (A/B)
 FNET_CORESIDENT = os.environ.get("CODD_FNET_CORESIDENT", "0") == "1"
+# the context network (read by the NEXT frame only) starts after the feature encoder + correlation pyramid (which the
+# update loop of THIS frame waits for) instead of beside them (A/B)
+CNET_AFTER_FNET = os.environ.get("CODD_CNET_AFTER_FNET", "0") == "1"
 # the flow encoder's 7x7 convolution beside the correlation encoder's first 3x3: 1 = small-footprint configurations for
 # the former, 2 = for both (A/B)
 ENC_CORESIDENT = int(os.environ.get("CODD_ENC_CORESIDENT", "1"))
@@ -456,6 +459,8 @@ class RAFT3D(ops.RuntimeState, nn.Module):
             self.cnet[0].fork(dev).prefork(cur)  # HRNet's branch streams join the frame graph through THIS stream
         for key, stream, fn in (("fmap", self._side[0], self.fnet), ("netinp", self._side[1], self.context)):
             stream.wait_stream(cur)
+            if key == "netinp" and CNET_AFTER_FNET:
+                stream.wait_stream(self._side[0])  # (A/B) the context network yields to the feature encoder + pyramid
             with torch.cuda.stream(stream):
                 out[key] = fn(image)
                 if key == "fmap" and state is not None and "memory" in state and state.get("raft_feat") is not None:
