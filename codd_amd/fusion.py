@@ -14,6 +14,7 @@ from .ops import Slice
 from .registry import build_loss, register
 from .stereo import cv
 
+PREFETCH_KEY = os.environ.get("CODD_PREFETCH_KEY", "1") == "1"  # (A/B switch; Fusion.prefetch_key)
 FUSE_FORGET = os.environ.get("CODD_FUSE_FORGET", "1") == "1"  # (A/B switch: Fusion.memory_query forget branch)
 
 
@@ -71,7 +72,7 @@ class Fusion(ops.RuntimeState, nn.Module):
         """key_layer(left_feat) (reference fusion.py:74-80, 361) depends on the stereo network only: issued on a side
         stream BEFORE the motion stage so that its four small launches run beside the update loop instead of between
         the loop and the cue kernels; memory_query joins it."""
-        if ops.Fork.serial:
+        if ops.Fork.serial or not PREFETCH_KEY:
             return
         dev = left_feat.device
         side = self.__dict__.get("_kside")
