@@ -117,7 +117,7 @@ def parse():
     ap.add_argument("--frame-pipeline", type=int, default=0, choices=[0, 1],
                     help="1: codd_amd.runtime.PipelinedRunner -- frame t+1's image-only work (stereo network, "
                          "RAFT3D encoders) overlaps frame t's motion + fusion inside one graph (same results, one "
-                         "frame of latency; measured 39.6 vs 39.7 frames/s: the CUs are already saturated by the "
+                         "frame of latency; measured 82.0 vs 83.1 frames/s in round 2 (DESIGN.md finding 15): the CUs are already saturated by the "
                          "intra-frame side streams); 0 (default): one frame at a time (FrameRunner)")
     ap.add_argument("--serial-streams", action="store_true",
                     help="disable the fork/join side streams (every launch on one stream) -- used for the "
@@ -467,7 +467,7 @@ def main():
             cr = conv_roofline(rr, (l, r), device)
             fams = cr["families"]
             # dominant family = where the frame's MFMA work is (the eager event brackets of this pass over-count the
-            # launch-bound small fp32 layers: ~8 us of host launch gap each; profiles/r02_* hold the rocprofv3 durations)
+            # launch-bound small fp32 layers: ~8 us of host launch gap each; profiles/r0N_kernel_stats_serial.md hold the rocprofv3 durations of every round)
             dom = max(fams, key=lambda k_: fams[k_]["issued_gflop"])
             fd = fams[dom]
             peak = FP32_MATRIX_PEAK_TFLOPS if dom == "fp32" else BF16_MATRIX_PEAK_TFLOPS

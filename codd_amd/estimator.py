@@ -104,7 +104,10 @@ class ConsistentOnlineDynamicDepth(RuntimeState, nn.Module):
             runner.reset()
         for idx, (l_img, r) in enumerate(zip(torch.unbind(img, 1), torch.unbind(r_img, 1))):
             if runner is not None:
-                out = dict(pred_disp=runner.step(l_img.contiguous(), r.contiguous()).clone(), **runner.last)
+                # the runner's outputs live in the captured graph's memory pool and are overwritten by the next
+                # replay: everything handed out of it is cloned
+                pred_g = runner.step(l_img.contiguous(), r.contiguous()).clone()
+                out = dict(pred_disp=pred_g, **{k: v.clone() for k, v in runner.last.items()})
             else:
                 out = self.consistent_online_depth_estimation(l_img.contiguous(), r.contiguous(), img_meta,
                                                               self.inference_state)

@@ -260,13 +260,6 @@ class PipelinedRunner:
         if estimator.motion is None or estimator.fusion is None:
             raise ValueError("the frame pipeline needs the motion and fusion stages (use FrameRunner)")
         self.est, self.metas, self.use_graph = estimator, img_metas, use_graph
-        # stage A runs on a side stream of the captured graph: HRNet's branch streams could only be forked from that
-        # (already forked) stream, which hipGraphInstantiate of ROCm 7.2 does not survive -> branches in sequence
-        cn = getattr(estimator.motion.raft3d, "cnet", None)
-        if cn is not None and hasattr(cn[0], "fork"):
-            cn[0].fork_branches = False
-        if estimator.stereo is not None:  # (same reason: no second stream inside the stereo network here)
-            estimator.stereo.fork_streams = False
         self.reset()
         self.graph = None
         self._static = None
@@ -284,13 +277,27 @@ class PipelinedRunner:
         dev = left.device
         raft = self.est.motion.raft3d
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            self.est.motion.prefetch(left)
-            pend = raft._pending
-            raft._pending = None
-            if pend is None:
-                raise RuntimeError("PipelinedRunner needs the side streams (ops.Fork.serial must be False)")
-            out = self.est.stereo.stereo_matching(left, right, self.metas, {})
+        # stage A runs on a side stream of the captured graph: HRNet's branch streams and the stereo network's second
+        # stream could only be forked from that (already forked) stream, which hipGraphInstantiate of ROCm 7.2 does not
+        # survive -> no inner forks, for THIS call only (the estimator is shared with FrameRunner / eager callers,
+        # whose schedule and runner-cache key must not change behind their back)
+        cn = getattr(raft, "cnet", None)
+        scoped = [(m, a, getattr(m, a, True)) for m, a in
+                  (((cn[0], "fork_branches"),) if cn is not None and hasattr(cn[0], "fork") else ()) +
+                  (((self.est.stereo, "fork_streams"),) if self.est.stereo is not None else ())]
+        for m, a, _ in scoped:
+            setattr(m, a, False)
+        try:
+            with torch.cuda.stream(side):
+                self.est.motion.prefetch(left)
+                pend = raft._pending
+                raft._pending = None
+                if pend is None:
+                    raise RuntimeError("PipelinedRunner needs the side streams (ops.Fork.serial must be False)")
+                out = self.est.stereo.stereo_matching(left, right, self.metas, {})
+        finally:
+            for m, a, v in scoped:
+                setattr(m, a, v)
         return dict(pred_disp=out["pred_disp"], left_feat=out["left_feat"], right_feat=out["right_feat"],
                     left_img=left, fmap=pend["fmap"], netinp=pend["netinp"])
 

@@ -171,20 +171,6 @@ STEREO_PIPE = os.environ.get("CODD_STEREO_PIPE", "1") == "1"  # (A/B: HITNetMF._
 FORK_INIT_FINE = int(os.environ.get("CODD_FORK_INIT_FINE", "3"))  # (A/B: this many of the finest scales on ONE side stream)
 
 
-class _LazyHyps(list):
-    """The per-scale hypotheses; entries [first_forked, ...) were produced on a side stream that is joined on first use."""
-
-    def __init__(self, items, first_forked, fork):
-        super().__init__(items)
-        self._first, self._fork = first_forked, fork
-
-    def __getitem__(self, i):
-        if self._fork is not None and isinstance(i, int) and i >= self._first:
-            self._fork.join()
-            self._fork = None
-        return super().__getitem__(i)
-
-
 @register
 class TileInitialization(ops.RuntimeState, nn.Module):
     """reference initialization.py:48-230."""
@@ -228,14 +214,17 @@ class TileInitialization(ops.RuntimeState, nn.Module):
         # idle): the coarse scales on side streams beside the finest one
         n = len(_LEVELS)
         if FORK_INIT_FINE and not ops.Fork.serial and getattr(self, "fork_streams", True):
-            # ONE branch: the two finest scales (needed last by the coarse-to-fine propagation) on a side stream beside
-            # the coarse scales' initialisation AND their propagation steps (latency-bound ~10 us launches); joined
-            # when the propagation first asks for one of them
+            # ONE branch: the FORK_INIT_FINE finest scales on a side stream beside the coarse scales' initialisation
+            # (latency-bound ~10 us launches).  Joined BEFORE returning: the result is a plain list that may be
+            # iterated, sliced or indexed in any order (the overlap with the coarse PROPAGATION steps is what
+            # HITNetMF._stereo_matching_pipelined does with explicit events).
             fk = self.__dict__.get("_fk")
             if fk is None or fk.dev != fea_l[0].device:
                 fk = self.__dict__["_fk"] = ops.Fork(fea_l[0].device, 1)
             fine = fk.run(0, lambda: [level(lvl) for lvl in range(n - FORK_INIT_FINE, n)])
-            return [None, _LazyHyps([level(lvl) for lvl in range(n - FORK_INIT_FINE)] + fine, n - FORK_INIT_FINE, fk)]
+            coarse = [level(lvl) for lvl in range(n - FORK_INIT_FINE)]
+            fk.join()
+            return [None, coarse + fine]
         if FORK_INIT_LEVELS and not ops.Fork.serial and getattr(self, "fork_streams", True):
             fk = self.__dict__.get("_fk")
             if fk is None or fk.dev != fea_l[0].device:

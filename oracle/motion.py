@@ -11,7 +11,8 @@ them -- SURVEY.md section 8c): correlation lookup (lietorch_extras.corr_index_fo
 dense SE3 Gauss-Newton builder + 6x6 solve (se3_build_inplace, cholesky6x6_forward), SE3
 algebra (oracle/se3.py), point splatting (pytorch3d PointsRasterizer + AlphaCompositor) and
 HRNet (oracle/hrnet.py).  They are specified here from the call sites and the libraries'
-published semantics and validated by invariants (tests/test_oracle_motion.py).
+published semantics and validated by invariants (tests/test_oracle_invariants.py) and by independent derivations
+that share no code with this file (tests/test_independent_derivations.py).
 """
 import torch
 import torch.nn.functional as F
