@@ -168,6 +168,19 @@ def conv_roofline(runner, frames, device):
         chains.append(p.nlayers)
         return rc
 
+    orig_roll = ops._launch_roll
+
+    def timed_roll(lib, p, stream):  # rolling-window launch (one or two layers): algorithmic FLOPs of its layers
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(torch.cuda.current_stream(device))
+        rc = orig_roll(lib, p, stream)
+        e.record(torch.cuda.current_stream(device))
+        cin = p.C0 + p.C1
+        per_px = {0: cin * 9 * p.cout_store, 1: cin * 9 * p.C + p.C * 9 * p.cout_store, 2: cin * p.C + p.C * 9 * p.cout_store}[p.mode]
+        recs.append((s, e, 2.0 * per_px * p.H * p.W * p.B, (p.B, cin, p.cout_store, 3, -10 - p.mode, p.H, p.W, 1, 0), 0))
+        rolls.append(1 if p.mode == 0 else 2)
+        return rc
+
     orig_multi = ops._launch_conv_multi
 
     def timed_multi(lib, params, n, stream):  # several independent small convolutions in one launch
@@ -182,6 +195,8 @@ def conv_roofline(runner, frames, device):
         multis.append(n)
         return rc
 
+    rolls = []
+    ops._launch_roll = timed_roll
     multis = []
     ops._launch_conv_multi = timed_multi
     chains = []
@@ -213,6 +228,7 @@ def conv_roofline(runner, frames, device):
     finally:
         ops._launch_conv = orig
         ops._launch_chain = orig_chain
+        ops._launch_roll = orig_roll
         ops._launch_conv_multi = orig_multi
         ops.Fork.serial = serial_before
         for fname, fn in saved.items():
@@ -240,7 +256,7 @@ def conv_roofline(runner, frames, device):
             log("conv B%d Cin%-4d Cout%-4d k%dx%d out %3dx%-3d s%d m%d terms%d : n=%3d  %7.3f ms  %6.1f us/launch  %5.1f TF"
                 % (*key, n, ms, ms / n * 1e3, f / ms / 1e9))
     return dict(launches=len(recs), time_ms=t_ms, gflop=flops / 1e9, hbm=hbm,
-                chain_launches=len(chains), chain_layers=sum(chains), multi_launches=len(multis), multi_jobs=sum(multis),
+                chain_launches=len(chains), chain_layers=sum(chains), roll_launches=len(rolls), roll_layers=sum(rolls), multi_launches=len(multis), multi_jobs=sum(multis),
                 families={k: dict(launches=v[0], ms=round(v[1], 3), gflop=round(v[2] / 1e9, 2),
                                   issued_gflop=round(v[3] / 1e9, 2)) for k, v in fam.items()})
 
@@ -495,6 +511,7 @@ def main():
                         algorithmic_frac_of_fp32_matrix_peak=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4),
                         families=fams, conv_launches_per_frame=cr["launches"],
                         chain_launches_per_frame=cr["chain_launches"], conv_layers_inside_chains=cr["chain_layers"],
+                        rolling_window_launches_per_frame=cr["roll_launches"], conv_layers_inside_rolling_launches=cr["roll_layers"],
                         multi_job_launches_per_frame=cr["multi_launches"], convs_inside_multi_job_launches=cr["multi_jobs"], conv_gflop_per_frame=round(cr["gflop"], 2),
                         conv_ms_per_frame=round(cr["time_ms"], 3),
                         whole_conv_algorithmic_tflops=round(cr["gflop"] / cr["time_ms"], 2),

@@ -59,6 +59,17 @@ class ChainParams(C.Structure):
                 ("out", C.c_void_p), ("out_ctot", C.c_int), ("out_coff", C.c_int), ("cout_store", C.c_int),
                 ("th", C.c_int), ("tw", C.c_int)]
 
+
+
+class RollParams(C.Structure):
+    _fields_ = [("in0", View), ("in1", View), ("C0", C.c_int), ("C1", C.c_int),
+                ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("mode", C.c_int),
+                ("wA", C.c_void_p), ("bA", C.c_void_p), ("wB", C.c_void_p), ("bB", C.c_void_p),
+                ("actA", C.c_int), ("actB", C.c_int), ("residual", C.c_int),
+                ("out", C.c_void_p), ("out_ctot", C.c_int), ("out_coff", C.c_int), ("cout_store", C.c_int),
+                ("rh", C.c_int)]
+
+
 _i, _f, _p, _ll = C.c_int, C.c_float, C.c_void_p, C.c_longlong
 
 # name -> (restype, argtypes); must list every function declared in include/codd_hip.h
@@ -71,6 +82,9 @@ SIGNATURES = {
     "codd_chain_pack_layer": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "codd_conv_chain_check": (_i, [C.POINTER(ChainParams)]),
     "codd_conv_chain": (_i, [C.POINTER(ChainParams), _p]),
+    "codd_roll_packed_size": (_ll, [_i, _i, _i]),
+    "codd_roll_pack_weights": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "codd_conv_roll": (_i, [C.POINTER(RollParams), _p]),
     "codd_conv2d_packed_size": (_ll, [_i] * 6),
     "codd_conv2d_pack_weights": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "codd_tile_costvol_argmin": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _i, _p]),
@@ -125,7 +139,7 @@ SIGNATURES = {
     "codd_fusion_blend": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 7  # CODD_ABI_VERSION of include/codd_hip.h
+ABI_VERSION = 8  # CODD_ABI_VERSION of include/codd_hip.h
 _lib = None
 MISSING = []
 

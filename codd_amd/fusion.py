@@ -79,7 +79,7 @@ class Fusion(ops.RuntimeState, nn.Module):
         if side is None or side.device != dev:
             side = self.__dict__["_kside"] = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), ops.stage("fusion"):
             self.__dict__["_pending"] = (left_feat, self._key(left_feat), side)
 
     def _key(self, x):
@@ -92,6 +92,10 @@ class Fusion(ops.RuntimeState, nn.Module):
 
     def memory_query(self, outputs, state, *args, **kwargs):
         """reference fusion.py:357-402."""
+        with ops.stage("fusion"):  # conv precision of the stage (ops._STAGE_PRECISION)
+            return self._memory_query(outputs, state, *args, **kwargs)
+
+    def _memory_query(self, outputs, state, *args, **kwargs):
         left_feat, pred_curr = outputs["left_feat"], outputs["pred_disp"]
         pend = self.__dict__.pop("_pending", None)
         if pend is not None:  # projected beside the motion stage (prefetch_key): always join the side stream

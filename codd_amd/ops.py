@@ -221,7 +221,13 @@ def set_conv_precision(mode):
 # north-star budget -- and its arg-min / arg-max selections flip for ~1.5 % of the pixels; the stereo network
 # (7 % of the frame's conv FLOPs) therefore stays on the exact-fp32 kernels, everything else (RAFT3D encoders and the
 # 16 update iterations, Fusion: 93 % of the FLOPs, O(1) feature scales, smooth outputs) runs split-bf16.
-_STAGE_PRECISION = dict(stereo="fp32", context="fp32")
+# Round 4: Fusion as well.  Over the configured sequence length (tests/test_gpu_headline_parity.py::
+# test_recurrent_sequence_matches_oracle, 16 frames) the split-bf16 error of Fusion's weight path is multiplied by
+# |pred_warp - pred_curr| (up to 250 px with the synthetic weights, whose weight-head logits saturate the sigmoid): from
+# frame 6 on isolated 4x4 blocks take the other side of a 0 | 1 fusion weight and the all-pixel mean leaves the 1e-3 px
+# budget (6.6e-3 ... 1.5e-2 px); with Fusion's ~10 quarter-resolution layers on the exact-fp32 kernels frames 0-13 stay
+# at <= 1e-4 px (profiles/r04_sequence_divergence.log).  CODD_FUSION_PRECISION=split restores the round-3 policy.
+_STAGE_PRECISION = dict(stereo="fp32", context="fp32", fusion=_os.environ.get("CODD_FUSION_PRECISION", "fp32"))
 
 
 class stage:
@@ -1022,6 +1028,111 @@ def conv_chain(x, pch, x2=None, res1=None, out=None, cout_store=None, tile=None)
     p.th, p.tw = pch.tile(lib, p, B, H, W) if tile is None else tile
     _abi.check(_launch_chain(lib, p, _stream()), "codd_conv_chain")
     return out
+
+
+# ---------------------------------------------------------------------------- rolling-window convolutions
+# (csrc/conv_roll.hip, include/codd_hip.h codd_conv_roll): one 3x3, a pair of 3x3 (BasicBlock / merge tail) or a
+# 1x1 -> 3x3 pair per launch for HITNet's large 16- / 32-channel maps.  A/B switch CODD_ROLL (default on), maps of at
+# least ROLL_MIN_PIXELS pixels (below that a 64-column strip grid cannot fill the chip and the tile kernels win).
+USE_ROLL = _os.environ.get("CODD_ROLL", "1") == "1"
+ROLL_MIN_PIXELS = int(_os.environ.get("CODD_ROLL_MIN_PIXELS", str(2 * 288 * 480)))
+ROLL_RH = int(_os.environ.get("CODD_ROLL_RH", "0"))  # dev override of the rows per workgroup
+
+
+ROLL_C32 = _os.environ.get("CODD_ROLL_C32", "0") == "1"  # (dev: the 32-channel instantiations lose to the tile kernels)
+
+
+def use_roll(C, B, Cin_unused, H, W):
+    """Rolling-window launch for a C-channel stride-1 layer (pair) on a [B, *, H, W] map?  Measured on MI355X
+    (tools/time_roll.py): 16 channels at >= 288x480x2 pixels 1.4-1.8x the tile kernels; the 32-channel class has too
+    few 64-column strips on HITNet's half-resolution maps to fill 256 CUs and stays on the tile kernels."""
+    return USE_ROLL and (C == 16 or (C == 32 and ROLL_C32)) and B * H * W >= ROLL_MIN_PIXELS
+
+
+class PackedRoll:
+    """Weights of one codd_conv_roll launch.  ``stages``: one or two dicts(w [cout,cin,k,k], b | None, act); k = 3
+    for every stage except that the FIRST of two may be 1x1 (then cin <= 64).  C = the output channels of every stage
+    (16 | 32); ``residual``: add the chain input to the last stage (pair of 3x3 only)."""
+
+    def __init__(self, stages, residual=False):
+        lib = _abi.load()
+        assert len(stages) in (1, 2)
+        w0 = stages[0]["w"]
+        _require_gpu(w0)
+        ks = [int(st["w"].shape[2]) for st in stages]
+        self.C = int(stages[-1]["w"].shape[1]) if len(stages) == 2 else int(w0.shape[1])
+        self.cin = int(w0.shape[1])
+        self.cout = int(stages[-1]["w"].shape[0])
+        if len(stages) == 1:
+            self.mode = 0
+        else:
+            self.mode = 1 if ks[0] == 3 else 2
+        assert ks[-1] == 3 and (ks[0] in (1, 3)) and self.C in (16, 32), (ks, self.C)
+        assert not residual or self.mode == 1
+        self.residual = bool(residual)
+        self.acts = [ACT[st.get("act", "none")] for st in stages]
+        self.w, self.b = [], []
+        for st, k in zip(stages, ks):
+            w = st["w"].detach().float().contiguous()
+            cout, cin = int(w.shape[0]), int(w.shape[1])
+            assert cout <= self.C and (k == 1 or cin == self.C), (cout, cin, self.C)
+            n = lib.codd_roll_packed_size(self.C, k, cin)
+            if n <= 0:
+                raise _abi.CoddHipError("conv_roll: unsupported stage %dx%d %d->%d" % (k, k, cin, cout))
+            buf = torch.empty(n, device=w.device, dtype=torch.float32)
+            _abi.check(lib.codd_roll_pack_weights(w.data_ptr(), buf.data_ptr(), self.C, cout, cin, k, _stream()), "roll_pack")
+            self.w.append(buf)
+            b = st.get("b")
+            if b is not None:
+                bb = torch.zeros(self.C, device=w.device, dtype=torch.float32)
+                bb[:cout] = b.detach().float()
+                b = bb
+            self.b.append(b)
+
+
+def _roll_rh(B, H, W, mode):
+    """Output rows per workgroup: the largest row block that still gives every CU ~3 workgroups (the strips of a
+    launch are independent; a row block re-reads `lag` rows of its neighbour and idles for the pipeline fill)."""
+    if ROLL_RH:
+        return ROLL_RH
+    stride = 60 if mode == 1 else 62
+    strips = -(-W // stride) * B
+    want = 3 * 256
+    nrb = max(1, -(-want // strips))
+    return max(4, -(-H // nrb))
+
+
+def conv_roll(x, pr, x2=None, out=None, cout_store=None, rh=None):
+    """Run the packed rolling-window launch on (x | x2) -> out [B, cout_store, H, W] (tensor or Slice)."""
+    lib = _abi.load()
+    xs = _as_slice(x)
+    _require_gpu(xs.buf)
+    B, C0, H, W = xs.shape
+    C1 = 0 if x2 is None else _as_slice(x2).c
+    assert C0 + C1 == pr.cin, (C0, C1, pr.cin)
+    cs = pr.cout if cout_store is None else cout_store
+    if out is None:
+        out = torch.empty(B, cs, H, W, device=xs.buf.device, dtype=torch.float32)
+    os_ = _as_slice(out)
+    assert os_.shape == (B, cs, H, W), (os_.shape, (B, cs, H, W))
+    p = _abi.RollParams()
+    p.in0, p.in1, p.C0, p.C1, p.B, p.H, p.W = _view(xs), _view(x2), C0, C1, B, H, W
+    p.C, p.mode = pr.C, pr.mode
+    p.wA, p.bA = pr.w[0].data_ptr(), None if pr.b[0] is None else pr.b[0].data_ptr()
+    p.actA = pr.acts[0]
+    if pr.mode != 0:
+        p.wB, p.bB = pr.w[1].data_ptr(), None if pr.b[1] is None else pr.b[1].data_ptr()
+        p.actB = pr.acts[1]
+    p.residual = int(pr.residual)
+    p.out, p.out_ctot, p.out_coff, p.cout_store = os_.buf.data_ptr(), os_.buf.shape[1], os_.coff, cs
+    p.rh = _roll_rh(B, H, W, pr.mode) if rh is None else rh
+    _abi.check(_launch_roll(lib, p, _stream()), "codd_conv_roll")
+    return out
+
+
+def _launch_roll(lib, p, stream):
+    """Single choke point of every rolling-window launch (bench.py wraps it with HIP events)."""
+    return lib.codd_conv_roll(C.byref(p), stream)
 
 
 def _launch_chain(lib, p, stream):

@@ -64,6 +64,19 @@ def chain(owner, key, specs, stage=0):
     return ent[1]
 
 
+def roll(owner, key, specs, residual=False):
+    """ops.PackedRoll (one rolling-window launch: csrc/conv_roll.hip) of the nn.Conv2d modules in ``specs`` =
+    [(conv, act), ...] (one 3x3, two 3x3 or 1x1 -> 3x3); cached on ``owner`` per parameter version like ``packed``."""
+    mods = [m for m, _ in specs]
+    ver = tuple((m.weight.data_ptr(), m.weight._version, None if m.bias is None else m.bias._version) for m in mods)
+    cache = owner.__dict__.setdefault("_codd_packed_cat", {})
+    ent = cache.get(("roll", key))
+    if ent is None or ent[0] != ver:
+        ent = cache[("roll", key)] = (ver, ops.PackedRoll([dict(w=m.weight, b=m.bias, act=a) for m, a in specs],
+                                                          residual=residual), tuple(mods))
+    return ent[1]
+
+
 def _rb(blk, a, b, act="lrelu", first=False, last=False):
     """Chain specs of a BasicBlock whose input lives in LDS buffer ``a``: conv1 a -> b, conv2 b -> a (+ a).
     ``first``: the block opens the chain (its input is the chain input, staged into buffer ``a``); ``last``: conv2
@@ -119,7 +132,11 @@ class HITUNet(nn.Module):
         def seq(s, t):
             for m in s:
                 if isinstance(m, nn.Conv2d):
-                    t = cv(m, t, act="lrelu")
+                    if (m.kernel_size == (3, 3) and m.stride == (1, 1) and m.in_channels == m.out_channels and
+                            ops.use_roll(m.out_channels, *t.shape)):
+                        t = ops.conv_roll(t, roll(m, "single", [(m, "lrelu")]))
+                    else:
+                        t = cv(m, t, act="lrelu")
             return t
 
         def up_merge(up, merge, skip, t):
@@ -128,6 +145,10 @@ class HITUNet(nn.Module):
                 pch = chain(merge, "merge", [(merge[0], dict(src=-1, dst=0, act="lrelu")), (merge[2], dict(src=0, dst=1, act="lrelu")),
                                              (merge[4], dict(src=1, dst=-1, act="lrelu"))])
                 return ops.conv_chain(skip, pch, x2=u)
+            if ops.use_roll(merge[0].out_channels, *skip.shape):
+                # 1x1 (skip | up) -> 3x3 as one rolling-window launch, the last 3x3 as another
+                t = ops.conv_roll(skip, roll(merge, "head", [(merge[0], "lrelu"), (merge[2], "lrelu")]), x2=u)
+                return ops.conv_roll(t, roll(merge, "tail", [(merge[4], "lrelu")]))
             t = cv(merge[0], skip, x2=u, act="lrelu")
             t = cv(merge[2], t, act="lrelu")
             return cv(merge[4], t, act="lrelu")
@@ -252,8 +273,12 @@ class BasicBlock(nn.Module):
     def run(self, x):
         """lrelu(conv2(lrelu(conv1(x))) + x): the trailing LeakyReLU of the enclosing Sequential is
         fused into the second conv's epilogue."""
-        t = cv(self.conv1[0][0], x, act="lrelu")
-        return cv(self.conv2[0], t, res1=x, act="lrelu")
+        c1, c2 = self.conv1[0][0], self.conv2[0]
+        if c1.dilation[0] == 1 and ops.use_roll(c1.out_channels, *x.shape) and c1.in_channels == c1.out_channels:
+            # both convolutions + residual + LeakyReLU in one rolling-window launch (intermediate in LDS)
+            return ops.conv_roll(x, roll(self, "block", [(c1, "lrelu"), (c2, "lrelu")], residual=True))
+        t = cv(c1, x, act="lrelu")
+        return cv(c2, t, res1=x, act="lrelu")
 
 
 def _resblock(c, d=1):
@@ -331,8 +356,11 @@ class PostTileUpdate(nn.Module):
     def forward(self, fl, prev):
         if ops.use_chain(*fl.shape[2:]):
             return self._forward_chains(fl, prev)
-        t = cv(self.conv1[0], fl, x2=prev, act="lrelu")
-        t = cv(self.conv1[2], t, act="lrelu")
+        if ops.use_roll(self.conv1[0].out_channels, *fl.shape):
+            t = ops.conv_roll(fl, roll(self, "head", [(self.conv1[0], "lrelu"), (self.conv1[2], "lrelu")]), x2=prev)
+        else:
+            t = cv(self.conv1[0], fl, x2=prev, act="lrelu")
+            t = cv(self.conv1[2], t, act="lrelu")
         for blk in self.resblocks:
             t = blk[0].run(t)
         if self._final:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CODD_ABI_VERSION 7
+#define CODD_ABI_VERSION 8
 
 #define CODD_OK 0
 #define CODD_EINVAL (-1)
@@ -226,6 +226,41 @@ int codd_chain_pack_layer(const float* w, const float* bias, int cout, int cin, 
 /* CODD_OK if codd_conv_chain accepts the program (LDS budget, buffer discipline); launches nothing */
 int codd_conv_chain_check(const codd_chain_params* p);
 int codd_conv_chain(const codd_chain_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ROLLING-WINDOW convolutions (exact fp32, v_mfma_f32_16x16x4_f32) for HITNet's large-map, few-channel stride-1
+ * layers (round 4): one launch runs
+ *   mode 0   y = actA(conv3x3_A(x) + bA)
+ *   mode 1   y = actB(conv3x3_B(actA(conv3x3_A(x) + bA)) + bB [+ x])      BasicBlock (reference
+ *            model/stereo/hitnet/propagation.py:103-121 incl. the enclosing LeakyReLU, :119-121) and the two trailing
+ *            3x3 layers of a U-Net merge (backbone.py:31-39)
+ *   mode 2   y = actB(conv3x3_B(actA(conv1x1_A(cat[in0, in1]) + bA)) + bB)  head of a merge / PostTileUpdate
+ *            (backbone.py:24-30, propagation.py:255-258)
+ * with C = 16 | 32 channels out of every stage, "same" zero padding per stage, x = cat[in0, in1] (C0 + C1 = C for
+ * modes 0 / 1, <= 64 for mode 2).  A workgroup walks a 64-column strip down `rh` rows; weights stay in registers, the
+ * intermediate of a pair stays in LDS (csrc/conv_roll.hip).  Weights are packed per stage by codd_roll_pack_weights
+ * (w: [Cout][Cin][k][k] fp32, Cout <= C, output channels past Cout are zero; codd_roll_packed_size floats).
+ * Only channels [0, cout_store) of the last stage are written.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+  codd_view in0, in1;
+  int C0, C1;
+  int B, H, W;
+  int C;                 /* 16 | 32 */
+  int mode;              /* 0 | 1 | 2 */
+  const float* wA;       /* packed weights of stage A (16-byte aligned) */
+  const float* bA;       /* bias of stage A or NULL */
+  const float* wB;       /* stage B (modes 1, 2) */
+  const float* bB;
+  int actA, actB;        /* CODD_ACT_* */
+  int residual;          /* mode 1: add the chain input before actB */
+  float* out;            /* NCHW, channels [out_coff, out_coff + cout_store) of a buffer with out_ctot channels */
+  int out_ctot, out_coff, cout_store;
+  int rh;                /* output rows per workgroup (launch granularity; any value >= 1 gives the same result) */
+} codd_roll_params;
+long long codd_roll_packed_size(int C, int k, int Cin);
+int codd_roll_pack_weights(const float* w, float* packed, int C, int Cout, int Cin, int k, void* stream);
+int codd_conv_roll(const codd_roll_params* p, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stereo (HITNetMF)

@@ -28,7 +28,10 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-OUT = os.path.join(ROOT, "tests", "golden", "headline_oracle_long_sub4.npz")
+# CODD_GOLDEN_OUT / CODD_GOLDEN_THREADS: write somewhere else with another CPU thread count -- used once to measure how
+# far TWO ORACLE RUNS drift apart over the recurrence (different thread counts = different fp32 summation orders in
+# torch's CPU convolutions): profiles/r04_oracle_self_divergence.log
+OUT = os.environ.get("CODD_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden", "headline_oracle_long_sub4.npz"))
 SUB = 4
 
 # name -> (case of test_gpu_headline_parity.CASES that gives shape / intrinsics, iters, frames)
@@ -43,7 +46,7 @@ def main():
     from codd_amd import synth
     from oracle import codd as oc
     only = [a for a in sys.argv[1:] if not a.startswith("--")]
-    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 16)))
+    torch.set_num_threads(int(os.environ.get("CODD_GOLDEN_THREADS", max(1, min(os.cpu_count() or 1, 16)))))
     arrays = {}
     if os.path.exists(OUT):
         old = np.load(OUT)

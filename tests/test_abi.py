@@ -24,7 +24,7 @@ def test_header_symbols_exported_and_bound():
         assert getattr(lib, n) is not None
     for n in _abi.SIGNATURES:
         assert n in names, f"{n} bound but not declared in include/codd_hip.h"
-    assert lib.codd_abi_version() == _abi.ABI_VERSION == 7  # CODD_ABI_VERSION of include/codd_hip.h
+    assert lib.codd_abi_version() == _abi.ABI_VERSION == 8  # CODD_ABI_VERSION of include/codd_hip.h
 
 
 def test_conv_packed_size_is_consistent():
@@ -41,3 +41,19 @@ def test_product_has_no_cpu_fallback():
     from codd_amd import ops
     with pytest.raises(_abi.CoddHipError):
         ops.PackedConv(torch.zeros(16, 3, 3, 3), torch.zeros(16))
+
+
+def test_roll_packed_size_and_argument_checks():
+    """codd_roll_packed_size / codd_conv_roll argument validation (no launch: every call below is rejected first)."""
+    import ctypes as C
+    lib = _abi.load()
+    assert lib.codd_roll_packed_size(16, 3, 16) == 1 * 9 * 1 * 64 * 4
+    assert lib.codd_roll_packed_size(32, 3, 32) == 2 * 9 * 2 * 64 * 4
+    assert lib.codd_roll_packed_size(32, 1, 40) == 2 * 3 * 64 * 4
+    assert lib.codd_roll_packed_size(24, 3, 24) == -1
+    p = _abi.RollParams()
+    assert lib.codd_conv_roll(C.byref(p), None) != 0  # C = 0
+    p.C, p.mode = 48, 0
+    assert lib.codd_conv_roll(C.byref(p), None) == -2  # CODD_EUNSUPPORTED
+    p.C = 16
+    assert lib.codd_conv_roll(C.byref(p), None) == -1  # CODD_EINVAL: null pointers

@@ -616,3 +616,75 @@ def test_persistent_quad_kernel_matches_torch():
             assert n >= 3
     finally:
         ops.set_conv_precision(prev)
+
+
+ROLL_CASES = [
+    # mode (0: 3x3, 1: 3x3 -> 3x3, 2: 1x1 -> 3x3), C, cin, c0 (first source's channels), B, H, W, residual, rows/workgroup
+    (0, 16, 16, 16, 1, 37, 130, False, 8), (1, 16, 16, 16, 2, 29, 75, True, 7), (1, 16, 16, 16, 1, 64, 200, False, 64),
+    (2, 16, 32, 16, 1, 33, 190, False, 5), (0, 32, 32, 32, 1, 21, 64, False, 4), (1, 32, 32, 32, 1, 40, 125, True, 9),
+    (2, 32, 40, 24, 2, 19, 61, False, 19), (2, 32, 64, 64, 1, 17, 70, False, 6), (1, 16, 16, 16, 1, 5, 9, True, 3),
+    (2, 16, 48, 16, 1, 12, 63, False, 4), (1, 16, 16, 8, 1, 130, 62, True, 130), (0, 16, 16, 16, 1, 3, 1, False, 1),
+]
+
+
+@pytest.mark.parametrize("case", ROLL_CASES, ids=lambda c: "m%d_c%d_%dx%d" % (c[0], c[1], c[5], c[6]))
+def test_conv_roll_matches_torch(case):
+    """Rolling-window launches (csrc/conv_roll.hip: BasicBlock pairs, merge heads / tails of HITNet, reference
+    propagation.py:103-121, backbone.py:24-39) against torch fp32 on the CPU: strips that do not divide the width,
+    row blocks that do not divide the height, maps smaller than one strip / one row block, two concatenated sources,
+    batch 2, output written into a channel slice of a larger buffer (neighbouring channels untouched)."""
+    from codd_amd import ops
+    from codd_amd.ops import Slice
+    mode, C, cin, c0, B, H, W, res, rh = case
+    k0 = 1 if mode == 2 else 3
+    wa, ba = rnd(C, cin, k0, k0, seed=1) / (cin * k0 * k0) ** 0.5, rnd(C, seed=2) * 0.1
+    wb, bb = rnd(C, C, 3, 3, seed=3) / (C * 9) ** 0.5, rnd(C, seed=4) * 0.1
+    x = rnd(B, cin, H, W, seed=9)
+    t = F.leaky_relu(F.conv2d(x, wa, ba, padding=k0 // 2), 0.2)
+    if mode == 0:
+        ref = t
+    else:
+        y = F.conv2d(t, wb, bb, padding=1)
+        ref = F.relu(y + x) if res else F.leaky_relu(y, 0.2)  # (relu after the residual: a second activation code)
+    st = [dict(w=wa.to(dev()), b=ba.to(dev()), act="lrelu")]
+    if mode:
+        st.append(dict(w=wb.to(dev()), b=bb.to(dev()), act="relu" if res else "lrelu"))
+    pr = ops.PackedRoll(st, residual=res)
+    xd = x.to(dev())
+    out = torch.full((B, C + 3, H, W), 5.0, device=dev())
+    if c0 < cin:
+        ops.conv_roll(Slice(xd, 0, c0), pr, x2=Slice(xd, c0, cin - c0), out=Slice(out, 2, C), rh=rh)
+    else:
+        ops.conv_roll(xd, pr, out=Slice(out, 2, C), rh=rh)
+    got = out.cpu()
+    assert (got[:, 2:2 + C] - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    assert (got[:, :2] == 5.0).all() and (got[:, 2 + C:] == 5.0).all()
+    # the launch granularity must not change a single bit
+    out2 = torch.empty(B, C, H, W, device=dev())
+    ops.conv_roll(Slice(xd, 0, c0), pr, x2=Slice(xd, c0, cin - c0) if c0 < cin else None, out=out2, rh=max(1, rh // 2 + 1))
+    assert torch.equal(out2.cpu(), got[:, 2:2 + C])
+
+
+def test_roll_launches_equal_tile_kernels_in_hitnet():
+    """HITNetMF with the rolling-window launches (default) against the same network on the per-layer tile kernels
+    (CODD_ROLL=0 path): same arithmetic per output (k-ordered fp32 fma chains), so the disparities agree to fp32
+    rounding of the few layers whose chunking differs."""
+    import codd_amd  # noqa: F401
+    from codd_amd import configs, ops, synth
+    from codd_amd.registry import build_estimator
+    est = build_estimator(configs.stereo_only()).eval()
+    synth.load_synthetic_weights(est, gain=1.4)
+    est = est.to(dev())
+    H, W = 576, 960
+    img, r_img, _ = synth.stereo_sequence(H, W, 1)
+    l, r = img[:, 0].to(dev()), r_img[:, 0].to(dev())
+    prev = ops.USE_ROLL
+    try:
+        ops.USE_ROLL = True
+        a = est.stereo.stereo_matching(l, r)["pred_disp"].clone()
+        ops.USE_ROLL = False
+        b = est.stereo.stereo_matching(l, r)["pred_disp"].clone()
+    finally:
+        ops.USE_ROLL = prev
+    d = (a - b).abs()
+    assert d.median().item() < 1e-5 and (d > 0.25).float().mean().item() < 1e-4, (d.median().item(), d.max().item())
