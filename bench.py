@@ -98,15 +98,23 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=32)
-    ap.add_argument("--precision", default="split", choices=["split", "fp32", "bf16"],
+    ap.add_argument("--precision", default="split", choices=["split", "fp32", "bf16", "bf16mix"],
                     help="arithmetic of the convolution family (codd_amd.ops.set_conv_precision): split = split-bf16 "
                          "operands / fp32 accumulate for RAFT3D + Fusion and exact fp32 for HITNet (default, parity-"
                          "tested at 1e-3 px); fp32 = exact-fp32 kernels everywhere; bf16 = bf16 operands / fp32 "
-                         "accumulate everywhere (BASELINE.json configs[4])")
+                         "accumulate everywhere (BASELINE.json configs[4]); bf16mix = bf16 operands for RAFT3D's feature encoder "
+                         "and update block only, exact fp32 for HITNet / context network / Fusion")
     ap.add_argument("--stereo-only", action="store_true")
     ap.add_argument("--fp32-steps", type=int, default=30,
                     help="after the timed region (rank 0, N = 1, split precision only): time this many steady-state frames "
                          "with EVERY convolution on the exact-fp32 kernels and report them as fp32_exact_fps (0 = skip)")
+    ap.add_argument("--two-video-steps", type=int, default=60,
+                    help="after the timed region (rank 0, N = 1): frames per video of a pass with TWO independent videos "
+                         "resident on the GPU (two frame graphs on two streams), reported as fps_two_videos_per_gpu -- the "
+                         "throughput headroom beside the one-video-per-GPU headline (0 = skip)")
+    ap.add_argument("--no-pmc-traffic", dest="pmc_traffic", action="store_false",
+                    help="do not measure roofline.traffic with two rocprofv3 --pmc child passes (N = 1 only, ~40 s); the "
+                         "newest committed capture under profiles/ is quoted instead")
     ap.add_argument("--tune-db", default=None,
                     help="JSON file of tuned launch configurations: loaded if it exists (no tuning launches, e.g. under "
                          "a profiler), written at the end otherwise")
@@ -259,6 +267,54 @@ def conv_roofline(runner, frames, device):
                 chain_launches=len(chains), chain_layers=sum(chains), roll_launches=len(rolls), roll_layers=sum(rolls), multi_launches=len(multis), multi_jobs=sum(multis),
                 families={k: dict(launches=v[0], ms=round(v[1], 3), gflop=round(v[2] / 1e9, 2),
                                   issued_gflop=round(v[3] / 1e9, 2)) for k, v in fam.items()})
+
+
+def pmc_traffic(args, kernel_pattern):
+    """HBM-side traffic per launch of the kernels whose name contains ``kernel_pattern``, measured with the PMC counters
+    as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 passes (--kernel-trace --pmc only),
+    gfx950 correction traffic = (2 * FETCH_SIZE + WRITE_SIZE) KiB (FETCH_SIZE counts wide reads at half size).  Each pass
+    re-runs this script for 4 eager, serial-stream frames.  -> (bytes per launch, source text) or (None, None)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, None  # no profiler, or this process already runs under one
+    sums = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            with tempfile.TemporaryDirectory(dir="/tmp") as td:
+                cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", td, "-o", "p", "--",
+                       sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--fp32-steps", "0", "--two-video-steps", "0",
+                       "--no-pmc-traffic", "--serial-streams", "--no-graph", "--steps", "4", "--prewarm", "2", "--warmup", "1",
+                       "--precision", args.precision, "--iters", str(args.iters), "--height", str(args.height),
+                       "--width", str(args.width)] + (["--stereo-only"] if args.stereo_only else [])
+                env = dict(os.environ, TMPDIR="/tmp")
+                for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+                    env.pop(k, None)
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
+                path = None
+                for root, _, files in os.walk(td):
+                    for f in files:
+                        if f.endswith("counter_collection.csv"):
+                            path = os.path.join(root, f)
+                tot, n = 0.0, 0
+                for r in csv.DictReader(open(path)):
+                    if r["Counter_Name"] == counter and kernel_pattern in r["Kernel_Name"]:
+                        tot += float(r["Counter_Value"]); n += 1
+                if n == 0:
+                    return None, None
+                sums[counter] = (tot, n)
+    except Exception as e:  # pragma: no cover  (profiler missing / refused / timed out: the committed capture is quoted)
+        log(f"pmc traffic passes failed: {e!r}")
+        return None, None
+    f, nf = sums["FETCH_SIZE"]
+    w, nw = sums["WRITE_SIZE"]
+    return round((2.0 * f / nf + w / nw) * 1024.0), (
+        f"measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate child passes of bench.py, "
+        f"4 eager serial-stream frames, {nf} launches of *{kernel_pattern}*); traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB "
+        f"(gfx950: FETCH_SIZE counts wide reads at half size)")
 
 
 def cpu_baseline(args):
@@ -472,6 +528,7 @@ def main():
     roof = None
     cpu = None
     fp32_fps = None
+    two_fps = None
     if rank == 0:
         try:
             l, r, _ = frame(1)
@@ -493,7 +550,13 @@ def main():
             # process: the figure of the newest committed capture is quoted with its source, else null
             traffic, tsrc = None, None
             pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-            for tname in sorted((f for f in os.listdir(pdir) if f.endswith("_conv_traffic.json")), reverse=True):
+            if world == 1 and args.pmc_traffic and not args.serial_streams:
+                # measured by THIS run: two child passes of this script under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE
+                # need separate passes on gfx950), 4 eager serial-stream frames each, ~20 s per pass, hard timeouts
+                pat = {"split_bf16": "conv_bf16_kernel", "bf16": "conv_bf16_kernel", "fp32": "conv_"}[dom]
+                traffic, tsrc = pmc_traffic(args, pat)
+                log(f"pmc traffic passes done: {traffic}")
+            for tname in ([] if traffic is not None else sorted((f for f in os.listdir(pdir) if f.endswith("_conv_traffic.json")), reverse=True)):
                 tj = json.load(open(os.path.join(pdir, tname)))
                 if tj.get("family") == dom:
                     traffic, tsrc = round(tj["traffic_bytes_per_launch"]), f"profiles/{tname} (committed rocprofv3 --pmc passes, not this run): " + tj["correction"]
@@ -541,6 +604,34 @@ def main():
             finally:
                 _ops_tune.set_conv_precision(prev)
             log(f"fp32-exact pass done: {fp32_fps}")
+        if world == 1 and args.two_video_steps > 0 and not args.stereo_only and not pipelined and not args.no_graph:
+            # throughput headroom, reported BESIDE the headline (one video per GPU): two independent videos resident on
+            # this GPU -- two model replicas (own persistent buffers), two captured frame graphs replayed on two streams
+            try:
+                est2 = build_model(args, device)
+                runners = [runner, FrameRunner(est2, metas[0], use_graph=True)]
+                runners[1].reset()
+                streams = [torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)]
+
+                def both(i):
+                    for rr, ss in zip(runners, streams):
+                        with torch.cuda.stream(ss):
+                            rr.step(*frame(i)[:2])
+
+                for ss in streams:
+                    ss.wait_stream(torch.cuda.current_stream(device))
+                for i in range(20):  # primes the second video's state, captures its graph, settles the clocks
+                    both(i)
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for i in range(args.two_video_steps):
+                    both(20 + i)
+                torch.cuda.synchronize(device)
+                two_fps = round(2 * args.two_video_steps / (time.perf_counter() - t0), 3)
+                del runners, est2
+            except Exception as e:  # pragma: no cover
+                two_fps = repr(e)
+            log(f"two-videos pass done: {two_fps}")
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline_subprocess(args)
             log("cpu baseline done")
@@ -552,8 +643,10 @@ def main():
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": {"split": "f32 (split-bf16 MFMA operands, f32 accumulate; HITNet + context network exact f32)", "fp32": "f32",
-                      "bf16": "bf16 (MFMA operands; f32 accumulate, f32 everywhere outside the convolutions)"}[args.precision],
+            "dtype": {"split": "f32 (split-bf16 MFMA operands, f32 accumulate; HITNet + context network + Fusion exact f32)", "fp32": "f32",
+                      "bf16": "bf16 (MFMA operands; f32 accumulate, f32 everywhere outside the convolutions)",
+                      "bf16mix": "bf16 MFMA operands / f32 accumulate for RAFT3D's encoder + update block; HITNet + context "
+                                 "network + Fusion exact f32"}[args.precision],
             "data": "synthetic",
             "config": {"workload": ("HITNetMF stereo-only" if args.stereo_only else
                                     "full CODD (HITNetMF + Motion/RAFT3D iters=%d + Fusion)" % args.iters) +
@@ -573,6 +666,7 @@ def main():
             "epe_vs_synthetic_gt": red["epe"][0],
             # every convolution on the exact-fp32 kernels (--precision fp32), same frame, shorter run
             "fp32_exact_fps": fp32_fps,
+            "fps_two_videos_per_gpu": two_fps,
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

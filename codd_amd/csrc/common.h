@@ -52,6 +52,23 @@ static inline bool xs_view_ok(const codd_xs_view& d, int C, int H, int W) {
          d.bt >= 0 && d.bl >= 0 && d.hp >= d.bt + H && d.wp >= d.bl + W;
 }
 
+// XCD-contiguous work-item walk for kernels whose NEIGHBOURING workgroups share input (halo rows / columns): the
+// dispatcher places workgroup L (linear id, x fastest) on XCD L % 8, so neighbours land on eight different L2s and
+// every shared byte is fetched up to 8 times from HBM.  Workgroup L takes item start[L % 8] + L / 8 instead: every
+// XCD walks ONE contiguous range of the x-fastest item order.  (Same mapping as conv_kernel.h conv_xcd_item.)
+__device__ __forceinline__ int codd_xcd_item(int L, int n) {
+  const int q = n >> 3, r = n & 7, x = L & 7, idx = L >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + idx;
+}
+// (bx, by, bz) of this workgroup's item under the walk above, for a 3-D grid
+__device__ __forceinline__ void codd_xcd_block(int& bx, int& by, int& bz) {
+  const int nx = gridDim.x, ny = gridDim.y;
+  int it = codd_xcd_item(blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z), nx * ny * gridDim.z);
+  bx = it % nx; it /= nx;
+  by = it % ny;
+  bz = it / ny;
+}
+
 // wave64 butterfly helpers
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -26,6 +26,9 @@
 #include "common.h"
 #include "conv_kernel.h"  // view_ptr, conv_xcd_item
 
+#ifdef ROLL_ABL_CLK  // dev (tools/ubench/roll_ablate.hip): shader-clock / wall-clock ticks of workgroup 0's main loop
+__device__ long long roll_clk[16];
+#endif
 namespace {
 
 // the activations HITNet uses (the generic act_apply carries exp / log / tanh code for every epilogue value)
@@ -65,6 +68,9 @@ __global__ __launch_bounds__(64 * 4 * (C / 16)) void conv_roll_kernel(const Roll
   const int g = lane >> 4, j = lane & 15;
   const int seg = wave & 3, half = wave >> 2;
 
+#ifdef ROLL_ABL_CLK
+  const long long wal_in_ = wall_clock64();
+#endif
   int bid = conv_xcd_item(blockIdx.x, gridDim.x);
   const int strip = bid % k.nstrips; bid /= k.nstrips;
   const int rb = bid % k.nrb;
@@ -259,6 +265,9 @@ __global__ __launch_bounds__(64 * 4 * (C / 16)) void conv_roll_kernel(const Roll
   float* outp = p.out + ((size_t)b * p.out_ctot + p.out_coff + 16 * half + 4 * g) * (size_t)HW;
   const bool st_col = col_in && px >= (MODE == 1 ? 2 : 1) && px <= (MODE == 1 ? 61 : 62);
 
+#ifdef ROLL_ABL_CLK
+  const long long clk0_ = clock64(), wal0_ = wall_clock64();
+#endif
   for (int t = 0; t < T; ++t) {
     // (1) start the load of input row li = t + 4 (MODE 2: of this step's stage-A operands)
 #ifndef ROLL_ABL_NOLOAD
@@ -341,6 +350,12 @@ __global__ __launch_bounds__(64 * 4 * (C / 16)) void conv_roll_kernel(const Roll
     ROLL_BARRIER();
     if (++sl_in >= (NIN ? NIN : 1)) sl_in = 0;
   }
+#ifdef ROLL_ABL_CLK
+  if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1 || blockIdx.x == gridDim.x / 2)) {
+    const int o_ = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 4 : 8);
+    roll_clk[o_] = clock64() - clk0_; roll_clk[o_ + 1] = wal_in_; roll_clk[o_ + 2] = wal0_; roll_clk[o_ + 3] = wall_clock64();
+  }
+#endif
 #undef ROLL_3X3
 #undef ROLL_3X3_X2
 #undef ROLL_MM8

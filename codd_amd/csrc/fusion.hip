@@ -207,8 +207,10 @@ __global__ __launch_bounds__(256) void fusion_forget_kernel(const float* __restr
   __shared__ float spc[TS * TS], spw[TS * TS];
   __shared__ float sd[9][RS * RS];
   __shared__ __attribute__((aligned(16))) float sw[9 * NC + 12];  // W_eff [9][NC] | beta[9] | c0
-  const int tid = threadIdx.x, b = blockIdx.z;
-  const int y0 = blockIdx.y * 16, x0 = blockIdx.x * 16;
+  const int tid = threadIdx.x;
+  int bx_, by_, b;  // neighbouring tiles share their halo (22 x 22 of 16 x 16 pixels): keep them on one XCD's L2
+  codd_xcd_block(bx_, by_, b);
+  const int y0 = by_ * 16, x0 = bx_ * 16;
   const size_t N = (size_t)H * W;
   const float* pcb = pc_ + (size_t)b * N;
   const float* pwb = pw_ + (size_t)b * N;

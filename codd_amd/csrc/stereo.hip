@@ -74,7 +74,9 @@ __global__ __launch_bounds__(256) void costvol_argmin4_kernel(const float* __res
                                                               int disp_coff, int zero_dxdy) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int xt0 = blockIdx.x * TPB, y = blockIdx.y, b = blockIdx.z;
+  int bx_, y, b;  // x-neighbours share all but four columns of their right-feature windows: keep them on one XCD's L2
+  codd_xcd_block(bx_, y, b);
+  const int xt0 = bx_ * TPB;
   const int win = D + 4 * (TPB - 1);  // window length per channel (multiple of 4)
   const int base = 4 * xt0 - (D - 1); // image x of window element 0
   float* rl = sm;                     // [C][win]

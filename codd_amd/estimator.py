@@ -182,7 +182,7 @@ class ConsistentOnlineDynamicDepth(RuntimeState, nn.Module):
         from . import ops
         from .runtime import FrameRunner
         rkey = (tuple(img.shape[-2:]), int(img.shape[0]), tuple(img_meta[0].get("intrinsics", ())), str(img.device),
-                ops.CONV_PRECISION, bool(ops._AUTOTUNE), bool(ops.Fork.serial), self._weights_token())
+                ops.CONV_PRECISION, bool(ops.BF16_STAGE_POLICY), tuple(sorted(ops._STAGE_PRECISION.items())), bool(ops._AUTOTUNE), bool(ops.Fork.serial), self._weights_token())
         cache = self.__dict__.setdefault("_runners", OrderedDict())
         runner = cache.pop(rkey, None)
         if runner is None:

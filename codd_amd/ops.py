@@ -207,11 +207,19 @@ ALLPAIRS_SPLIT = _os.environ.get("CODD_ALLPAIRS_SPLIT", "1") == "1"  # (A/B swit
 _TERMS = dict(split=3, bf16=1)
 
 
+# "bf16" with BF16_STAGE_POLICY on ("bf16mix" in bench.py / set_conv_precision): the stages of _STAGE_PRECISION keep
+# their exact-fp32 kernels (HITNet, whose output IS the disparity, the context network, Fusion) and only RAFT3D's
+# feature encoder and its 16 update iterations -- 85 % of the frame's convolution FLOPs -- run on plain bf16 operands.
+BF16_STAGE_POLICY = False
+
+
 def set_conv_precision(mode):
-    global CONV_PRECISION
-    if mode not in ("split", "fp32", "bf16"):
-        raise ValueError("conv precision must be 'split', 'fp32' or 'bf16'")
-    prev, CONV_PRECISION = CONV_PRECISION, mode
+    """-> the previous mode (pass it back to restore).  "bf16mix" = "bf16" + the stage policy."""
+    global CONV_PRECISION, BF16_STAGE_POLICY
+    if mode not in ("split", "fp32", "bf16", "bf16mix"):
+        raise ValueError("conv precision must be 'split', 'fp32', 'bf16' or 'bf16mix'")
+    prev = "bf16mix" if CONV_PRECISION == "bf16" and BF16_STAGE_POLICY else CONV_PRECISION
+    CONV_PRECISION, BF16_STAGE_POLICY = ("bf16", True) if mode == "bf16mix" else (mode, False)
     return prev
 
 
@@ -239,8 +247,10 @@ class stage:
 
     def __enter__(self):
         self.prev = None
-        if CONV_PRECISION == "split" and self.name in _STAGE_PRECISION:
-            self.prev = set_conv_precision(_STAGE_PRECISION[self.name])
+        if self.name in _STAGE_PRECISION and (CONV_PRECISION == "split" or (CONV_PRECISION == "bf16" and BF16_STAGE_POLICY)):
+            to = _STAGE_PRECISION[self.name]
+            if to != "split" or CONV_PRECISION == "split":  # (a "split" stage under bf16mix stays bf16)
+                self.prev = set_conv_precision(to)
 
     def __exit__(self, *exc):
         if self.prev is not None:

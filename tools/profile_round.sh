@@ -8,15 +8,15 @@ ROUND=${ROUND:-r03}; TAG=${TAG:-}; ARGS=${ARGS:-}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_${ROUND}${TAG}; mkdir -p $OUT
 cp $R/codd_amd/tuned/mi355x.json $OUT/tune_db.json   # the shipped launch configurations (what bench.py runs by default)
-python $R/bench.py $ARGS --no-cpu-baseline --fp32-steps 0 --tune-db $OUT/tune_db.json > $OUT/bench_plain.log 2>&1   # un-profiled reference run
+python $R/bench.py $ARGS --no-cpu-baseline --fp32-steps 0 --two-video-steps 0 --no-pmc-traffic --tune-db $OUT/tune_db.json > $OUT/bench_plain.log 2>&1   # un-profiled reference run
 for mode in serial default; do
   flag=""; [ $mode = serial ] && flag="--serial-streams"
   rm -rf /tmp/st_$mode
-  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$mode -o s -- python $R/bench.py $ARGS --steps 60 --no-cpu-baseline --fp32-steps 0 --tune-db $OUT/tune_db.json $flag > $OUT/bench_$mode.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st_$mode -o s -- python $R/bench.py $ARGS --steps 60 --no-cpu-baseline --fp32-steps 0 --two-video-steps 0 --no-pmc-traffic --tune-db $OUT/tune_db.json $flag > $OUT/bench_$mode.log 2>&1
   cp /tmp/st_$mode/s_kernel_stats.csv $OUT/${mode}_kernel_stats.csv
   [ $mode = default ] && python3 $R/tools/timeline_gaps.py /tmp/st_$mode/s_kernel_trace.csv --dump $OUT/frame_sequence.txt > $OUT/timeline_default.txt 2>&1
 done
-CMD="python $R/bench.py $ARGS --no-cpu-baseline --fp32-steps 0 --tune-db $OUT/tune_db.json --serial-streams --steps 4 --prewarm 2 --warmup 1 --no-graph"
+CMD="python $R/bench.py $ARGS --no-cpu-baseline --fp32-steps 0 --two-video-steps 0 --no-pmc-traffic --tune-db $OUT/tune_db.json --serial-streams --steps 4 --prewarm 2 --warmup 1 --no-graph"
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do
   tag=$(echo $set | cut -d' ' -f1)
   rm -rf /tmp/pm_$tag

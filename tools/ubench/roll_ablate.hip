@@ -31,5 +31,14 @@ int main(int argc, char** argv) {
   hipEventRecord(e1, 0); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   printf("C %d mode %d B %d %dx%d rh %d: %.1f us\n", C, mode, B, H, W, rh, ms / N * 1e3);
+#ifdef ROLL_ABL_CLK
+  long long hc[16];
+  hipMemcpyFromSymbol(hc, HIP_SYMBOL(roll_clk), 128);
+  const long long base = hc[1] < hc[9] ? (hc[1] < hc[5] ? hc[1] : hc[5]) : (hc[9] < hc[5] ? hc[9] : hc[5]);
+  for (int o = 0; o < 12; o += 4)
+    printf("  workgroup %s: entry +%.2f us, prologue %.2f us, main loop %.2f us (%lld shader ticks), ends +%.2f us\n",
+           o == 0 ? "first" : (o == 4 ? "last " : "mid  "), (hc[o + 1] - base) / 100.0, (hc[o + 2] - hc[o + 1]) / 100.0,
+           (hc[o + 3] - hc[o + 2]) / 100.0, hc[o], (hc[o + 3] - base) / 100.0);
+#endif
   return 0;
 }
