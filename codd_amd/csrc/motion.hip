@@ -453,10 +453,14 @@ extern "C" int codd_raft_geometry(const float* T, const float* depth1, const flo
 #define GN_JS 44  // floats per neighbour record (16-byte aligned)
 #define GN_WAVES 4
 #define GN_SOLVE_WAVES 14  // 27 sums over 14 waves: <= 2 each
+// split-bf16 copy of ae_j / 8 for the MFMA builder (se3_gn_build2_kernel): per pixel [plane hi | lo][32 bf16] = 128 bytes
+// = 32 floats; hi = bf16_rne(v), lo = bf16_rne(v - hi) as everywhere else (common.h xs_store8)
+#define GN_AQ 32
 __global__ void se3_gn_prep_kernel(const float* __restrict__ ae, int ae_c, const float* __restrict__ xyz,
                                    const float* __restrict__ delta, const float* __restrict__ wgt,
                                    const float* __restrict__ d1, int h, int w, float fx, float fy, float cx, float cy,
-                                   float* __restrict__ jd, int* __restrict__ cnt, int ntiles) {
+                                   float* __restrict__ jd, int* __restrict__ cnt, int ntiles,
+                                   unsigned short* __restrict__ aeq) {
   const int N = h * w;
   const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
   if (j < ntiles) cnt[b * ntiles + j] = 0;  // arrival counters of the builder launched next (ntiles <= N)
@@ -473,6 +477,10 @@ __global__ void se3_gn_prep_kernel(const float* __restrict__ ae, int ae_c, const
     const float v = av[c] * (c < ae_c ? 0.125f : 0.f);
     rp[c] = v;
     a2 += v * v;
+    const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
+    unsigned short* q = aeq + ((size_t)b * N + j) * (2 * GN_AQ);
+    q[c] = __builtin_bit_cast(unsigned short, hi);
+    q[GN_AE + c] = __builtin_bit_cast(unsigned short, lo);
   }
   const V3 X = inv_project(d1[(size_t)b * N + j], xj, yj, fx, fy, cx, cy);
   const float* xb = xyz + ((size_t)b * N + j) * 3;
@@ -503,7 +511,8 @@ __global__ __launch_bounds__(64) void gn_heads_prep_kernel(const codd_xs_view hs
                                                           const float* __restrict__ xyz, const float* __restrict__ d1,
                                                           int h, int w, float fx, float fy, float cx, float cy,
                                                           float* __restrict__ jd, float* __restrict__ wout,
-                                                          int* __restrict__ cnt, int ntiles) {
+                                                          int* __restrict__ cnt, int ntiles,
+                                                          unsigned short* __restrict__ aeq) {
   const int N = h * w;
   const int lane = threadIdx.x, px = lane & 15, g = lane >> 4, b = blockIdx.y;
   if (lane == 0)  // arrival counters of the builder launched next
@@ -576,7 +585,20 @@ __global__ __launch_bounds__(64) void gn_heads_prep_kernel(const codd_xs_view hs
       v[r] = (acc[t][r] + bias[16 * t + 4 * g + r]) * 0.125f;
       a2 += v[r] * v[r];
     }
-    if (ok) *(f32x4*)(rp + 16 * t + 4 * g) = v;
+    if (ok) {
+      *(f32x4*)(rp + 16 * t + 4 * g) = v;
+      // split-bf16 planes of the same four dims (16 t + 4 g ..): 8 bytes per plane
+      unsigned short hq[4], lq[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const __bf16 hi = (__bf16)v[r], lo = (__bf16)(v[r] - (float)hi);
+        hq[r] = __builtin_bit_cast(unsigned short, hi);
+        lq[r] = __builtin_bit_cast(unsigned short, lo);
+      }
+      unsigned short* q = aeq + ((size_t)b * N + j) * (2 * GN_AQ) + 16 * t + 4 * g;
+      *(uint2*)q = uint2{(unsigned)hq[0] | ((unsigned)hq[1] << 16), (unsigned)hq[2] | ((unsigned)hq[3] << 16)};
+      *(uint2*)(q + GN_AE) = uint2{(unsigned)lq[0] | ((unsigned)lq[1] << 16), (unsigned)lq[2] | ((unsigned)lq[3] << 16)};
+    }
   }
   a2 += __shfl_xor(a2, 16, 64);
   a2 += __shfl_xor(a2, 32, 64);
@@ -776,6 +798,151 @@ __global__ __launch_bounds__(64 * GN_WAVES) void se3_gn_build_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// MFMA builder (round 4, CODD_GN_MFMA=1; off by default, see gn_mfma()): the 32-term affinity dot products -- 18 of the scalar builder's 110
+// VALU instructions per neighbour -- move to the bf16 matrix pipe, which this VALU-bound kernel leaves idle.
+//   * neighbours are taken 16 at a time; Gram block G[j][i] = <ae_j, ae_i> for the tile's 64 pixels by
+//     v_mfma_f32_32x32x16_bf16 on split-bf16 operands (3 terms, as the convolutions: hi*hi + hi*lo + lo*hi):
+//     rows = neighbours, columns = pixels; MFMA q covers pixels 32 q .. 32 q + 31, two k-steps cover the 32 dims:
+//     12 MFMAs = 384 matrix-pipe cycles per 16 neighbours (24 per neighbour, against 87 VALU cycles);
+//   * row m of the A operand holds neighbour (m % 4) + 4 (m / 8), i.e. rows m and m + 4 the SAME neighbour, so that
+//     accumulator register r of BOTH lane halves is neighbour r: the neighbour stays wave-uniform (scalar record
+//     loads, SGPR operands as before) and lane L = pixel L picks accumulator set L / 32 with one v_cndmask;
+//   * everything after the dot product is the scalar builder's arithmetic, instruction for instruction.
+// (The fp32-MFMA variant of round 2 gained nothing: v_mfma_f32_16x16x4_f32 runs at the VALU's own FMA rate.)
+// ------------------------------------------------------------------------------------------------
+typedef float gn_f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(64 * GN_WAVES) void se3_gn_build2_kernel(
+    const float* __restrict__ T, const float* __restrict__ jd, const uint4* __restrict__ aeq, int h, int w, float fx,
+    float fy, float cx, float cy, int radius, int tiles_x, int ntiles, int q4, int gmax, float* part) {
+  __shared__ float red[GN_WAVES][27][64];
+  const int N = h * w;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+  const int tx0 = (tile % tiles_x) * 8, ty0 = (tile / tiles_x) * 8;
+  const int ylo = max(ty0 - radius, 0), yhi = min(ty0 + 7 + radius, h - 1);
+  const int xlo = max(tx0 - radius, 0), xhi = min(tx0 + 7 + radius, w - 1);
+  const int ncols = xhi - xlo + 1, nj = (yhi - ylo + 1) * ncols;
+  const int G = gn_groups(nj, q4, gmax);
+  if (g >= G) return;
+  const int slot = g * GN_WAVES + wave, nslots = G * GN_WAVES;
+  const int s0 = (int)((long long)nj * slot / nslots), s1 = (int)((long long)nj * (slot + 1) / nslots);
+
+  const int xi = tx0 + (lane & 7), yi = ty0 + (lane >> 3);
+  const bool vi = xi < w && yi < h;
+  const int i = vi ? yi * w + xi : 0;
+  const int xim = xi - radius, yim = yi - radius;
+  const unsigned twor = 2u * (unsigned)radius;
+  const float* rec = jd + (size_t)b * N * GN_JS;
+  const SE3T Ti = se3_load(T + ((size_t)b * N + i) * 7);
+  const V3 c0 = qrot(Ti.q, V3{1.f, 0.f, 0.f}), c1 = qrot(Ti.q, V3{0.f, 1.f, 0.f}), c2 = qrot(Ti.q, V3{0.f, 0.f, 1.f});
+  const float ai2 = rec[(size_t)i * GN_JS + 41];
+  // B operands: pixel p = 32 q + (lane % 32) of the tile, dims 16 s + 8 (lane / 32) .. + 7, planes hi | lo
+  const int hh = lane >> 5;
+  const uint4* aqb = aeq + (size_t)b * N * 8;  // 8 x 16 bytes per pixel: [plane][octet]
+  codd_bf16x8 bh[2][2], bl[2][2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int p = 32 * q + (lane & 31), px = tx0 + (p & 7), py = ty0 + (p >> 3);
+    const uint4* pp = aqb + (size_t)((px < w && py < h) ? py * w + px : 0) * 8 + hh;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bh[q][s] = __builtin_bit_cast(codd_bf16x8, pp[2 * s]);
+      bl[q][s] = __builtin_bit_cast(codd_bf16x8, pp[4 + 2 * s]);
+    }
+  }
+  const int nb = (lane & 3) + 4 * ((lane & 31) >> 3);  // neighbour (of a block of 16) this lane's A row carries
+
+  float H00 = 0.f, H11 = 0.f, b0 = 0.f, b1 = 0.f, b4z = 0.f;
+  v2f h02 = {0.f, 0.f}, h04 = h02, h12 = h02, h14 = h02, h22 = h02, h24 = h02, h32 = h02, h34 = h02, h44 = h02, h54 = h02;
+  v2f b23 = h02, b45 = h02;
+  const float nfy = -fy;
+  // running (row, column) of the next neighbour of this wave's piece [s0, s1) of the row-major list
+  int yj = ylo + s0 / ncols, xj = xlo + s0 % ncols;
+
+  for (int blk = s0; blk < s1; blk += 16) {
+    gn_f32x16 acc0, acc1;
+    {
+      const int idx = min(blk + nb, s1 - 1);
+      const int ay = idx / ncols, ax = idx - ay * ncols;
+      const uint4* ap = aqb + (size_t)((ylo + ay) * w + xlo + ax) * 8 + hh;
+      const codd_bf16x8 ah0 = __builtin_bit_cast(codd_bf16x8, ap[0]), ah1 = __builtin_bit_cast(codd_bf16x8, ap[2]);
+      const codd_bf16x8 al0 = __builtin_bit_cast(codd_bf16x8, ap[4]), al1 = __builtin_bit_cast(codd_bf16x8, ap[6]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+      // small terms first; the two accumulators alternate
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh[0][0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh[1][0], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh[0][1], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh[1][1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl[0][0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl[1][0], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl[0][1], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl[1][1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh[0][0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh[1][0], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh[0][1], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh[1][1], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (blk + r < s1) {  // (wave-uniform)
+        const float dot = hh ? acc1[r] : acc0[r];
+        const bool rowin = vi && (unsigned)(yj - yim) <= twor;
+        const float4* rp4 = (const float4*)(rec + ((size_t)yj * w + xj) * GN_JS);
+        const float4 r8 = rp4[8], r9 = rp4[9], r10 = rp4[10];  // scalar loads (wave-uniform address)
+        const float Xx = r8.x, Xy = r8.y, Xz = r8.z;
+        const float Yz = fmaf(c0.z, Xx, fmaf(c1.z, Xy, fmaf(c2.z, Xz, Ti.t.z)));
+        const bool in = rowin && (unsigned)(xj - xim) <= twor && Xz >= MIN_DEPTH && Yz >= MIN_DEPTH;
+        const float d2 = fmaxf(fmaf(-2.f, dot, ai2 + r10.y), 0.f);
+        const float a = in ? __builtin_amdgcn_rcpf(1.f + __expf(d2)) : 0.f;  // sigmoid(-d2), masked
+        if (++xj > xhi) { xj = xlo; ++yj; }
+#ifndef GN_NO_SKIP
+        if (__ballot(a > 1e-9f) == 0ull) continue;
+#endif
+        const float Yx = fmaf(c0.x, Xx, fmaf(c1.x, Xy, fmaf(c2.x, Xz, Ti.t.x)));
+        const float Yy = fmaf(c0.y, Xx, fmaf(c1.y, Xy, fmaf(c2.y, Xz, Ti.t.y)));
+        const float d = __builtin_amdgcn_rcpf(fmaxf(Yz, MIN_DEPTH));
+        const float xn = Yx * d, yn = Yy * d;
+        const float fxd = fx * d, fyd = fy * d, xy = xn * yn, fxx = fx * xn, fyy = fy * yn;
+        const v2f Jx23 = {-fxd * xn, -fx * xy}, Jx45 = {fmaf(fxx, xn, fx), -fx * yn};
+        const v2f Jy23 = {-fyd * yn, fmaf(-fyy, yn, nfy)}, Jy45 = {fy * xy, fy * xn};
+        const v2f Jz23 = {-d * d, -yn * d}, Jz45 = {xn * d, 0.f};
+        const float rx = r8.w - (fxx + cx), ry = r9.x - (fyy + cy), rz = r9.y - d;
+        const float wx = a * r9.z, wy = a * r9.w, wz = a * r10.x;
+        const float wJx0 = wx * fxd, wJy1 = wy * fyd, wJz4 = wz * Jz45.x;
+        const v2f wJx23 = wx * Jx23, wJx45 = wx * Jx45, wJy23 = wy * Jy23, wJy45 = wy * Jy45, wJz23 = wz * Jz23;
+        H00 = fmaf(wJx0, fxd, H00);
+        h02 = GN_PK((v2f)(wJx0), Jx23, h02);
+        h04 = GN_PK((v2f)(wJx0), Jx45, h04);
+        H11 = fmaf(wJy1, fyd, H11);
+        h12 = GN_PK((v2f)(wJy1), Jy23, h12);
+        h14 = GN_PK((v2f)(wJy1), Jy45, h14);
+        h22 = GN_PK((v2f)(wJx23.x), Jx23, h22); h22 = GN_PK((v2f)(wJy23.x), Jy23, h22); h22 = GN_PK((v2f)(wJz23.x), Jz23, h22);
+        h24 = GN_PK((v2f)(wJx23.x), Jx45, h24); h24 = GN_PK((v2f)(wJy23.x), Jy45, h24); h24 = GN_PK((v2f)(wJz23.x), Jz45, h24);
+        h32 = GN_PK((v2f)(wJx23.y), Jx23, h32); h32 = GN_PK((v2f)(wJy23.y), Jy23, h32); h32 = GN_PK((v2f)(wJz23.y), Jz23, h32);
+        h34 = GN_PK((v2f)(wJx23.y), Jx45, h34); h34 = GN_PK((v2f)(wJy23.y), Jy45, h34); h34 = GN_PK((v2f)(wJz23.y), Jz45, h34);
+        h44 = GN_PK((v2f)(wJx45.x), Jx45, h44); h44 = GN_PK((v2f)(wJy45.x), Jy45, h44); h44 = GN_PK((v2f)(wJz4), Jz45, h44);
+        h54 = GN_PK((v2f)(wJx45.y), Jx45, h54); h54 = GN_PK((v2f)(wJy45.y), Jy45, h54);
+        b0 = fmaf(wJx0, rx, b0);
+        b1 = fmaf(wJy1, ry, b1);
+        b23 = GN_PK(wJx23, (v2f)(rx), b23); b23 = GN_PK(wJy23, (v2f)(ry), b23); b23 = GN_PK(wJz23, (v2f)(rz), b23);
+        b45 = GN_PK(wJx45, (v2f)(rx), b45); b45 = GN_PK(wJy45, (v2f)(ry), b45);
+        b4z = fmaf(wJz4, rz, b4z);
+      }
+    }
+  }
+  const float Hs[27] = {H00, 0.f, h02.x, h02.y, h04.x, h04.y, H11, h12.x, h12.y, h14.x, h14.y, h22.x, h22.y, h24.x,
+                        h24.y, h32.y, h34.x, h34.y, h44.x, h44.y, h54.y, b0, b1, b23.x, b23.y, b45.x + b4z, b45.y};
+#pragma unroll
+  for (int k = 0; k < 27; ++k) red[wave][k][lane] = Hs[k];
+  __syncthreads();
+  float* pp = part + (((size_t)b * ntiles + tile) * gmax + g) * 27 * 64 + lane;
+  for (int k = wave; k < 27; k += GN_WAVES)
+    pp[k * 64] = ((red[0][k][lane] + red[1][k][lane]) + red[2][k][lane]) + red[3][k][lane];
+}
+
 // Damp, solve (Cholesky, fp64) and retract the 64 pixels of one tile from its summed normal equations sums[27][64]
 // (one wave; lane = pixel).
 static __device__ __forceinline__ void gn_solve_tile(float* __restrict__ T, const float (*sums)[64], int lane, int b,
@@ -880,14 +1047,25 @@ static inline int gn_gmax(int radius) {
   return gn_groups(NC * NC, gn_q4(), 1 << 20);
 }
 
-extern "C" long long codd_se3_gn_scratch(int B, int h, int w, int radius) {
+// floats of scratch in front of the split-bf16 embedding planes (16-byte aligned)
+static inline size_t gn_aeq_offset(int B, int h, int w, int radius) {
   const int ntiles = cdiv(w, 8) * cdiv(h, 8);
-  return (long long)B * ntiles * gn_gmax(radius) * 27 * 64 + (long long)B * h * w * GN_JS + (long long)B * ntiles;
+  const size_t n = (size_t)B * ntiles * gn_gmax(radius) * 27 * 64 + (size_t)B * h * w * GN_JS + (size_t)B * ntiles;
+  return (n + 3) & ~(size_t)3;
 }
-// [partials | neighbour records | per-tile arrival counters]
+extern "C" long long codd_se3_gn_scratch(int B, int h, int w, int radius) {
+  return (long long)gn_aeq_offset(B, h, w, radius) + (long long)B * h * w * GN_AQ;
+}
+// [partials | neighbour records | per-tile arrival counters | split-bf16 embeddings (MFMA builder)]
 static inline int* gn_counters(float* Hb, int B, int h, int w, int radius) {
   const int ntiles = cdiv(w, 8) * cdiv(h, 8);
   return (int*)(Hb + (size_t)B * ntiles * gn_gmax(radius) * 27 * 64 + (size_t)B * h * w * GN_JS);
+}
+static inline bool gn_mfma() {
+  // A/B (dev), OFF: 1 = se3_gn_build2_kernel (dot products on the bf16 matrix pipe).  Measured (DESIGN finding 38):
+  // 15 % fewer VALU instructions per neighbour, 116.9 against 118.5 us -- the builder is not bound by its VALU count
+  static const bool f = getenv("CODD_GN_MFMA") && atoi(getenv("CODD_GN_MFMA")) == 1;
+  return f;
 }
 static inline bool gn_fused_solve() {
   // dev A/B, OFF: measured 85.2-86.4 against 86.1-87.3 frames/s for the separate solve launch (DESIGN finding 24)
@@ -908,8 +1086,12 @@ static int gn_build_solve(float* T, int B, int h, int w, float fx, float fy, flo
     CODD_LAUNCH_CHECK();
     return CODD_OK;
   }
-  se3_gn_build_kernel<false><<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, s>>>(T, jd, h, w, fx, fy, cx, cy, radius, tiles_x,
-                                                                             ntiles, q4, gmax, part, cnt, lm, ep);
+  if (gn_mfma())
+    se3_gn_build2_kernel<<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, s>>>(
+        T, jd, (const uint4*)(Hb + gn_aeq_offset(B, h, w, radius)), h, w, fx, fy, cx, cy, radius, tiles_x, ntiles, q4, gmax, part);
+  else
+    se3_gn_build_kernel<false><<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, s>>>(T, jd, h, w, fx, fy, cx, cy, radius, tiles_x,
+                                                                               ntiles, q4, gmax, part, cnt, lm, ep);
   CODD_LAUNCH_CHECK();
   se3_gn_solve_kernel<<<dim3(ntiles, B), 64 * GN_SOLVE_WAVES, 0, s>>>(T, part, h, w, radius, tiles_x, ntiles, q4, gmax, lm, ep);
   CODD_LAUNCH_CHECK();
@@ -925,7 +1107,8 @@ extern "C" int codd_se3_gn_step(float* T, const float* ae, int ae_c, const float
   float* jd = Hb + (size_t)B * ntiles * gn_gmax(radius) * 27 * 64;
   hipStream_t s = (hipStream_t)stream;
   se3_gn_prep_kernel<<<dim3(cdiv(h * w, 128), B), 128, 0, s>>>(ae, ae_c, xyz, delta, weight, depth1, h, w, fx, fy, cx,
-                                                             cy, jd, gn_counters(Hb, B, h, w, radius), ntiles);
+                                                             cy, jd, gn_counters(Hb, B, h, w, radius), ntiles,
+                                                             (unsigned short*)(Hb + gn_aeq_offset(B, h, w, radius)));
   CODD_LAUNCH_CHECK();
   return gn_build_solve(T, B, h, w, fx, fy, cx, cy, radius, lm, ep, Hb, s);
 }
@@ -941,7 +1124,8 @@ extern "C" int codd_se3_gn_step_heads(float* T, codd_xs_view hidden, const void*
   float* jd = Hb + (size_t)B * ntiles * gn_gmax(radius) * 27 * 64;
   hipStream_t s = (hipStream_t)stream;
   gn_heads_prep_kernel<<<dim3(cdiv(h * w, 16), B), 64, 0, s>>>(hidden, (const uint4*)head_w, head_b, xyz, depth1, h, w, fx, fy, cx, cy,
-                                                               jd, weight_out, gn_counters(Hb, B, h, w, radius), ntiles);
+                                                               jd, weight_out, gn_counters(Hb, B, h, w, radius), ntiles,
+                                                               (unsigned short*)(Hb + gn_aeq_offset(B, h, w, radius)));
   CODD_LAUNCH_CHECK();
   return gn_build_solve(T, B, h, w, fx, fy, cx, cy, radius, lm, ep, Hb, s);
 }

@@ -1041,3 +1041,39 @@ def test_hrmodule_fused_sum_equals_per_term_launches():
         ops.set_conv_precision(prev)
     for a, b in zip(outs[False], outs[True]):
         assert a.shape == b.shape and (a - b).abs().max().item() < 1e-4 * max(1.0, a.abs().max().item())
+
+
+def test_se3_gn_step_mfma_builder_matches_scalar_builder():
+    """se3_gn_build2_kernel (CODD_GN_MFMA=1: affinity dot products as split-bf16 MFMA Gram blocks) against the default
+    scalar builder on the same inputs, in a child process (the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+from codd_amd import ops
+g = torch.Generator().manual_seed(3)
+B, h, w = 1, 37, 61
+T = torch.zeros(B, h, w, 7); T[..., 6] = 1; T[..., :3] = torch.randn(B, h, w, 3, generator=g) * 0.02
+d1 = torch.rand(B, h, w, generator=g) * 30 + 3
+ae = torch.randn(B, 32, h, w, generator=g) * 3
+xyz = torch.rand(B, h, w, 3, generator=g) * 40
+delta = torch.randn(B, 3, h, w, generator=g) * 0.2
+wgt = torch.sigmoid(torch.randn(B, 3, h, w, generator=g))
+Tg = T.cuda()
+ops.se3_gn_step(Tg, ae.cuda(), xyz.cuda(), delta.cuda(), wgt.cuda(), d1.cuda(), [40.0, 42.0, w / 2.0, h / 2.0], radius=9)
+torch.save(Tg.cpu(), sys.argv[1])
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("0", "1"):
+        path = os.path.join(root, "gpurun_out", f"_gn_mfma_{flag}.pt")
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        subprocess.run([sys.executable, "-c", code, path], cwd=root, env=dict(os.environ, CODD_GN_MFMA=flag), check=True, timeout=300)
+        outs.append(torch.load(path))
+        os.remove(path)
+    step = (outs[0][..., :3]).abs().max().item()
+    err = (outs[0] - outs[1]).abs().max().item()
+    print("scalar vs MFMA builder: max |delta T|", err, "step", step)
+    assert err < 1e-4 * max(1.0, step)
