@@ -108,6 +108,7 @@ SIGNATURES = {
     "codd_cvx_upsample": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "codd_cvx_upsample_se3_weight": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p]),
     "codd_disp_to_depth": (_i, [_p, _ll, _f, _p, _p]),
+    "codd_subsample": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "codd_splat": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f,
                         _p, _p, _p, _p]),
     "codd_splat_scratch": (_ll, [_i, _i, _i, _f]),

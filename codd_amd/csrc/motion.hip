@@ -1285,6 +1285,28 @@ extern "C" int codd_disp_to_depth(const float* disp, long long n, float bf, floa
   return CODD_OK;
 }
 
+// out[b][y][x] = in[b][oy + step y][ox + step x]: the 1/8-resolution depth samples of RAFT3D (`depth[:, 3::8, 3::8]`,
+// reference raft3d.py:213-216) as a kernel of this library (a strided torch copy inside the captured frame otherwise)
+__global__ void subsample_kernel(const float* __restrict__ in, int H, int W, int oy, int ox, int step, int h, int w,
+                                 float* __restrict__ out, long long n) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int x = (int)(e % w);
+  const long long t = e / w;
+  const int y = (int)(t % h);
+  const long long b = t / h;
+  out[e] = in[(b * H + oy + (long long)step * y) * W + ox + step * x];
+}
+
+extern "C" int codd_subsample(const float* in, int B, int H, int W, int oy, int ox, int step, float* out, void* stream) {
+  if (!in || !out || B < 1 || H < 1 || W < 1 || step < 1 || oy < 0 || ox < 0 || oy >= H || ox >= W) return CODD_EINVAL;
+  const int h = (H - oy + step - 1) / step, w = (W - ox + step - 1) / step;
+  const long long n = (long long)B * h * w;
+  subsample_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(in, H, W, oy, ox, step, h, w, out, n);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Forward splat (Motion.transform_and_project, reference motion.py:82-130).
 //   count   (per source point): project, store (u, v, z); count the point on every covered pixel;

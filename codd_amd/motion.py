@@ -496,8 +496,8 @@ class RAFT3D(ops.RuntimeState, nn.Module):
             fmap_curr = self.fnet(image_curr)
         pyr = pre[1] if pre is not None and pre[0] is fmap_prev else ops.allpairs_corr(fmap_prev, fmap_curr)
         net, inp = ops.context_split(net_inp)
-        d1 = depth_prev[:, 3::8, 3::8].contiguous()
-        d2 = depth_curr[:, 3::8, 3::8].contiguous()
+        d1 = ops.subsample(depth_prev.contiguous(), 3, 3, 8)  # depth[:, 3::8, 3::8] (raft3d.py:213-216)
+        d2 = ops.subsample(depth_curr.contiguous(), 3, 3, 8)
         mask = weight = zr = None
         cxs, mxs = self.update_block.input_buffers(net)
         for it in range(iters):

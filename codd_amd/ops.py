@@ -1439,6 +1439,25 @@ def disp_to_depth(disp, bf):
     return out
 
 
+def subsample(x, oy, ox, step):
+    """x[:, oy::step, ox::step] of a contiguous [B, H, W] map as a kernel of this library."""
+    lib = _abi.load()
+    _require_gpu(x)
+    B, H, W = x.shape
+    assert x.is_contiguous() and x.dtype == torch.float32
+    out = torch.empty(B, -(-(H - oy) // step), -(-(W - ox) // step), device=x.device, dtype=torch.float32)
+    _abi.check(lib.codd_subsample(x.data_ptr(), B, H, W, oy, ox, step, out.data_ptr(), _stream()), "subsample")
+    return out
+
+
+def batch_pair(a, b):
+    """torch.cat([a, b], 0) of two contiguous fp32 tensors of one shape as ONE copy kernel of this library."""
+    assert a.shape == b.shape and a.dtype == b.dtype == torch.float32
+    out = torch.empty((2 * a.shape[0],) + tuple(a.shape[1:]), device=a.device, dtype=torch.float32)
+    copy_many([(out[:a.shape[0]], a.contiguous()), (out[a.shape[0]:], b.contiguous())])
+    return out
+
+
 def splat(T, depth, featA, featB, with_flow, H, W, oy, ox, ds, K, radius, bf=0.0):
     """T [B,HT,WT,7], depth [B,HT,WT] sampled at (oy+ds*y, ox+ds*x) -> (out [B,C,H,W], z [B,1,H,W])."""
     lib = _abi.load()

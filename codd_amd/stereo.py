@@ -459,7 +459,7 @@ class HITNetMF(ops.RuntimeState, nn.Module):
         scale-by-scale (events) -- ONE branch, one join."""
         B, dev = left_img.shape[0], left_img.device
         ti, tu = self.tile_init, self.tile_update
-        g = self.backbone.stages(torch.cat([left_img, right_img], 0))
+        g = self.backbone.stages(ops.batch_pair(left_img, right_img))
         feas = [next(g), next(g)]  # 1/16, 1/8 (on the caller's stream)
         L, R = (lambda i: feas[i][:B]), (lambda i: feas[i][B:])
         rt = self.__dict__.get("_pipe")
@@ -495,7 +495,7 @@ class HITNetMF(ops.RuntimeState, nn.Module):
             with ops.stage("stereo"):
                 return self._stereo_matching_pipelined(left_img, right_img)
         with ops.stage("stereo"):  # exact-fp32 convs: the disparity itself flows through these layers (ops.stage)
-            pyr = self.extract_feat(torch.cat([left_img, right_img], 0))
+            pyr = self.extract_feat(ops.batch_pair(left_img, right_img))
             fea_l = [p[:B] for p in pyr]
             fea_r = [p[B:] for p in pyr]
             self.tile_init.fork_streams = getattr(self, "fork_streams", True)

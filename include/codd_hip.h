@@ -372,6 +372,9 @@ int codd_cvx_upsample_se3_weight(const float* T, const float* weight, const floa
 
 /* disparity -> depth (motion.py:154-165): depth = clip(bf / (disp + 1e-5), 0, 210). */
 int codd_disp_to_depth(const float* disp, long long n, float bf, float* depth, void* stream);
+/* out[b][y][x] = in[b][oy + step*y][ox + step*x], out is [B][ceil((H-oy)/step)][ceil((W-ox)/step)]: RAFT3D's
+ * 1/8-resolution depth samples `depth[:, 3::8, 3::8]` (reference model/motion/raft3d/raft3d.py:213-216). */
+int codd_subsample(const float* in, int B, int H, int W, int oy, int ox, int step, float* out, void* stream);
 
 /* Forward splat of the previous state into the current frame (Motion.transform_and_project,
  * motion.py:82-130 = pytorch3d PointsRasterizer(K=8) + AlphaCompositor) fused with
