@@ -55,6 +55,7 @@ struct ConvB {
   int wslots;                     // slots of one (channel group, chunk) weight image = planes * wplane16
   int tiles_x, tiles_y, ncog, cout_eff;
   int khe;                        // tap rows of one tap set (kh, or kh / 2 with a dual tap set)
+  int gpf;                        // gate epilogues: 1 = prefetch the channel-quad operands per pixel unit (A/B: CODD_GATE_PREFETCH)
   int xcd;                        // 1: XCD-contiguous work-item walk (workgroup b, placed on XCD b % 8, takes a
                                   // contiguous range of tiles of one channel group: conv_kernel.h conv_xcd_item)
 };
@@ -158,6 +159,12 @@ static inline int convb_geometry(const codd_conv_params* pp, ConvB& k, size_t& l
   {  // dev switch CODD_CONVB_XCD=0|1 (minimum grid CODD_CONVB_XCD_MIN)
     static const int xcd_on = getenv("CODD_CONVB_XCD") ? atoi(getenv("CODD_CONVB_XCD")) : 0;
     static const int xcd_min = getenv("CODD_CONVB_XCD_MIN") ? atoi(getenv("CODD_CONVB_XCD_MIN")) : 16;
+    {
+      // (dev A/B, OFF: 95.9 against 95.9 frames/s in one session -- the gate operands' latency is not what the
+      // 28 us of the gate-input convolution are made of)
+      static const int gpf = getenv("CODD_GATE_PREFETCH") ? atoi(getenv("CODD_GATE_PREFETCH")) : 0;
+      k.gpf = gpf;
+    }
     k.xcd = grid >= xcd_min ? xcd_on : 0;  // bit 0: XCD-contiguous walk, bit 1: channel group fastest
   }
   return CODD_OK;
@@ -480,42 +487,6 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
     const int orec = p.xso_hp * p.xso_wp;
     uint4* xo = (uint4*)p.xso + (size_t)b * (p.xso_terms == 3 ? 2 : 1) * p.xso_c8 * orec;
     const bool odd = g & 1;
-    // Gate epilogues (gate = 2 | 3): ALL channel-quad operands of the wave's A x B tiles are requested up front, in
-    // straight-line code with clamped (always valid) addresses -- up to 3 x A x B 16-byte loads in flight, ONE exposed
-    // L2 / HBM latency -- instead of load -> wait -> use per operand and tile (18 dependent round trips on the
-    // 3 x 2-tile configuration of the gate-input convolution: 28 us for a layer whose traffic is worth 11 us)
-    f32x4 gt1[A][B], gt2[A][B], gt3[A][B];
-    if (p.gate >= 2) {
-      const int hw_ = p.Hout * p.Wout;
-      const int G = p.gate == 2 ? k.cout_eff / 3 : k.cout_eff;
-      auto c4p = [&](const float* base, int ctot, int c, int pix) {
-        return (const f32x4*)(base + (((size_t)b * (ctot >> 2) + (c >> 2)) * hw_ + pix) * 4);
-      };
-#pragma unroll
-      for (int a = 0; a < A; ++a) {
-        const int u = pgi * A + a;
-        const int prow = u / k.xb;
-        const int oyc = min(ty * k.th + prow, p.Hout - 1);
-        const int oxc = min(tx * k.tw + (u - prow * k.xb) * 16 + j, p.Wout - 1);
-        const int pixc = oyc * p.Wout + oxc;
-#pragma unroll
-        for (int m = 0; m < B; ++m) {
-          gt1[a][m] = gt2[a][m] = gt3[a][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (KS == 2 && ((a * B + m) & 1) != kpart) continue;
-          const int co0 = min((cog * CGW * B + cgi * B + m) * 16 + 4 * g, k.cout_eff - 4);
-          const int ctile = co0 & ~15;  // (wave-uniform class of the tile)
-          if (p.gate == 2) {
-            gt1[a][m] = *c4p(p.res1.ptr, p.res1.ctot, p.res1.coff + co0, pixc);
-            if (ctile < 2 * G) gt2[a][m] = *c4p(p.res2.ptr, p.res2.ctot, p.res2.coff + co0, pixc);
-            if (ctile >= G && ctile < 2 * G) gt3[a][m] = *c4p(p.post.ptr, p.post.ctot, p.post.coff + co0 - G, pixc);
-          } else {
-            gt1[a][m] = *c4p(p.res1.ptr, p.res1.ctot, p.res1.coff + G + co0, pixc);
-            gt2[a][m] = *c4p(p.res1.ptr, p.res1.ctot, p.res1.coff + co0, pixc);
-            gt3[a][m] = *c4p(p.post.ptr, p.post.ctot, p.post.coff + co0, pixc);
-          }
-        }
-      }
-    }
 #pragma unroll
     for (int a = 0; a < A; ++a) {
       const int u = pgi * A + a;
@@ -523,6 +494,36 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
       const int oy = ty * k.th + prow;
       const int ox = tx * k.tw + (u - prow * k.xb) * 16 + j;
       const bool inb = u < k.pu && oy < p.Hout && ox < p.Wout;
+      // Gate epilogues (gate = 2 | 3): the channel-quad operands of this pixel unit's B tiles are requested together,
+      // in straight-line code with clamped (always valid) addresses -- 3 B 16-byte loads in flight, one exposed
+      // L2 / HBM latency per unit -- instead of load -> wait -> use per operand and tile.  (All A x B tiles at once
+      // costs 12 A B registers and the K loop its occupancy: 34.8 -> 40.8 us on the 5 x 2-tile configuration.)
+      f32x4 gt1[B], gt2[B], gt3[B];
+#pragma unroll
+      for (int m = 0; m < B; ++m) gt1[m] = gt2[m] = gt3[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.gate >= 2 && k.gpf) {
+        const int hw_ = p.Hout * p.Wout;
+        const int G = p.gate == 2 ? k.cout_eff / 3 : k.cout_eff;
+        const int pixc = min(oy, p.Hout - 1) * p.Wout + min(ox, p.Wout - 1);
+        auto c4p = [&](const float* base, int ctot, int c) {
+          return (const f32x4*)(base + (((size_t)b * (ctot >> 2) + (c >> 2)) * hw_ + pixc) * 4);
+        };
+#pragma unroll
+        for (int m = 0; m < B; ++m) {
+          if (KS == 2 && ((a * B + m) & 1) != kpart) continue;
+          const int co0 = min((cog * CGW * B + cgi * B + m) * 16 + 4 * g, k.cout_eff - 4);
+          const int ctile = co0 & ~15;  // (wave-uniform class of the tile)
+          if (p.gate == 2) {
+            gt1[m] = *c4p(p.res1.ptr, p.res1.ctot, p.res1.coff + co0);
+            if (ctile < 2 * G) gt2[m] = *c4p(p.res2.ptr, p.res2.ctot, p.res2.coff + co0);
+            if (ctile >= G && ctile < 2 * G) gt3[m] = *c4p(p.post.ptr, p.post.ctot, p.post.coff + co0 - G);
+          } else {
+            gt1[m] = *c4p(p.res1.ptr, p.res1.ctot, p.res1.coff + G + co0);
+            gt2[m] = *c4p(p.res1.ptr, p.res1.ctot, p.res1.coff + co0);
+            gt3[m] = *c4p(p.post.ptr, p.post.ctot, p.post.coff + co0);
+          }
+        }
+      }
 #pragma unroll
       for (int m = 0; m < B; ++m) {
         if (KS == 2 && ((a * B + m) & 1) != kpart) continue;  // the k-split partner's tile
@@ -550,22 +551,30 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
           }
           const int G = p.gate == 2 ? k.cout_eff / 3 : k.cout_eff;
           if (p.gate == 2) {
-            v += gt1[a][m];  // (operands prefetched above; dead lanes never store)
+            if (k.gpf) v += gt1[m];  // (operands prefetched above; dead lanes never store)
+            else if (live) v += *c4(p.res1.ptr, p.res1.ctot, p.res1.coff + co0);
             if (ctile >= 2 * G) {  // q's input stream
               if (live) *c4(p.out, p.out_ctot, p.out_coff + co0 - G) = v;
               continue;
             }
-            v += gt2[a][m];
+            if (k.gpf) v += gt2[m];
+            else if (live) v += *c4(p.res2.ptr, p.res2.ctot, p.res2.coff + co0);
             v = convb_act_slow(v, CODD_ACT_SIGMOID);
             if (ctile < G) {  // z
               if (live) *c4(p.out, p.out_ctot, p.out_coff + co0) = v;
               continue;
             }
             rco = co0 - G;  // r * h -> records
-            v *= gt3[a][m];
+            if (k.gpf) v *= gt3[m];
+            else if (live) v *= *c4(p.post.ptr, p.post.ctot, p.post.coff + rco);
           } else {
-            v += gt1[a][m];
-            const f32x4 z = gt2[a][m], h = gt3[a][m];
+            f32x4 z = gt2[m], h = gt3[m];
+            if (k.gpf) v += gt1[m];
+            else if (live) {
+              v += *c4(p.res1.ptr, p.res1.ctot, p.res1.coff + G + co0);
+              z = *c4(p.res1.ptr, p.res1.ctot, p.res1.coff + co0);
+              h = *c4(p.post.ptr, p.post.ctot, p.post.coff + co0);
+            }
             v = convb_act_slow(v, CODD_ACT_TANH);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = (1.f - z[r]) * h[r] + z[r] * v[r];
