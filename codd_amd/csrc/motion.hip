@@ -650,7 +650,7 @@ template <bool FUSE>
 __global__ __launch_bounds__(64 * GN_WAVES) void se3_gn_build_kernel(
     float* T, const float* __restrict__ jd, int h, int w, float fx, float fy, float cx, float cy,
     int radius, int tiles_x, int ntiles, int q4, int gmax, float* part, int* cnt, float lm, float ep) {
-  __shared__ float red[GN_WAVES][27][64];
+  __shared__ float red[FUSE ? GN_WAVES : 1][27][64];
   __shared__ int s_last;
   const int N = h * w;
   const int lane = threadIdx.x & 63;
@@ -758,14 +758,25 @@ __global__ __launch_bounds__(64 * GN_WAVES) void se3_gn_build_kernel(
   // combine the workgroup's 4 partial sums in a fixed order, one [27][64] partial per workgroup
   const float Hs[27] = {H00, 0.f, h02.x, h02.y, h04.x, h04.y, H11, h12.x, h12.y, h14.x, h14.y, h22.x, h22.y, h24.x,
                         h24.y, h32.y, h34.x, h34.y, h44.x, h44.y, h54.y, b0, b1, b23.x, b23.y, b45.x + b4z, b45.y};
-#pragma unroll
-  for (int k = 0; k < 27; ++k) red[wave][k][lane] = Hs[k];
-  __syncthreads();
   float* pp = part + (((size_t)b * ntiles + tile) * gmax + g) * 27 * 64 + lane;
   if constexpr (!FUSE) {
-    for (int k = wave; k < 27; k += GN_WAVES)
-      pp[k * 64] = ((red[0][k][lane] + red[1][k][lane]) + red[2][k][lane]) + red[3][k][lane];
+    // wave w adds its sums into ONE [27][64] LDS image after wave w - 1 (same order, same bits as
+    // ((s0 + s1) + s2) + s3 over four images): 6.9 KB instead of 27.6 KB per workgroup, so that four resident
+    // builder workgroups leave 132 KB of a CU's LDS to a co-scheduled convolution (finding 41)
+    float (*acc_)[64] = red[0];
+#pragma unroll
+    for (int w_ = 0; w_ < GN_WAVES; ++w_) {
+      if (wave == w_) {
+#pragma unroll
+        for (int k = 0; k < 27; ++k) acc_[k][lane] = w_ == 0 ? Hs[k] : acc_[k][lane] + Hs[k];
+      }
+      __syncthreads();
+    }
+    for (int k = wave; k < 27; k += GN_WAVES) pp[k * 64] = acc_[k][lane];
   } else {
+#pragma unroll
+    for (int k = 0; k < 27; ++k) red[wave][k][lane] = Hs[k];
+    __syncthreads();
     // Device-scope hand-over WITHOUT fences (an agent-scope fence writes back / invalidates the whole L2 of the XCD --
     // measured: +280 us per step, every other workgroup loses its cached neighbour records): the partials are written
     // through (relaxed agent-scope stores = sc1), each wave waits for its own stores, the workgroup's arrival is
