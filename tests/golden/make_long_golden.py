@@ -7,6 +7,7 @@ selection flipped in frame t feeds every later frame.  The three-frame golden (m
 drift; this file holds the CPU oracle's (oracle/codd.py) disparity for
 
   * cfg3_long  : full CODD 960x576, iters = 16, frames 0 .. 15 of the synthetic video (the bench configuration)
+  * cfg5_long  : full CODD 640x512 (TartanAir shape), iters = 16, frames 0 .. 15
   * cfg5_it1   : full CODD 640x512 (TartanAir shape), iters = 1 -- the value the reference configures for TartanAir
                  (reference configs/models/codd.py:6) -- frames 0 .. 5
 
@@ -38,6 +39,7 @@ SUB = 4
 LONG_CASES = {
     "cfg3_long": ("cfg3_codd_960x576", 16, 16),
     "cfg5_it1": ("cfg5_tartanair_640x512", 1, 6),
+    "cfg5_long": ("cfg5_tartanair_640x512", 16, 16),
 }
 
 

@@ -688,3 +688,38 @@ def test_roll_launches_equal_tile_kernels_in_hitnet():
         ops.USE_ROLL = prev
     d = (a - b).abs()
     assert d.median().item() < 1e-5 and (d > 0.25).float().mean().item() < 1e-4, (d.median().item(), d.max().item())
+
+
+def test_conv_roll_random_shapes():
+    """40 seeded random (mode, C, sources, batch, map size, rows per workgroup) draws of codd_conv_roll against torch
+    fp32 on the CPU -- widths around the 60 / 62-column strip stride, heights around the row-block size, 1-pixel maps."""
+    import random
+    from codd_amd import ops
+    rng = random.Random(1234)
+    for it in range(40):
+        mode = rng.choice([0, 1, 1, 2])
+        C = rng.choice([16, 16, 32])
+        cin = C if mode != 2 else rng.choice([16, 24, 32, 40, 48, 64])
+        B = rng.choice([1, 1, 2])
+        H = rng.choice([1, 2, 3, 5, 8, 13, 21, 34, 47])
+        W = rng.choice([1, 2, 15, 16, 17, 59, 60, 61, 62, 63, 64, 65, 119, 120, 121, 124, 125, 187])
+        rh = rng.choice([1, 2, 3, 4, 7, 12, 50])
+        res = mode == 1 and rng.random() < 0.5
+        c0 = cin if (mode != 2 or rng.random() < 0.3) else rng.choice([c for c in (8, 16, 24, 32) if c < cin])
+        if mode != 2 and rng.random() < 0.3:
+            c0 = rng.choice([4, 8, 12])
+        k0 = 1 if mode == 2 else 3
+        wa, ba = rnd(C, cin, k0, k0, seed=it) / (cin * k0 * k0) ** 0.5, rnd(C, seed=it + 1) * 0.1
+        wb, bb = rnd(C, C, 3, 3, seed=it + 2) / (C * 9) ** 0.5, rnd(C, seed=it + 3) * 0.1
+        x = rnd(B, cin, H, W, seed=it + 4)
+        t = F.leaky_relu(F.conv2d(x, wa, ba, padding=k0 // 2), 0.2)
+        ref = t if mode == 0 else F.leaky_relu(F.conv2d(t, wb, bb, padding=1) + (x if res else 0), 0.2)
+        st = [dict(w=wa.to(dev()), b=ba.to(dev()), act="lrelu")] + ([dict(w=wb.to(dev()), b=bb.to(dev()), act="lrelu")] if mode else [])
+        pr = ops.PackedRoll(st, residual=res)
+        xd = x.to(dev())
+        if c0 < cin:
+            got = ops.conv_roll(xd[:, :c0].contiguous(), pr, x2=xd[:, c0:].contiguous(), rh=rh)
+        else:
+            got = ops.conv_roll(xd, pr, rh=rh)
+        err = (got.cpu() - ref).abs().max().item()
+        assert err < 2e-5 * max(1.0, ref.abs().max().item()), (it, mode, C, cin, c0, B, H, W, rh, res, err)

@@ -9,8 +9,10 @@ import test_gpu_headline_parity as T
 from codd_amd import synth
 from oracle import codd as oc
 
-frames = [int(a) for a in sys.argv[1:]] or [13, 14, 15]
-H, W, intr, _, _, _ = T.CASES["cfg3_codd_960x576"]
+frames = [int(a) for a in sys.argv[1:] if a.isdigit()] or [13, 14, 15]
+CASE = next((a for a in sys.argv[1:] if a in T.CASES), "cfg3_codd_960x576")
+print("case", CASE)
+H, W, intr, _, _, _ = T.CASES[CASE]
 sd = T._build(True)[1]
 img, r_img, _ = synth.stereo_sequence(H, W, max(frames) + 1)
 torch.set_num_threads(max(1, min(os.cpu_count() or 1, 16)))
