@@ -107,6 +107,11 @@ class BasicBlock(nn.Module):
 # BASELINE.json configs[4] across a splat pixel boundary (mean |disparity delta| over all pixels 1.9e-5 -> 2.5e-3 px on
 # frame 1) -- the context features enter all 16 updates
 FUSE_SUM = _os.environ.get("CODD_HR_FUSE_SUM", "0") == "1"
+# round 4: only the SUMMATION of a fuse layer as one launch per output branch, convolutions untouched: 26 launches per
+# frame less and +1.0 % frame rate (every launch of the frame graph costs ~3.8 us of wall clock, DESIGN finding 43) --
+# but the sum kernel rounds one ulp differently from resize-accumulate (fp contraction), and that alone flips
+# configs[4]'s near-camera cluster (2.5e-3 px on frame 1, finding 30): OFF.
+FUSE_TERMS = _os.environ.get("CODD_HR_FUSE_TERMS", "0") == "1"
 
 
 class HRModule(nn.Module):
@@ -201,6 +206,27 @@ class HRModule(nn.Module):
                 level = nxt
             return [ops.hr_fuse_sum([xs[i] if j == i else term[(i, j)] for j in range(nb)], xs[i].shape[2:], relu=True)
                     for i in range(nb)]
+
+        def fuse_terms(i):
+            """Output branch i with the convolutions exactly as below (same launches, same bits) but ONE summation
+            launch (ops.hr_fuse_sum: same bilinear expression, same j order) instead of a resize / add launch per term."""
+            terms = []
+            for j in range(nb):
+                if j == i:
+                    terms.append(xs[j])
+                elif j > i:
+                    f = self.fuse_layers[i][j]
+                    terms.append(cbn(f[0], f[1], xs[j]))
+                else:
+                    t = xs[j]
+                    chain = self.fuse_layers[i][j]
+                    for k, f in enumerate(chain):
+                        t = cbn(f[0], f[1], t, "relu" if k != len(chain) - 1 else "none")
+                    terms.append(t)
+            return ops.hr_fuse_sum(terms, xs[i].shape[2:], relu=True)
+
+        if FUSE_TERMS and fk is None:
+            return [fuse_terms(i) for i in range(nb)]
 
         def fuse(i):
             acc = torch.empty_like(xs[i])

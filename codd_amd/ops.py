@@ -570,6 +570,7 @@ def _db_cfg_ok(lib, p, c, sig):
 
 
 MULTI_CONV = _os.environ.get("CODD_MULTI_CONV", "1") == "1"  # (A/B switch of conv2d_multi)
+MULTI_MB = int(_os.environ.get("CODD_MULTI_MB", "1"))  # 16-channel blocks per workgroup of a multi-job launch (1 | 2)
 # tuner candidates on the persistent quad kernel (layout 3: weights resident in LDS, workgroups walk the tiles).  OFF:
 # measured on MI355X (tools/time_persist.py, profiles/r03_persist_times.log) it LOSES to the per-tile kernel on every
 # big HITNet layer it was written for (16->16 3x3 at 576x960: 59.8 vs 50.5 us; 32->32 at 288x480: 54.4 vs 47.3) --
@@ -619,8 +620,8 @@ def conv2d_multi(jobs):
             p.Cout, p.Hout, p.Wout = pc.cout, Hout, Wout
             p.kh, p.kw, p.sy, p.sx, p.pad_t, p.pad_l, p.dil_y, p.dil_x = pc.kh, pc.kw, st, st, pad, pad, 1, 1
             p.act = ACT[j.get("act", "none")]
-            p.mb, p.npb, p.nw, p.ck, p.layout = 1, 1, 4, ck, 1
-            p.wpacked = pc.packed(ck, 1, 1).data_ptr()
+            p.mb, p.npb, p.nw, p.ck, p.layout = MULTI_MB, 1, 4, ck, 1
+            p.wpacked = pc.packed(ck, MULTI_MB, 1).data_ptr()
             keep.append(out)
         rc = _launch_conv_multi(lib, arr, len(ids), _stream())
         if rc == 0:
