@@ -1674,7 +1674,9 @@ __global__ void hr_fuse_sum_kernel(const HrTerms tm, int C, int Ho, int Wo, int 
       v = (1.f - ly) * ((1.f - lx) * p[y0 * Wi + x0] + lx * p[y0 * Wi + x1]) +
           ly * ((1.f - lx) * p[y1 * Wi + x0] + lx * p[y1 * Wi + x1]);
     }
-    acc = k == 0 ? v : acc + v;
+    // the same bits as the separate launches (resize_bilinear_kernel with accumulate / add_relu_kernel / a convolution's
+    // res1 operand): the term is complete before ONE rounded addition -- never contracted into the blend's last fma
+    acc = k == 0 ? v : __fadd_rn(v, acc);
   }
   out[e] = relu ? fmaxf(acc, 0.f) : acc;
 }
