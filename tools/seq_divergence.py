@@ -17,7 +17,8 @@ from codd_amd.runtime import FrameRunner
 
 DEV = "cuda:0"
 N = int(os.environ.get("N", "16"))
-name = "cfg3_codd_960x576"
+name = os.environ.get("CASE", "cfg3_codd_960x576")
+PREFIX = {"cfg3_codd_960x576": "cfg3_long", "cfg5_tartanair_640x512": "cfg5_long"}[name]
 H, W, intr, img_shape, _, _ = T.CASES[name]
 z = np.load(T.LONG_GOLDEN)
 sub = int(z["sub"])
@@ -80,7 +81,7 @@ if "default" not in want:
     want = ["default"] + want
 variants = {k: ALL[k] for k in want}
 res = {k: run(k, **v) for k, v in variants.items()}
-gold = [torch.from_numpy(z[f"cfg3_long_f{f}"]) for f in range(N)]
+gold = [torch.from_numpy(z[f"{PREFIX}_f{f}"]) for f in range(N)]
 print(f"frames 0..{N - 1}; sub-grid 1/{sub} for the oracle rows, every pixel for the product-vs-product rows")
 for k in res:
     line(f"{k} vs ORACLE (tracked)", [x[::sub, ::sub] for x in res[k]], gold)
