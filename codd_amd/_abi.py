@@ -113,6 +113,7 @@ SIGNATURES = {
                         _p, _p, _p, _p]),
     "codd_splat_scratch": (_ll, [_i, _i, _i, _f]),
     "codd_resize_bilinear": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p]),
+    "codd_resize_bilinear_add": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _p]),
     "codd_add_relu": (_i, [_p, _p, _ll, _i, _p, _p]),
     "codd_hr_fuse_sum": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "codd_copy_many": (_i, [_p, _p, _p, _i, _p]),

@@ -1597,9 +1597,12 @@ extern "C" int codd_induced_flow(const float* T, const float* depth, int B, int 
 // ------------------------------------------------------------------------------------------------
 // HRNet helpers: bilinear resize (torch F.interpolate semantics) and add(+relu).
 // ------------------------------------------------------------------------------------------------
+// ``extra`` (optional, contiguous [B, C, Ho, Wo]): added to the accumulation base before the blend is added --
+// out = relu?((out + extra) + v) / (extra + v): the "+ x_i" term of an HRModule fuse layer without its own launch
+// (the same two rounded additions as an add_relu launch followed by this one)
 __global__ void resize_bilinear_kernel(const float* __restrict__ in, int C, int Hi, int Wi, int Ho, int Wo, int ac,
                                        float* __restrict__ out, int out_ctot, int out_coff, int accumulate, int relu,
-                                       long long total) {
+                                       long long total, const float* __restrict__ extra) {
   long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
   const int x = (int)(e % Wo);
@@ -1622,7 +1625,12 @@ __global__ void resize_bilinear_kernel(const float* __restrict__ in, int C, int 
   float v = (1.f - ly) * ((1.f - lx) * p[y0 * Wi + x0] + lx * p[y0 * Wi + x1]) +
             ly * ((1.f - lx) * p[y1 * Wi + x0] + lx * p[y1 * Wi + x1]);
   float* o = out + ((size_t)b * out_ctot + out_coff + c) * Ho * Wo + (size_t)y * Wo + x;
-  if (accumulate) v += *o;
+  if (extra) {
+    const float xe = extra[e];
+    v += accumulate ? __fadd_rn(*o, xe) : xe;
+  } else if (accumulate) {
+    v += *o;
+  }
   if (relu) v = fmaxf(v, 0.f);
   *o = v;
 }
@@ -1632,7 +1640,18 @@ extern "C" int codd_resize_bilinear(const float* in, int B, int C, int Hi, int W
   if (!in || !out) return CODD_EINVAL;
   const long long total = (long long)B * C * Ho * Wo;
   resize_bilinear_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(in, C, Hi, Wi, Ho, Wo, align_corners, out,
-                                                                            out_ctot, out_coff, accumulate, relu, total);
+                                                                            out_ctot, out_coff, accumulate, relu, total, nullptr);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
+extern "C" int codd_resize_bilinear_add(const float* in, int B, int C, int Hi, int Wi, int Ho, int Wo, int align_corners,
+                                        float* out, int out_ctot, int out_coff, int accumulate, int relu,
+                                        const float* extra, void* stream) {
+  if (!in || !out || !extra) return CODD_EINVAL;
+  const long long total = (long long)B * C * Ho * Wo;
+  resize_bilinear_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(in, C, Hi, Wi, Ho, Wo, align_corners, out,
+                                                                            out_ctot, out_coff, accumulate, relu, total, extra);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }

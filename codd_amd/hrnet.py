@@ -112,6 +112,8 @@ FUSE_SUM = _os.environ.get("CODD_HR_FUSE_SUM", "0") == "1"
 # but the sum kernel rounds one ulp differently from resize-accumulate (fp contraction), and that alone flips
 # configs[4]'s near-camera cluster (2.5e-3 px on frame 1, finding 30): OFF.
 FUSE_TERMS = _os.environ.get("CODD_HR_FUSE_TERMS", "0") == "1"
+FOLD_SELF = _os.environ.get("CODD_HR_FOLD_SELF", "1") == "1"  # (A/B: the "+ x_i" term of a fuse layer without its own launch)
+DEFER_FUSE = _os.environ.get("CODD_HR_DEFER_FUSE", "1") == "1"  # (A/B: fuse-layer convolutions as deferred multi-job launches)
 
 
 class HRModule(nn.Module):
@@ -228,22 +230,66 @@ class HRModule(nn.Module):
         if FUSE_TERMS and fk is None:
             return [fuse_terms(i) for i in range(nb)]
 
+        # Every convolution of the fuse layers that reads branch outputs only -- the 1x1 convolutions of the up paths
+        # (j > i) and all but the last convolution of the down chains (j < i) -- is independent of the others: they are
+        # issued level by level inside ops.deferred_convs() and leave as multi-job launches with the parameters of
+        # their single launches (bit-identical; 33 convolutions of a 4-branch network in ~10 launches).  The
+        # accumulation into the output branch (resize / add / last chain convolution with its res1 operand) keeps its
+        # launches and its j order.
+        pre = {}
+        if fk is None and DEFER_FUSE:
+            level = [(i, j, 0, xs[j]) for i in range(nb) for j in range(nb) if j > i or i - j >= 2]
+            while level:
+                nxt = []
+                with ops.deferred_convs():
+                    for i, j, k, t in level:
+                        if j > i:
+                            f = self.fuse_layers[i][j]
+                            pre[(i, j)] = cbn(f[0], f[1], t)
+                        else:
+                            f = self.fuse_layers[i][j][k]
+                            y = cbn(f[0], f[1], t, "relu")
+                            if k + 2 < i - j:
+                                nxt.append((i, j, k + 1, y))
+                            else:
+                                pre[(i, j)] = y  # input of the chain's last convolution
+                level = nxt
+
         def fuse(i):
             acc = torch.empty_like(xs[i])
+            # the "+ x_i" term has no launch of its own (FOLD_SELF): it rides on the next up-sampling term as its
+            # ``extra`` addend, or -- for the last branch, where it is the last term -- on the last chain convolution
+            # as res2; (acc + x_i) + term / ((conv + acc) + x_i): the same roundings in the same order
+            fold = FOLD_SELF and xs[i].is_contiguous()
+            carry = None
             for j in range(nb):
                 first, last = j == 0, j == nb - 1
                 if j == i:
-                    ops.add_relu(xs[j], None if first else acc, relu=last, out=acc)
+                    if fold and not last:
+                        carry = xs[j]  # added by the next term (j + 1 > i: an up-sampling term)
+                    elif not (fold and last and nb > 1):  # (folded into the previous chain convolution below)
+                        ops.add_relu(xs[j], None if first else acc, relu=last, out=acc)
                 elif j > i:
                     f = self.fuse_layers[i][j]
-                    t = cbn(f[0], f[1], xs[j])
-                    ops.resize_bilinear(t, xs[i].shape[2:], False, out=acc, accumulate=not first, relu=last)
+                    t = pre[(i, j)] if (i, j) in pre else cbn(f[0], f[1], xs[j])
+                    if carry is not None:
+                        ops.resize_bilinear(t, xs[i].shape[2:], False, out=acc, accumulate=j - 1 > 0, relu=last, extra=carry)
+                        carry = None
+                    else:
+                        ops.resize_bilinear(t, xs[i].shape[2:], False, out=acc, accumulate=not first, relu=last)
                 else:
-                    t = xs[j]
                     chain = self.fuse_layers[i][j]
-                    for k, f in enumerate(chain):
+                    if (i, j) in pre:
+                        t, k0 = pre[(i, j)], len(chain) - 1
+                    else:
+                        t, k0 = xs[j], 0
+                    self_next = fold and i == nb - 1 and j == i - 1  # x_i (the last term) rides on this chain's last conv
+                    for k in range(k0, len(chain)):
+                        f = chain[k]
                         if k != len(chain) - 1:
                             t = cbn(f[0], f[1], t, "relu")
+                        elif self_next:
+                            cbn(f[0], f[1], t, "relu", res1=None if first else acc, res2=xs[i], out=acc)
                         else:
                             cbn(f[0], f[1], t, "relu" if last else "none", res1=None if first else acc, out=acc)
             return acc

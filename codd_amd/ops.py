@@ -539,6 +539,10 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
     p.terms = 0
     p.wpacked = pc.packed(ck, mb, 1 if layout == 3 else layout).data_ptr()  # (layout 3 = layout 1 weights, persistent kernel)
     p.mb, p.npb, p.nw, p.ck, p.layout = mb, npb, nw, ck, layout
+    if _DEFERRED is not None and layout == 1 and npb == 1 and nw == 4 and mb == 1:
+        # inside ``with deferred_convs():`` -- recorded, launched on exit together with its independent neighbours
+        _DEFERRED.append((ConvParams.from_buffer_copy(p), (x, x2, res1, res2, post, out, pc)))
+        return out
     rc = _launch_conv(lib, p, _stream())
     if rc == -2:
         # a tuned / loaded configuration this build does not support (e.g. a tune db from another version):
@@ -576,6 +580,42 @@ MULTI_MB = int(_os.environ.get("CODD_MULTI_MB", "1"))  # 16-channel blocks per w
 # big HITNet layer it was written for (16->16 3x3 at 576x960: 59.8 vs 50.5 us; 32->32 at 288x480: 54.4 vs 47.3) --
 # three small workgroups per CU overlap their staging better than one or two persistent ones with a register prefetch
 PERSIST_CONV = _os.environ.get("CODD_PERSIST_CONV", "0") == "1"
+
+
+_DEFERRED = None
+
+
+class deferred_convs:
+    """``with ops.deferred_convs(): ...`` -- exact-fp32 convolutions issued inside the block whose launch configuration is
+    the multi-job class (quad layout, 4 x 16 tiles, 16 channels per workgroup: csrc/conv_quad_kernel.h) are RECORDED with
+    the parameters the single launch would have used and launched on exit, up to four per codd_conv2d_multi launch: the
+    same kernel body on the same parameters, i.e. bit-identical results, and one kernel node instead of up to four (every
+    node of the frame graph costs ~3.8 us of wall clock, DESIGN.md finding 43).  Convolutions of other classes launch at
+    once.  The caller guarantees that the convolutions inside one block do not read one another's results."""
+
+    def __enter__(self):
+        global _DEFERRED
+        self.prev, _DEFERRED = _DEFERRED, []
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFERRED
+        items, _DEFERRED = _DEFERRED, self.prev
+        if exc[0] is not None or not items:
+            return False
+        lib = _abi.load()
+        for k0 in range(0, len(items), 4):
+            chunk = items[k0:k0 + 4]
+            rc = -2
+            if len(chunk) > 1 and MULTI_CONV:
+                arr = (ConvParams * len(chunk))(*[c[0] for c in chunk])
+                rc = _launch_conv_multi(lib, arr, len(chunk), _stream())
+                if rc not in (0, -2):
+                    _abi.check(rc, "codd_conv2d_multi (deferred)")
+            if rc != 0:
+                for pp, _ in chunk:
+                    _abi.check(_launch_conv(lib, pp, _stream()), "codd_conv2d (deferred)")
+        return False
 
 
 def _launch_conv_multi(lib, params, n, stream):
@@ -1502,13 +1542,21 @@ def se3_identity(B, h, w, device):
     return T
 
 
-def resize_bilinear(x, size, align_corners, out=None, accumulate=False, relu=False):
+def resize_bilinear(x, size, align_corners, out=None, accumulate=False, relu=False, extra=None):
+    """``extra`` (contiguous [B, C, Ho, Wo]; ``out`` then a whole tensor): out = relu?((out + extra) + blend) with
+    ``accumulate``, (extra + blend) without -- an add_relu launch folded in with its rounding."""
     lib = _abi.load()
     B, Cc, Hi, Wi = x.shape
     Ho, Wo = size
     if out is None:
         out = _f32(B, Cc, Ho, Wo, like=x)
     os_ = _as_slice(out)
+    if extra is not None:
+        assert extra.is_contiguous() and tuple(extra.shape) == (B, Cc, Ho, Wo) and os_.buf.shape[1] == Cc and os_.coff == 0
+        _abi.check(lib.codd_resize_bilinear_add(x.data_ptr(), B, Cc, Hi, Wi, Ho, Wo, int(align_corners), os_.buf.data_ptr(),
+                                                os_.buf.shape[1], os_.coff, int(accumulate), int(relu), extra.data_ptr(),
+                                                _stream()), "resize_bilinear_add")
+        return out
     _abi.check(lib.codd_resize_bilinear(x.data_ptr(), B, Cc, Hi, Wi, Ho, Wo, int(align_corners), os_.buf.data_ptr(),
                                         os_.buf.shape[1], os_.coff, int(accumulate), int(relu), _stream()),
                "resize_bilinear")

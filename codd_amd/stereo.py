@@ -212,10 +212,15 @@ class TileInitialization(ops.RuntimeState, nn.Module):
         name = _LEVELS[lvl]
         tc = getattr(self, f"tile_conv{name}")
         pc0, pc1 = packed(tc[0]), packed(tc[2])
-        tl = ops.conv2d(ops.conv2d(fl, pc0, stride=4, act="lrelu"), pc1, act="lrelu")
-        # right features: same weights, stride (4,1) on the image zero-padded 3 px on the right
-        tr = ops.conv2d(fr, pc0, stride=(4, 1), pad_tl=(0, 0, 0, 3), act="lrelu")
-        tr = ops.conv2d(tr, pc1, act="lrelu")
+        # left / right tile features are independent chains: convolutions of the same depth leave as ONE multi-job launch
+        # where both are of the multi-job class (ops.deferred_convs: same parameters, same bits)
+        with ops.deferred_convs():
+            tl = ops.conv2d(fl, pc0, stride=4, act="lrelu")
+            # right features: same weights, stride (4,1) on the image zero-padded 3 px on the right
+            tr = ops.conv2d(fr, pc0, stride=(4, 1), pad_tl=(0, 0, 0, 3), act="lrelu")
+        with ops.deferred_convs():
+            tl = ops.conv2d(tl, pc1, act="lrelu")
+            tr = ops.conv2d(tr, pc1, act="lrelu")
         B, _, Ht, Wt = tl.shape
         aug = torch.empty(B, 32 if lvl == 0 else 64, Ht, Wt, device=fl.device, dtype=torch.float32)
         cost = torch.empty(B, 1, Ht, Wt, device=fl.device, dtype=torch.float32)
@@ -326,8 +331,9 @@ class TileUpdate(nn.Module):
         up = Slice(aug, 32, 16)
         ops.hyp_upsample(prev, 2.0, up)
         w0, w1 = ops.tile_warp_cost(fl, fr, hyp, up)
-        cv(self.decrease[0], w0, act="lrelu", out=Slice(aug, 16, 16))
-        cv(self.decrease[0], w1, act="lrelu", out=Slice(aug, 48, 16))
+        with ops.deferred_convs():  # (two independent 1x1 convolutions: one multi-job launch, same bits)
+            cv(self.decrease[0], w0, act="lrelu", out=Slice(aug, 16, 16))
+            cv(self.decrease[0], w1, act="lrelu", out=Slice(aug, 48, 16))
         if ops.use_chain(*aug.shape[2:]):
             pch = chain(self, "update", [(self.conv0[0], dict(src=-1, dst=0, act="lrelu"))] + _rb(self.resblock0[0], 0, 1) +
                         _rb(self.resblock1[0], 0, 1) + [(self.lastconv, dict(src=0, dst=-1))])

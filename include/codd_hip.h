@@ -406,6 +406,13 @@ int codd_se3_identity(float* T, long long npix, void* stream);
  * out view += / = resize(in).  accumulate: 0 overwrite, 1 add; relu applied after. */
 int codd_resize_bilinear(const float* in, int B, int C, int Hi, int Wi, int Ho, int Wo, int align_corners,
                          float* out, int out_ctot, int out_coff, int accumulate, int relu, void* stream);
+/* as codd_resize_bilinear, plus `extra` (contiguous [B, C, Ho, Wo], out_ctot == C, out_coff == 0 expected by the index):
+ * out = relu?((out + extra) + blend) when accumulate, (extra + blend) otherwise -- the "+ x_i" term of an mmseg HRModule
+ * fuse layer (configs/models/codd.py:44-74) folded into the neighbouring up-sampling term, with the roundings of the two
+ * separate launches. */
+int codd_resize_bilinear_add(const float* in, int B, int C, int Hi, int Wi, int Ho, int Wo, int align_corners,
+                             float* out, int out_ctot, int out_coff, int accumulate, int relu, const float* extra,
+                             void* stream);
 
 /* y = relu?(a + b) elementwise (HRNet fuse sums), n floats. */
 int codd_add_relu(const float* a, const float* b, long long n, int relu, float* y, void* stream);

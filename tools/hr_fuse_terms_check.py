@@ -8,17 +8,18 @@ est = T._build(False, 16)[0].to("cuda:0")
 img, _, _ = synth.stereo_sequence(512, 640, 1)
 x = img[:, 0].to("cuda:0")
 r3 = est.motion.raft3d
+FLAG = os.environ.get("FLAG", "FUSE_TERMS")
 logs = {False: [], True: []}
 orig = hrnet.HRModule.run if hasattr(hrnet.HRModule, "run") else hrnet.HRModule.forward
 name = "run" if hasattr(hrnet.HRModule, "run") else "forward"
 def hooked(self, *a, **k):
     out = orig(self, *a, **k)
-    logs[hrnet.FUSE_TERMS].append([o.clone() for o in out])
+    logs[getattr(hrnet, FLAG)].append([o.clone() for o in out])
     return out
 setattr(hrnet.HRModule, name, hooked)
 outs = []
 for flag in (False, True):
-    hrnet.FUSE_TERMS = flag
+    setattr(hrnet, FLAG, flag)
     with ops.stage("context"):
         outs.append(r3.context(x).clone())
 for m, (a, b) in enumerate(zip(logs[False], logs[True])):
