@@ -113,7 +113,8 @@ FUSE_SUM = _os.environ.get("CODD_HR_FUSE_SUM", "0") == "1"
 # configs[4]'s near-camera cluster (2.5e-3 px on frame 1, finding 30): OFF.
 FUSE_TERMS = _os.environ.get("CODD_HR_FUSE_TERMS", "0") == "1"
 FOLD_SELF = _os.environ.get("CODD_HR_FOLD_SELF", "1") == "1"  # (A/B: the "+ x_i" term of a fuse layer without its own launch)
-DEFER_FUSE = _os.environ.get("CODD_HR_DEFER_FUSE", "1") == "1"  # (A/B: fuse-layer convolutions as deferred multi-job launches)
+DEFER_FUSE = _os.environ.get("CODD_HR_DEFER_FUSE", "1") == "1"
+LOCKSTEP_FUSE = _os.environ.get("CODD_HR_LOCKSTEP_FUSE", "1") == "1"  # (A/B: chain-ending convolutions of all branches per j)  # (A/B: fuse-layer convolutions as deferred multi-job launches)
 
 
 class HRModule(nn.Module):
@@ -293,6 +294,41 @@ class HRModule(nn.Module):
                         else:
                             cbn(f[0], f[1], t, "relu" if last else "none", res1=None if first else acc, out=acc)
             return acc
+
+        if fk is None and DEFER_FUSE and LOCKSTEP_FUSE:
+            # all output branches in lockstep over j: term j of every branch at once.  The last convolutions of the down
+            # chains j -> i (i > j) accumulate into DIFFERENT output branches, so they do not depend on one another and
+            # leave as one deferred multi-job launch per j (13 instead of 22 launches per frame); every branch still
+            # sees its terms in j order with the same operands, i.e. the same bits as fuse(i) above.
+            accs = [torch.empty_like(x) for x in xs]
+            folds = [FOLD_SELF and x.is_contiguous() for x in xs]
+            carry = [None] * nb
+            for j in range(nb):
+                first, last = j == 0, j == nb - 1
+                with ops.deferred_convs():
+                    for i in range(j + 1, nb):  # down chains j -> i: the chain's last convolution
+                        chain = self.fuse_layers[i][j]
+                        t = pre[(i, j)] if (i, j) in pre else xs[j]
+                        assert (i, j) in pre or len(chain) == 1
+                        f = chain[-1]
+                        if folds[i] and i == nb - 1 and j == i - 1:  # x_i (the branch's last term) rides along as res2
+                            cbn(f[0], f[1], t, "relu", res1=None if first else accs[i], res2=xs[i], out=accs[i])
+                        else:
+                            cbn(f[0], f[1], t, "relu" if last else "none", res1=None if first else accs[i], out=accs[i])
+                # the branch's own term
+                if folds[j] and not last:
+                    carry[j] = xs[j]
+                elif not (folds[j] and last and nb > 1):
+                    ops.add_relu(xs[j], None if first else accs[j], relu=last, out=accs[j])
+                for i in range(j):  # up paths j -> i
+                    f = self.fuse_layers[i][j]
+                    t = pre[(i, j)] if (i, j) in pre else cbn(f[0], f[1], xs[j])
+                    if carry[i] is not None:
+                        ops.resize_bilinear(t, xs[i].shape[2:], False, out=accs[i], accumulate=j - 1 > 0, relu=last, extra=carry[i])
+                        carry[i] = None
+                    else:
+                        ops.resize_bilinear(t, xs[i].shape[2:], False, out=accs[i], accumulate=not first, relu=last)
+            return accs
 
         outs = [on(i, lambda i=i: fuse(i)) for i in range(nb)]
         if fk is not None:
