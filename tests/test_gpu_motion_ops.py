@@ -1077,3 +1077,86 @@ torch.save(Tg.cpu(), sys.argv[1])
     err = (outs[0] - outs[1]).abs().max().item()
     print("scalar vs MFMA builder: max |delta T|", err, "step", step)
     assert err < 1e-4 * max(1.0, step)
+
+
+def test_resize_bilinear_add_equals_two_launches():
+    """codd_resize_bilinear_add (the '+ x_i' term of an HRModule fuse layer folded into the neighbouring up-sampling
+    term) against the two launches it replaces (add_relu, then resize_bilinear with accumulate): the same bits."""
+    from codd_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for (C, H, W, s) in [(18, 72, 120, 2), (36, 36, 60, 4), (7, 10, 14, 2)]:
+        acc0 = (torch.randn(1, C, H, W, generator=g) * 30).to(DEV)
+        xi = (torch.randn(1, C, H, W, generator=g) * 30).to(DEV)
+        t = (torch.randn(1, C, H // s, W // s, generator=g) * 30).to(DEV)
+        for accumulate in (True, False):
+            for relu in (True, False):
+                a = acc0.clone()
+                ops.add_relu(xi, a if accumulate else None, relu=False, out=a)
+                ops.resize_bilinear(t, (H, W), False, out=a, accumulate=True, relu=relu)
+                b = acc0.clone()
+                ops.resize_bilinear(t, (H, W), False, out=b, accumulate=accumulate, relu=relu, extra=xi)
+                assert torch.equal(a, b), (C, H, W, s, accumulate, relu, (a - b).abs().max().item())
+
+
+def test_deferred_convs_equal_single_launches():
+    """ops.deferred_convs(): independent convolutions of the multi-job class leave as codd_conv2d_multi launches with the
+    parameters of their single launches -- bit-identical outputs, residual / output-slice operands included; convolutions
+    of other classes inside the block launch at once."""
+    from codd_amd import ops
+    from codd_amd.ops import Slice
+    prev = ops.set_conv_precision("fp32")
+    try:
+        g = torch.Generator().manual_seed(9)
+        jobs = []
+        for (cin, cout, k, st, H, W) in [(18, 18, 3, 2, 72, 120), (36, 18, 1, 1, 36, 60), (72, 36, 1, 1, 36, 60),
+                                         (64, 16, 1, 1, 36, 60), (18, 36, 3, 2, 72, 120), (24, 24, 3, 1, 9, 15)]:
+            x = torch.randn(1, cin, H, W, generator=g).to(DEV)
+            w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(DEV)
+            pc = ops.PackedConv(w, (torch.randn(cout, generator=g) * 0.1).to(DEV))
+            Ho, Wo = (H + 2 * (k // 2) - k) // st + 1, (W + 2 * (k // 2) - k) // st + 1
+            res = torch.randn(1, cout, Ho, Wo, generator=g).to(DEV)
+            pc.tuned[(Ho, Wo, 1, st, st, 1, 1, k // 2, False, 0)] = (1, 4, 16 if cin <= 16 or k == 3 else 32, 1, 1)
+            jobs.append((x, pc, st, k // 2, res, cout, Ho, Wo))
+
+        def run():
+            outs = []
+            for x, pc, st, pad, res, cout, Ho, Wo in jobs:
+                buf = torch.full((1, cout + 2, Ho, Wo), 3.0, device=DEV)
+                ops.conv2d(x, pc, stride=st, pad=pad, act="relu", res1=res, out=Slice(buf, 1, cout))
+                outs.append(buf)
+            return outs
+
+        single = run()
+        with ops.deferred_convs():
+            batched = run()
+        torch.cuda.synchronize()
+        for a, b in zip(single, batched):
+            assert torch.equal(a, b)
+    finally:
+        ops.set_conv_precision(prev)
+
+
+def test_hrnet_launch_reductions_keep_every_bit():
+    """The context network with the round-4 launch reductions (deferred multi-job fuse convolutions, folded '+ x_i'
+    terms, lockstep chain endings) against the one-launch-per-term schedule: torch.equal on the output."""
+    import codd_amd  # noqa: F401
+    from codd_amd import configs, hrnet, ops, synth
+    from codd_amd.registry import build_estimator
+    est = build_estimator(configs.codd(iters=2)).eval()
+    synth.load_synthetic_weights(est, gain=1.4)
+    est = est.to(DEV)
+    img, _, _ = synth.stereo_sequence(256, 384, 1)
+    x = img[:, 0].to(DEV)
+    flags = ("DEFER_FUSE", "FOLD_SELF", "LOCKSTEP_FUSE")
+    saved = {f: getattr(hrnet, f) for f in flags}
+    try:
+        outs = []
+        for on in (True, False):
+            for f in flags:
+                setattr(hrnet, f, on)
+            with ops.stage("context"):
+                outs.append(est.motion.raft3d.context(x).clone())
+        assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max().item()
+    finally:
+        for f, v in saved.items():
+            setattr(hrnet, f, v)
