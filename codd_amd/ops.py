@@ -574,6 +574,7 @@ def _db_cfg_ok(lib, p, c, sig):
 
 
 MULTI_CONV = _os.environ.get("CODD_MULTI_CONV", "1") == "1"  # (A/B switch of conv2d_multi)
+MULTI_DEEP_FIRST = _os.environ.get("CODD_MULTI_DEEP_FIRST", "1") == "1"  # (A/B: job order inside a multi-job launch)
 MULTI_MB = int(_os.environ.get("CODD_MULTI_MB", "1"))  # 16-channel blocks per workgroup of a multi-job launch (1 | 2)
 # tuner candidates on the persistent quad kernel (layout 3: weights resident in LDS, workgroups walk the tiles).  OFF:
 # measured on MI355X (tools/time_persist.py, profiles/r03_persist_times.log) it LOSES to the per-tile kernel on every
@@ -606,6 +607,8 @@ class deferred_convs:
         lib = _abi.load()
         for k0 in range(0, len(items), 4):
             chunk = items[k0:k0 + 4]
+            if MULTI_DEEP_FIRST:
+                chunk = sorted(chunk, key=lambda c: -((c[0].C0 + c[0].C1) * c[0].kh * c[0].kw))
             rc = -2
             if len(chunk) > 1 and MULTI_CONV:
                 arr = (ConvParams * len(chunk))(*[c[0] for c in chunk])
@@ -641,6 +644,10 @@ def conv2d_multi(jobs):
         ids = group[k0:k0 + 4]
         if len(ids) < 2:
             break
+        if MULTI_DEEP_FIRST:
+            # workgroups are dispatched in job order: the job with the longest per-workgroup chain (most chunks x taps)
+            # goes first, so that its chain runs beside the wide, shallow jobs instead of after them
+            ids = sorted(ids, key=lambda i_: -(jobs[i_]["pc"].cin * jobs[i_]["pc"].kh * jobs[i_]["pc"].kw))
         arr = (ConvParams * len(ids))()
         keep = []
         for slot, idx in enumerate(ids):
