@@ -18,6 +18,10 @@ Prints ONE JSON line on rank 0 (see README / task contract), including
                   their summed duration measured with HIP events on the launch stream, vs the 2.5 PFLOP/s dense
                   bf16 matrix peak; the same on ALGORITHMIC direct-conv FLOPs, and the exact-fp32 family (HITNet)
                   vs the 157.3 TFLOP/s fp32 matrix peak, are reported beside it;
+                  roofline.traffic is measured by this run itself (two rocprofv3 --pmc child passes of this script,
+                  FETCH_SIZE and WRITE_SIZE separately; --no-pmc-traffic quotes the committed capture instead);
+  fps_two_videos_per_gpu -- two independent videos resident on the GPU (two frame graphs on two streams): throughput
+                  headroom reported beside the one-video-per-GPU headline;
   cpu_baseline -- the CPU oracle (port of the reference's PyTorch-CPU path) timed on this host's
                   cores: BASELINE.json configs[0] (512x256, 2 frames, stereo only) and ONE measured
                   steady-state frame of the benchmarked configuration (no scaling).
