@@ -1308,6 +1308,11 @@ def allpairs_corr_split(f1, f2):
             ok = [c for c in _ALLPAIRS_CFGS if _cfg_ok(lib, p, c)]
             if not ok:
                 raise _abi.CoddHipError("all-pairs: no split-bf16 configuration for a %dx%d map" % (hh, ww))
+            # the timing may only choose among configurations that give THE SAME BITS (tile shape and wave grid do not
+            # change a sum, the chunk depth does): a pick that depended on the box would make the pyramid -- and with it
+            # every selection downstream -- differ from lease to lease
+            if any(c[2] == 32 for c in ok):
+                ok = [c for c in ok if c[2] == 32]
             cfg = _allpairs_tune(lib, p, ok, f1[0], N, D) if tune else ok[0]
             if tune:
                 _ALLPAIRS_PICK[key] = cfg  # (un-tuned picks are not remembered: a later eager call may still time them)
