@@ -14,7 +14,7 @@ all_reduce of the [3,12] metric tensor after the timed frames, inside the timed 
 
 Prints ONE JSON line on rank 0 (see README / task contract), including
   roofline     -- MFMA roofline of the dominant kernel family (conv_bf16_kernel, the split-bf16 convolutions of
-                  RAFT3D + Fusion): MFMA FLOPs ISSUED (3 bf16 MFMAs per product) by its launches of one frame /
+                  RAFT3D): MFMA FLOPs ISSUED (3 bf16 MFMAs per product) by its launches of one frame /
                   their summed duration measured with HIP events on the launch stream, vs the 2.5 PFLOP/s dense
                   bf16 matrix peak; the same on ALGORITHMIC direct-conv FLOPs, and the exact-fp32 family (HITNet)
                   vs the 157.3 TFLOP/s fp32 matrix peak, are reported beside it;
@@ -104,7 +104,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--precision", default="split", choices=["split", "fp32", "bf16", "bf16mix"],
                     help="arithmetic of the convolution family (codd_amd.ops.set_conv_precision): split = split-bf16 "
-                         "operands / fp32 accumulate for RAFT3D + Fusion and exact fp32 for HITNet (default, parity-"
+                         "operands / fp32 accumulate for RAFT3D and exact fp32 for HITNet / context network / Fusion (default, parity-"
                          "tested at 1e-3 px); fp32 = exact-fp32 kernels everywhere; bf16 = bf16 operands / fp32 "
                          "accumulate everywhere (BASELINE.json configs[4]); bf16mix = bf16 operands for RAFT3D's feature encoder "
                          "and update block only, exact fp32 for HITNet / context network / Fusion")

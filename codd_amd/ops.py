@@ -228,7 +228,7 @@ def set_conv_precision(mode):
 # (~100 px) in their input channels and emit the disparity itself, so 1e-5 relative is ~1e-3 px absolute -- the whole
 # north-star budget -- and its arg-min / arg-max selections flip for ~1.5 % of the pixels; the stereo network
 # (7 % of the frame's conv FLOPs) therefore stays on the exact-fp32 kernels, everything else (RAFT3D encoders and the
-# 16 update iterations, Fusion: 93 % of the FLOPs, O(1) feature scales, smooth outputs) runs split-bf16.
+# 16 update iterations: ~90 % of the FLOPs, O(1) feature scales, smooth outputs) runs split-bf16.
 # Round 4: Fusion as well.  Over the configured sequence length (tests/test_gpu_headline_parity.py::
 # test_recurrent_sequence_matches_oracle, 16 frames) the split-bf16 error of Fusion's weight path is multiplied by
 # |pred_warp - pred_curr| (up to 250 px with the synthetic weights, whose weight-head logits saturate the sigmoid): from
