@@ -188,7 +188,12 @@ _LEVELS = ("16x", "8x", "4x", "2x", "1x")
 
 
 FORK_INIT_LEVELS = os.environ.get("CODD_FORK_INIT", "0") == "1"  # (A/B switch; TileInitialization.forward)
-STEREO_PIPE = os.environ.get("CODD_STEREO_PIPE", "1") == "1"  # (A/B: HITNetMF._stereo_matching_pipelined)
+STEREO_PIPE = os.environ.get("CODD_STEREO_PIPE", "1") == "1"
+# initialisation of scales 1/2 (>= 1) and 1/4 (>= 2) on the decoder's side stream, right behind the decoder stage that
+# produces their features, instead of on the caller's stream in front of the propagation step that consumes them: the
+# caller's stream (the long pole: ~60 dependent small launches) sheds 12 of them.  Same launches, same bits.  Round 4,
+# three alternating runs each: stereo-only 441 -> 460 -> 472 frames/s (0 / 1 / 2), full frame 97.1 -> 97.6 -> 97.7.
+PIPE_INIT_SIDE = int(os.environ.get("CODD_PIPE_INIT_SIDE", "2"))  # (A/B: HITNetMF._stereo_matching_pipelined)
 FORK_INIT_FINE = int(os.environ.get("CODD_FORK_INIT_FINE", "3"))  # (A/B: this many of the finest scales on ONE side stream)
 
 
@@ -474,18 +479,25 @@ class HITNetMF(ops.RuntimeState, nn.Module):
         side, ev3, ev2 = rt
         cur = torch.cuda.current_stream(dev)
         side.wait_stream(cur)
+        hyp2 = hyp3 = None
         with torch.cuda.stream(side):
-            feas.append(next(g)); ev3.record(side)
-            feas.append(next(g)); ev2.record(side)
+            feas.append(next(g))
+            if PIPE_INIT_SIDE >= 2:
+                hyp2 = ti.init_level(2, L(2), R(2), L(0))
+            ev3.record(side)
+            feas.append(next(g))
+            if PIPE_INIT_SIDE >= 1:
+                hyp3 = ti.init_level(3, L(3), R(3), L(1))
+            ev2.record(side)
             feas.append(next(g))
             hyp4 = ti.init_level(4, L(4), R(4), L(2))
         hyp0, hyp1 = ti.init_level(0, L(0), R(0), None), ti.init_level(1, L(1), R(1), None)
         h = tu.tile_update0(L(0), R(0), hyp0)[0]
         h = tu.tile_update1(L(1), R(1), hyp1, h)[0]
         cur.wait_event(ev3)
-        h = tu.tile_update2(L(2), R(2), ti.init_level(2, L(2), R(2), L(0)), h)[0]
+        h = tu.tile_update2(L(2), R(2), hyp2 if hyp2 is not None else ti.init_level(2, L(2), R(2), L(0)), h)[0]
         cur.wait_event(ev2)
-        h = tu.tile_update3(L(3), R(3), ti.init_level(3, L(3), R(3), L(1)), h)[0]
+        h = tu.tile_update3(L(3), R(3), hyp3 if hyp3 is not None else ti.init_level(3, L(3), R(3), L(1)), h)[0]
         cur.wait_stream(side)
         h = tu.tile_update4(L(4), R(4), hyp4, h)[0]
         r1 = tu.tile_update4_1(L(2), h)
