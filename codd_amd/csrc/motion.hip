@@ -456,11 +456,28 @@ extern "C" int codd_raft_geometry(const float* T, const float* depth1, const flo
 // split-bf16 copy of ae_j / 8 for the MFMA builder (se3_gn_build2_kernel): per pixel [plane hi | lo][32 bf16] = 128 bytes
 // = 32 floats; hi = bf16_rne(v), lo = bf16_rne(v - hi) as everywhere else (common.h xs_store8)
 #define GN_AQ 32
+// the pair builder's second record image (se3_gn_build3_kernel): [b][y][x / 2][k = 0..11][x & 1], k = X (3), target in
+// normalised image coordinates ((u - cx) / fx, (v - cy) / fy) and inverse depth, weights (wx fx^2, wy fy^2, wz), |a|^2;
+// the phantom partner of the last pixel of an odd-width row is written as zeros (depth 0 = masked, finite)
+static __device__ __forceinline__ void gn_geo2_store(float* __restrict__ geo2, int b, int h, int w, int yj, int xj, V3 X,
+                                                      float tx, float ty, float tz, float wx, float wy, float wz, float a2,
+                                                      float fx, float fy, float cx, float cy) {
+  if (!geo2) return;
+  const int wp2 = (w + 1) >> 1;
+  float* gp = geo2 + (((size_t)b * h + yj) * wp2 + (xj >> 1)) * 24 + (xj & 1);
+  const float v[12] = {X.x, X.y, X.z, (tx - cx) / fx, (ty - cy) / fy, tz, wx * fx * fx, wy * fy * fy, wz, a2, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 12; ++k) gp[2 * k] = v[k];
+  if (xj == w - 1 && !(xj & 1)) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) gp[2 * k + 1] = 0.f;
+  }
+}
 __global__ void se3_gn_prep_kernel(const float* __restrict__ ae, int ae_c, const float* __restrict__ xyz,
                                    const float* __restrict__ delta, const float* __restrict__ wgt,
                                    const float* __restrict__ d1, int h, int w, float fx, float fy, float cx, float cy,
                                    float* __restrict__ jd, int* __restrict__ cnt, int ntiles,
-                                   unsigned short* __restrict__ aeq) {
+                                   unsigned short* __restrict__ aeq, float* __restrict__ geo2) {
   const int N = h * w;
   const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
   if (j < ntiles) cnt[b * ntiles + j] = 0;  // arrival counters of the builder launched next (ntiles <= N)
@@ -490,6 +507,7 @@ __global__ void se3_gn_prep_kernel(const float* __restrict__ ae, int ae_c, const
   rp[35] = xb[0] + db[0]; rp[36] = xb[1] + db[N]; rp[37] = xb[2] + db[2 * N];
   rp[38] = wb[0]; rp[39] = wb[N]; rp[40] = wb[2 * N];
   rp[41] = a2; rp[42] = 0.f; rp[43] = 0.f;
+  gn_geo2_store(geo2, b, h, w, yj, xj, X, rp[35], rp[36], rp[37], rp[38], rp[39], rp[40], a2, fx, fy, cx, cy);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -512,7 +530,7 @@ __global__ __launch_bounds__(64) void gn_heads_prep_kernel(const codd_xs_view hs
                                                           int h, int w, float fx, float fy, float cx, float cy,
                                                           float* __restrict__ jd, float* __restrict__ wout,
                                                           int* __restrict__ cnt, int ntiles,
-                                                          unsigned short* __restrict__ aeq) {
+                                                          unsigned short* __restrict__ aeq, float* __restrict__ geo2) {
   const int N = h * w;
   const int lane = threadIdx.x, px = lane & 15, g = lane >> 4, b = blockIdx.y;
   if (lane == 0)  // arrival counters of the builder launched next
@@ -617,6 +635,7 @@ __global__ __launch_bounds__(64) void gn_heads_prep_kernel(const codd_xs_view hs
     *(f32x4*)(rp + 32) = f32x4{X.x, X.y, X.z, xb[0] + dl0};
     *(f32x4*)(rp + 36) = f32x4{xb[1] + dl1, xb[2] + dl2, wv[0], wv[1]};
     *(f32x4*)(rp + 40) = f32x4{wv[2], a2, 0.f, 0.f};
+    gn_geo2_store(geo2, b, h, w, yj, xj, X, xb[0] + dl0, xb[1] + dl1, xb[2] + dl2, wv[0], wv[1], wv[2], a2, fx, fy, cx, cy);
   }
 }
 
@@ -676,13 +695,25 @@ __global__ __launch_bounds__(64 * GN_WAVES) void se3_gn_build_kernel(
   const unsigned twor = 2u * (unsigned)radius;
   const float* rec = jd + (size_t)b * N * GN_JS;
   const float* aip = rec + (size_t)i * GN_JS;
+  // dev ablations (tools/ubench/gn_ablate.hip): GN_ABL_NOPRO no per-pixel loads in the prologue, GN_ABL_NODOT no
+  // affinity dot product, GN_ABL_NOGEOM no geometry / normal-equation updates, GN_ABL_NOSLOAD one record per row
+  // (scalar loads leave the inner loop), GN_ABL_NOEPI no reduction / partial store
+#ifdef GN_ABL_NOPRO
+  const SE3T Ti = {V3{0.01f * lane, 0.02f, 0.03f}, Q4{0.f, 0.f, 0.f, 1.f}};
+#else
   const SE3T Ti = se3_load(T + ((size_t)b * N + i) * 7);
+#endif
   // rotation matrix of T_i: Y = [c0 c1 c2] X + t
   const V3 c0 = qrot(Ti.q, V3{1.f, 0.f, 0.f}), c1 = qrot(Ti.q, V3{0.f, 1.f, 0.f}), c2 = qrot(Ti.q, V3{0.f, 0.f, 1.f});
   v2f ai[GN_AE / 2];
 #pragma unroll
+#ifdef GN_ABL_NOPRO
+  for (int c = 0; c < GN_AE / 2; ++c) ai[c] = v2f{0.01f * (lane + c), 0.02f * (lane - c)};
+  const float ai2 = 0.5f * lane;
+#else
   for (int c = 0; c < GN_AE / 2; ++c) ai[c] = *(const v2f*)(aip + 2 * c);
   const float ai2 = aip[41];
+#endif
   // normal-equation sums: the upper triangle of H as row pairs (H_p,q  H_p,q+1), q even -- rows 1, 3, 5 carry one
   // redundant lower-triangle entry so that every update is one packed FMA; H01 is structurally 0
   float H00 = 0.f, H11 = 0.f, b0 = 0.f, b1 = 0.f, b4z = 0.f;
@@ -698,7 +729,11 @@ __global__ __launch_bounds__(64 * GN_WAVES) void se3_gn_build_kernel(
     for (int xj = xa; xj <= xb; ++xj) {
       // wave-uniform address -> scalar loads; the whole 176-byte record is fetched up front (one batch of
       // s_load_dwordx4/x8/x16, one wait); SGPR pairs feed the packed FMAs directly
+#ifdef GN_ABL_NOSLOAD
+      const float4* rp4 = (const float4*)(rrow + (size_t)xa * GN_JS);
+#else
       const float4* rp4 = (const float4*)(rrow + (size_t)xj * GN_JS);
+#endif
       float4 r[11];
 #pragma unroll
       for (int q = 0; q < 11; ++q) r[q] = rp4[q];
@@ -712,9 +747,17 @@ __global__ __launch_bounds__(64 * GN_WAVES) void se3_gn_build_kernel(
         acc1 = GN_PK(ai[2 * q + 1], (v2f){r[q].z, r[q].w}, acc1);
       }
       acc0 += acc1;
+#ifdef GN_ABL_NODOT
+      const float dot = ai[0].x * r[0].x;
+#else
       const float dot = acc0.x + acc0.y;
+#endif
       const float d2 = fmaxf(fmaf(-2.f, dot, ai2 + r[10].y), 0.f);
       const float a = in ? __builtin_amdgcn_rcpf(1.f + __expf(d2)) : 0.f;  // sigmoid(-d2), masked
+#ifdef GN_ABL_NOGEOM
+      H00 += a;
+      continue;
+#endif
       // the affinity of far neighbours underflows against the accumulated sums: skip their geometry when every
       // lane's weight is below 1e-9 (relative effect on H, b < 1e-9; wave-uniform branch)
 #ifdef GN_STATS  // dev build (tools/gn_skip_rate.py): neighbour visits / visits skipped by the test below, per wave
@@ -759,6 +802,9 @@ __global__ __launch_bounds__(64 * GN_WAVES) void se3_gn_build_kernel(
   const float Hs[27] = {H00, 0.f, h02.x, h02.y, h04.x, h04.y, H11, h12.x, h12.y, h14.x, h14.y, h22.x, h22.y, h24.x,
                         h24.y, h32.y, h34.x, h34.y, h44.x, h44.y, h54.y, b0, b1, b23.x, b23.y, b45.x + b4z, b45.y};
   float* pp = part + (((size_t)b * ntiles + tile) * gmax + g) * 27 * 64 + lane;
+#ifdef GN_ABL_NOEPI
+  if (Hs[0] != 12345.f) return;
+#endif
   if constexpr (!FUSE) {
     // wave w adds its sums into ONE [27][64] LDS image after wave w - 1 (same order, same bits as
     // ((s0 + s1) + s2) + s3 over four images): 6.9 KB instead of 27.6 KB per workgroup, so that four resident
@@ -810,6 +856,146 @@ __global__ __launch_bounds__(64 * GN_WAVES) void se3_gn_build_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// Pair builder (round 4): TWO neighbours per loop step, every operation of the geometry a packed fp32 instruction over
+// the pair (v_pk_fma / v_pk_mul / v_pk_add_f32: lane half = neighbour parity), and the normal equations in the factored
+// form of the Jacobian (reference se3_field.py:115-147; lietorch's left perturbation):
+//     J = A [I | -[Y]x],  A = d(u, v, 1/z)/dY = d * A^,  A^ = [fx 0 -fx xn; 0 fy -fy yn; 0 0 -d],  Y = (xn, yn, 1) / d
+//     S^ = a A^T W A^  (5 non-zeros: S00 S11 S02 S12 S22),   g^ = a A^T W r   (fx, fy, cx, cy folded into the records)
+//     H_tt = d^2 S^,   H_tr = d N,   H_rr = Q^T N,   N = S^ Q,   Q = -[(xn, yn, 1)]x;   b_t = d g^,   b_r = Q^T g^
+// i.e. 80 packed instructions per PAIR for the geometry where the J-entry form above issues 76 (31 of them packed) per
+// NEIGHBOUR.  The pair's per-neighbour scalars (X, target, weights, |a|^2) come from a second record image
+// ``geo2`` [b][y][x / 2][12][2] (both prep kernels write it) so that every packed source is an aligned SGPR pair; the
+// embeddings stay in the 176-byte records.  Sums are kept per parity (2 x 26 accumulators) and added at the end.
+// ------------------------------------------------------------------------------------------------
+#define GN_G2 24  // floats per neighbour PAIR in geo2: [k = 0..11][parity]: X(3) target(3) weight(3) |a|^2 0 0
+__global__ __launch_bounds__(64 * GN_WAVES) void se3_gn_build3_kernel(
+    const float* __restrict__ T, const float* __restrict__ jd, const float* __restrict__ geo2, int h, int w, float fx,
+    float fy, float cx, float cy, int radius, int tiles_x, int ntiles, int q4, int gmax, float* __restrict__ part) {
+  __shared__ float red[27][64];
+  const int N = h * w, wp2 = (w + 1) >> 1;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+  const int tx0 = (tile % tiles_x) * 8, ty0 = (tile / tiles_x) * 8;
+  const int ylo = max(ty0 - radius, 0), yhi = min(ty0 + 7 + radius, h - 1);
+  const int xlo = max(tx0 - radius, 0), xhi = min(tx0 + 7 + radius, w - 1);
+  const int ncols = xhi - xlo + 1, nj = (yhi - ylo + 1) * ncols;
+  const int G = gn_groups(nj, q4, gmax);
+  if (g >= G) return;
+  const int slot = g * GN_WAVES + wave, nslots = G * GN_WAVES;
+  const int s0 = (int)((long long)nj * slot / nslots), s1 = (int)((long long)nj * (slot + 1) / nslots);
+  const int ys = ylo + s0 / ncols, xs = xlo + s0 % ncols;
+  const int ye = ylo + (s1 - 1) / ncols, xe = xlo + (s1 - 1) % ncols;
+
+  const int xi = tx0 + (lane & 7), yi = ty0 + (lane >> 3);
+  const bool vi = xi < w && yi < h;
+  const int i = vi ? yi * w + xi : 0;
+  const int xim = xi - radius, yim = yi - radius;
+  const unsigned twor = 2u * (unsigned)radius;
+  const float* rec = jd + (size_t)b * N * GN_JS;
+  const float* aip = rec + (size_t)i * GN_JS;
+  const SE3T Ti = se3_load(T + ((size_t)b * N + i) * 7);
+  const V3 c0 = qrot(Ti.q, V3{1.f, 0.f, 0.f}), c1 = qrot(Ti.q, V3{0.f, 1.f, 0.f}), c2 = qrot(Ti.q, V3{0.f, 0.f, 1.f});
+  v2f ai[GN_AE / 2];
+#pragma unroll
+  for (int c = 0; c < GN_AE / 2; ++c) ai[c] = *(const v2f*)(aip + 2 * c);
+  const float ai2 = aip[41];
+  const v2f Z = {0.f, 0.f};
+  v2f H00 = Z, H11 = Z, H02 = Z, H12 = Z, H22 = Z, H03 = Z, H04 = Z, H05 = Z, H13 = Z, H14 = Z, H15 = Z, H23 = Z, H24 = Z,
+      H25 = Z, H33 = Z, H34 = Z, H35 = Z, H44 = Z, H45 = Z, H55 = Z, b0 = Z, b1 = Z, b2 = Z, b3 = Z, b4 = Z, b5 = Z;
+#define BC(s) ((v2f){(s), (s)})
+
+  // Walk over the wave's pairs, row by row.  The records of a pair occupy 84 SGPRs (2 x 32 embedding values + 10 geometry
+  // pairs): five of the six 16-register tuples a wave has, so the compiler requests them in three or four separately
+  // awaited portions, and they cannot be requested a step ahead -- every attempt (next pair's records loaded into the
+  // registers the step has just finished with; scalar-cache warm-up loads; the embeddings through the wave's own LDS
+  // region with broadcast ds_read_b128) ended in SGPR spills through v_readlane / v_writelane, in vector loads, or at 2
+  // waves per SIMD and slower than this form (ROCm 7.2; DESIGN finding 45).
+  if (s1 > s0)
+  for (int yj = ys; yj <= ye; ++yj) {
+    const bool rowin = vi && (unsigned)(yj - yim) <= twor;
+    const float* rrow = rec + (size_t)yj * w * GN_JS;
+    const v2f* grow = (const v2f*)(geo2 + ((size_t)b * h + yj) * wp2 * GN_G2);
+    const int xa = yj == ys ? xs : xlo, xb = yj == ye ? xe : xhi;
+    for (int xp = xa >> 1; xp <= (xb >> 1); ++xp) {
+      const int x0 = 2 * xp, x1 = x0 + 1;
+      const bool own0 = x0 >= xa, own1 = x1 <= xb;  // (x0 <= xb and x1 >= xa always hold)
+      const float4* e0 = (const float4*)(rrow + (size_t)x0 * GN_JS);
+      const float4* e1 = (const float4*)(rrow + (size_t)min(x1, w - 1) * GN_JS);
+      const v2f* gp = grow + (size_t)xp * (GN_G2 / 2);
+      v2f G2[10];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) G2[k] = gp[k];
+      float4 r0[8], r1[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) r0[q] = e0[q];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) r1[q] = e1[q];
+      const v2f Xx = G2[0], Xy = G2[1], Xz = G2[2];
+      const v2f Yz = GN_PK(BC(c0.z), Xx, GN_PK(BC(c1.z), Xy, GN_PK(BC(c2.z), Xz, BC(Ti.t.z))));
+      const bool in0 = rowin & own0 & ((unsigned)(x0 - xim) <= twor) & (Xz.x >= MIN_DEPTH) & (Yz.x >= MIN_DEPTH);
+      const bool in1 = rowin & own1 & ((unsigned)(x1 - xim) <= twor) & (Xz.y >= MIN_DEPTH) & (Yz.y >= MIN_DEPTH);
+      v2f p0 = Z, p1 = Z, q0 = Z, q1 = Z;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        p0 = GN_PK(ai[2 * q], (v2f){r0[q].x, r0[q].y}, p0);
+        p1 = GN_PK(ai[2 * q + 1], (v2f){r0[q].z, r0[q].w}, p1);
+        q0 = GN_PK(ai[2 * q], (v2f){r1[q].x, r1[q].y}, q0);
+        q1 = GN_PK(ai[2 * q + 1], (v2f){r1[q].z, r1[q].w}, q1);
+      }
+      p0 += p1;
+      q0 += q1;
+      const v2f dot = {p0.x + p0.y, q0.x + q0.y};
+      const v2f e2 = GN_PK(BC(-2.f), dot, BC(ai2) + G2[9]);
+      const float ax = __builtin_amdgcn_rcpf(1.f + __expf(fmaxf(e2.x, 0.f)));
+      const float ay = __builtin_amdgcn_rcpf(1.f + __expf(fmaxf(e2.y, 0.f)));
+      const v2f a = {in0 ? ax : 0.f, in1 ? ay : 0.f};  // sigmoid(-d2), masked
+      if (__ballot(a.x > 1e-9f || a.y > 1e-9f) == 0ull) continue;  // (as in se3_gn_build_kernel)
+      const v2f Yx = GN_PK(BC(c0.x), Xx, GN_PK(BC(c1.x), Xy, GN_PK(BC(c2.x), Xz, BC(Ti.t.x))));
+      const v2f Yy = GN_PK(BC(c0.y), Xx, GN_PK(BC(c1.y), Xy, GN_PK(BC(c2.y), Xz, BC(Ti.t.y))));
+      const v2f d = {__builtin_amdgcn_rcpf(fmaxf(Yz.x, MIN_DEPTH)), __builtin_amdgcn_rcpf(fmaxf(Yz.y, MIN_DEPTH))};
+      const v2f xn = Yx * d, yn = Yy * d;
+      const v2f rx = G2[3] - xn, ry = G2[4] - yn, rz = G2[5] - d;  // (rx, ry in units of fx, fy: folded into S00, S11)
+      const v2f S00 = a * G2[6], S11 = a * G2[7], t = (a * G2[8]) * d;
+      const v2f S02 = -(S00 * xn), S12 = -(S11 * yn);
+      const v2f S22 = GN_PK(t, d, -GN_PK(S12, yn, S02 * xn));
+      const v2f g0 = S00 * rx, g1 = S11 * ry;
+      const v2f g2 = -GN_PK(t, rz, GN_PK(g1, yn, g0 * xn));
+      const v2f dd = d * d;
+      H00 = GN_PK(dd, S00, H00); H11 = GN_PK(dd, S11, H11); H02 = GN_PK(dd, S02, H02); H12 = GN_PK(dd, S12, H12);
+      H22 = GN_PK(dd, S22, H22);
+      const v2f N00 = yn * S02, N01 = GN_PK(-xn, S02, S00), N02 = -(yn * S00);
+      const v2f N10 = GN_PK(yn, S12, -S11), N11 = -(xn * S12), N12 = xn * S11;
+      const v2f N20 = GN_PK(yn, S22, -S12), N21 = GN_PK(-xn, S22, S02), N22 = GN_PK(xn, S12, -N00);
+      H03 = GN_PK(d, N00, H03); H04 = GN_PK(d, N01, H04); H05 = GN_PK(d, N02, H05);
+      H13 = GN_PK(d, N10, H13); H14 = GN_PK(d, N11, H14); H15 = GN_PK(d, N12, H15);
+      H23 = GN_PK(d, N20, H23); H24 = GN_PK(d, N21, H24); H25 = GN_PK(d, N22, H25);
+      H33 = GN_PK(yn, N20, H33) - N10; H34 = GN_PK(yn, N21, H34) - N11; H35 = GN_PK(yn, N22, H35) - N12;
+      H44 = GN_PK(-xn, N21, H44) + N01; H45 = GN_PK(-xn, N22, H45) + N02;
+      H55 = GN_PK(xn, N12, GN_PK(-yn, N02, H55));
+      b0 = GN_PK(d, g0, b0); b1 = GN_PK(d, g1, b1); b2 = GN_PK(d, g2, b2);
+      b3 = GN_PK(yn, g2, b3) - g1; b4 = GN_PK(-xn, g2, b4) + g0; b5 = GN_PK(xn, g1, GN_PK(-yn, g0, b5));
+    }
+  }
+#undef BC
+#define S2(v) ((v).x + (v).y)
+  const float Hs[27] = {S2(H00), 0.f, S2(H02), S2(H03), S2(H04), S2(H05), S2(H11), S2(H12), S2(H13), S2(H14), S2(H15),
+                        S2(H22), S2(H23), S2(H24), S2(H25), S2(H33), S2(H34), S2(H35), S2(H44), S2(H45), S2(H55),
+                        S2(b0), S2(b1), S2(b2), S2(b3), S2(b4), S2(b5)};
+#undef S2
+  float* pp = part + (((size_t)b * ntiles + tile) * gmax + g) * 27 * 64 + lane;
+#pragma unroll
+  for (int w_ = 0; w_ < GN_WAVES; ++w_) {  // (same one-image reduction in wave order as se3_gn_build_kernel<false>)
+    if (wave == w_) {
+#pragma unroll
+      for (int k = 0; k < 27; ++k) red[k][lane] = w_ == 0 ? Hs[k] : red[k][lane] + Hs[k];
+    }
+    __syncthreads();
+  }
+  for (int k = wave; k < 27; k += GN_WAVES) pp[k * 64] = red[k][lane];
+}
+
 // MFMA builder (round 4, CODD_GN_MFMA=1; off by default, see gn_mfma()): the 32-term affinity dot products -- 18 of the scalar builder's 110
 // VALU instructions per neighbour -- move to the bf16 matrix pipe, which this VALU-bound kernel leaves idle.
 //   * neighbours are taken 16 at a time; Gram block G[j][i] = <ae_j, ae_i> for the tile's 64 pixels by
@@ -1049,8 +1235,11 @@ __global__ __launch_bounds__(64 * GN_SOLVE_WAVES) void se3_gn_solve_kernel(
 // Neighbours per workgroup (4 waves): small enough that the launch is several dispatch rounds of equal-sized
 // waves (dynamic balance over the 256 CUs), large enough that a wave's set-up (its 32 + 12 per-pixel registers) and
 // the per-workgroup partial (6.9 KB) stay in the noise.
+static inline bool gn_pair();
 static inline int gn_q4() {
-  static const int q = getenv("CODD_GN_Q4") ? atoi(getenv("CODD_GN_Q4")) : 128;  // dev override
+  // 128 for the J-entry builder, 256 for the pair builder (half as many steps per neighbour, a pair slot lost at each
+  // end of a row segment: 103.5 us at 128, 100.3 at 192, 99.4 at 256, 104.7 at 384); CODD_GN_Q4 = dev override
+  static const int q = getenv("CODD_GN_Q4") ? atoi(getenv("CODD_GN_Q4")) : (gn_pair() ? 256 : 128);
   return q < 16 ? 16 : q;
 }
 static inline int gn_gmax(int radius) {
@@ -1064,8 +1253,13 @@ static inline size_t gn_aeq_offset(int B, int h, int w, int radius) {
   const size_t n = (size_t)B * ntiles * gn_gmax(radius) * 27 * 64 + (size_t)B * h * w * GN_JS + (size_t)B * ntiles;
   return (n + 3) & ~(size_t)3;
 }
+// floats in front of the pair builder's geo2 image
+static inline size_t gn_geo2_offset(int B, int h, int w, int radius) {
+  return gn_aeq_offset(B, h, w, radius) + (size_t)B * h * w * GN_AQ;
+}
 extern "C" long long codd_se3_gn_scratch(int B, int h, int w, int radius) {
-  return (long long)gn_aeq_offset(B, h, w, radius) + (long long)B * h * w * GN_AQ;
+  // (+ 2 pairs: the pair builder's warm-up loads read one pair past the step's own)
+  return (long long)gn_geo2_offset(B, h, w, radius) + ((long long)B * h * ((w + 1) / 2) + 2) * GN_G2;
 }
 // [partials | neighbour records | per-tile arrival counters | split-bf16 embeddings (MFMA builder)]
 static inline int* gn_counters(float* Hb, int B, int h, int w, int radius) {
@@ -1076,6 +1270,12 @@ static inline bool gn_mfma() {
   // A/B (dev), OFF: 1 = se3_gn_build2_kernel (dot products on the bf16 matrix pipe).  Measured (DESIGN finding 38):
   // 15 % fewer VALU instructions per neighbour, 116.9 against 118.5 us -- the builder is not bound by its VALU count
   static const bool f = getenv("CODD_GN_MFMA") && atoi(getenv("CODD_GN_MFMA")) == 1;
+  return f;
+}
+static inline bool gn_pair() {
+  // 1 = se3_gn_build3_kernel: two neighbours per step in packed fp32, factored normal equations; 0 (default) = the
+  // J-entry builder se3_gn_build_kernel<false> (A/B: DESIGN finding 45)
+  static const bool f = getenv("CODD_GN_PAIR") && atoi(getenv("CODD_GN_PAIR")) == 1;
   return f;
 }
 static inline bool gn_fused_solve() {
@@ -1097,7 +1297,10 @@ static int gn_build_solve(float* T, int B, int h, int w, float fx, float fy, flo
     CODD_LAUNCH_CHECK();
     return CODD_OK;
   }
-  if (gn_mfma())
+  if (gn_pair() && !gn_mfma())
+    se3_gn_build3_kernel<<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, s>>>(T, jd, Hb + gn_geo2_offset(B, h, w, radius), h, w, fx, fy,
+                                                                        cx, cy, radius, tiles_x, ntiles, q4, gmax, part);
+  else if (gn_mfma())
     se3_gn_build2_kernel<<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, s>>>(
         T, jd, (const uint4*)(Hb + gn_aeq_offset(B, h, w, radius)), h, w, fx, fy, cx, cy, radius, tiles_x, ntiles, q4, gmax, part);
   else
@@ -1119,7 +1322,8 @@ extern "C" int codd_se3_gn_step(float* T, const float* ae, int ae_c, const float
   hipStream_t s = (hipStream_t)stream;
   se3_gn_prep_kernel<<<dim3(cdiv(h * w, 128), B), 128, 0, s>>>(ae, ae_c, xyz, delta, weight, depth1, h, w, fx, fy, cx,
                                                              cy, jd, gn_counters(Hb, B, h, w, radius), ntiles,
-                                                             (unsigned short*)(Hb + gn_aeq_offset(B, h, w, radius)));
+                                                             (unsigned short*)(Hb + gn_aeq_offset(B, h, w, radius)),
+                                                             Hb + gn_geo2_offset(B, h, w, radius));
   CODD_LAUNCH_CHECK();
   return gn_build_solve(T, B, h, w, fx, fy, cx, cy, radius, lm, ep, Hb, s);
 }
@@ -1136,7 +1340,8 @@ extern "C" int codd_se3_gn_step_heads(float* T, codd_xs_view hidden, const void*
   hipStream_t s = (hipStream_t)stream;
   gn_heads_prep_kernel<<<dim3(cdiv(h * w, 16), B), 64, 0, s>>>(hidden, (const uint4*)head_w, head_b, xyz, depth1, h, w, fx, fy, cx, cy,
                                                                jd, weight_out, gn_counters(Hb, B, h, w, radius), ntiles,
-                                                               (unsigned short*)(Hb + gn_aeq_offset(B, h, w, radius)));
+                                                               (unsigned short*)(Hb + gn_aeq_offset(B, h, w, radius)),
+                                                             Hb + gn_geo2_offset(B, h, w, radius));
   CODD_LAUNCH_CHECK();
   return gn_build_solve(T, B, h, w, fx, fy, cx, cy, radius, lm, ep, Hb, s);
 }

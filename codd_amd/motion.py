@@ -32,6 +32,8 @@ FNET_CORESIDENT = os.environ.get("CODD_FNET_CORESIDENT", "0") == "1"
 # the context network (read by the NEXT frame only) starts after the feature encoder + correlation pyramid (which the
 # update loop of THIS frame waits for) instead of beside them (A/B)
 CNET_AFTER_FNET = os.environ.get("CODD_CNET_AFTER_FNET", "0") == "1"
+# the state-only launches in front of the first update (RAFT3D._preloop) on the fnet side stream behind the pyramid
+PRELOOP_SIDE = os.environ.get("CODD_PRELOOP_SIDE", "1") == "1"
 # the flow encoder's 7x7 convolution beside the correlation encoder's first 3x3: 1 = small-footprint configurations for
 # the former, 2 = for both (A/B)
 ENC_CORESIDENT = int(os.environ.get("CODD_ENC_CORESIDENT", "1"))
@@ -473,7 +475,29 @@ class RAFT3D(ops.RuntimeState, nn.Module):
                         t_, u_ = u_, t_
                 if key == "fmap" and state is not None and "memory" in state and state.get("raft_feat") is not None:
                     out["pyr"] = (state["raft_feat"], ops.allpairs_corr(state["raft_feat"], out["fmap"]))
+                    if PRELOOP_SIDE and state.get("raft_netinp") is not None:
+                        out["pre"] = self._preloop(state["raft_netinp"])
         self._pending = out
+
+    def _preloop(self, net_inp):
+        """The launches in front of the first update that only read the PREVIOUS frame's state (the context network's
+        output: reference raft3d.py:205-207,278): hidden-state / context split, their layouts for the gate epilogues,
+        the identity field and the first update's z|r convolutions.  Issued behind the correlation pyramid on the fnet
+        side stream they leave the frame's critical path (stereo -> update loop -> fusion); same launches, same bits."""
+        B, _, h, w = net_inp.shape
+        ub = self.update_block
+        net, inp = ops.context_split(net_inp)
+        pre = dict(src=net_inp, net=net, inp=inp, T=ops.se3_identity(B, h, w, net_inp.device), zr=None)
+        if ub._gates_fused(net) and ub.input_buffers(net)[0] is not None:
+            ub._fused_now = True
+            ub._h4(net), ub._ctx4(inp)
+            fkz = ub._forks(net_inp.device)[1]
+            prev, fkz.inline = fkz.inline, True  # (one launch: on THIS side stream, not on a fork of it)
+            try:
+                pre["zr"] = ub.zr_convs(net)
+            finally:
+                fkz.inline = prev
+        return pre
 
     def _join(self, key, dev):
         pend = getattr(self, "_pending", None)
@@ -495,17 +519,21 @@ class RAFT3D(ops.RuntimeState, nn.Module):
         K = [np.float32(v) for v in intrinsics]
         K8 = [float(v / np.float32(8.0)) for v in K]
         fmap_prev, net_inp = state["raft_feat"], state["raft_netinp"]
-        T = ops.se3_identity(B, h, w, image_curr.device)
         pend = getattr(self, "_pending", None) or {}
+        pl = pend.pop("pre", None)
+        if pl is not None and pl["src"] is not net_inp:
+            pl = None
+        T = pl["T"] if pl is not None else ops.se3_identity(B, h, w, image_curr.device)
         pre = pend.pop("pyr", None)  # (fmap_prev it was built from, pyramid): made on the fnet side stream by prefetch
         fmap_curr = self._join("fmap", dev)
         if fmap_curr is None:
             fmap_curr = self.fnet(image_curr)
         pyr = pre[1] if pre is not None and pre[0] is fmap_prev else ops.allpairs_corr(fmap_prev, fmap_curr)
-        net, inp = ops.context_split(net_inp)
+        net, inp = (pl["net"], pl["inp"]) if pl is not None else ops.context_split(net_inp)
         d1 = ops.subsample(depth_prev.contiguous(), 3, 3, 8)  # depth[:, 3::8, 3::8] (raft3d.py:213-216)
         d2 = ops.subsample(depth_curr.contiguous(), 3, 3, 8)
-        mask = weight = zr = None
+        mask = weight = None
+        zr = pl["zr"] if pl is not None else None
         cxs, mxs = self.update_block.input_buffers(net)
         for it in range(iters):
             # projection + pyramid lookup, one launch; in the split-bf16 modes its results are written straight into

@@ -1043,9 +1043,12 @@ def test_hrmodule_fused_sum_equals_per_term_launches():
         assert a.shape == b.shape and (a - b).abs().max().item() < 1e-4 * max(1.0, a.abs().max().item())
 
 
-def test_se3_gn_step_mfma_builder_matches_scalar_builder():
-    """se3_gn_build2_kernel (CODD_GN_MFMA=1: affinity dot products as split-bf16 MFMA Gram blocks) against the default
-    scalar builder on the same inputs, in a child process (the switch is read once per process)."""
+@pytest.mark.parametrize("env", [dict(CODD_GN_MFMA="1", CODD_GN_PAIR="0"), dict(CODD_GN_PAIR="1")], ids=["mfma", "pair"])
+def test_se3_gn_step_builder_variants_match_j_entry_builder(env):
+    """se3_gn_build2_kernel (CODD_GN_MFMA=1: affinity dot products as split-bf16 MFMA Gram blocks) and
+    se3_gn_build3_kernel (CODD_GN_PAIR=1: two neighbours per step in packed fp32, factored normal
+    equations) against the J-entry builder se3_gn_build_kernel<false> on the same inputs (odd width: the pair builder's
+    phantom partner), in child processes (the switches are read once per process)."""
     import os
     import subprocess
     import sys
@@ -1067,15 +1070,15 @@ torch.save(Tg.cpu(), sys.argv[1])
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for flag in ("0", "1"):
-        path = os.path.join(root, "gpurun_out", f"_gn_mfma_{flag}.pt")
+    for flag, e in (("0", dict(CODD_GN_MFMA="0", CODD_GN_PAIR="0")), ("1", env)):
+        path = os.path.join(root, "gpurun_out", f"_gn_variant_{flag}.pt")
         os.makedirs(os.path.dirname(path), exist_ok=True)
-        subprocess.run([sys.executable, "-c", code, path], cwd=root, env=dict(os.environ, CODD_GN_MFMA=flag), check=True, timeout=300)
+        subprocess.run([sys.executable, "-c", code, path], cwd=root, env=dict(os.environ, **e), check=True, timeout=300)
         outs.append(torch.load(path))
         os.remove(path)
     step = (outs[0][..., :3]).abs().max().item()
     err = (outs[0] - outs[1]).abs().max().item()
-    print("scalar vs MFMA builder: max |delta T|", err, "step", step)
+    print("J-entry builder vs", env, ": max |delta T|", err, "step", step)
     assert err < 1e-4 * max(1.0, step)
 
 
