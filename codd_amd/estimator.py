@@ -35,7 +35,7 @@ class ConsistentOnlineDynamicDepth(RuntimeState, nn.Module):
         """reference model/codd.py:80-126 (eval: everything under no_grad)."""
         with torch.no_grad():
             if self.motion is not None and hasattr(self.motion, "prefetch"):
-                self.motion.prefetch(left_img, state)  # image-only work (+ correlation pyramid) overlaps the stereo network
+                self.motion.prefetch(left_img, state, img_metas)  # image-only work (+ correlation pyramid) overlaps the stereo network
             outputs = self.stereo.stereo_matching(left_img, right_img, img_metas, state)
             if self.motion is not None:
                 if self.fusion is not None and hasattr(self.fusion, "prefetch_key"):

@@ -530,7 +530,10 @@ class RAFT3D(ops.RuntimeState, nn.Module):
             fmap_curr = self.fnet(image_curr)
         pyr = pre[1] if pre is not None and pre[0] is fmap_prev else ops.allpairs_corr(fmap_prev, fmap_curr)
         net, inp = (pl["net"], pl["inp"]) if pl is not None else ops.context_split(net_inp)
-        d1 = ops.subsample(depth_prev.contiguous(), 3, 3, 8)  # depth[:, 3::8, 3::8] (raft3d.py:213-216)
+        if pl is not None and pl.get("depth_prev") is depth_prev:
+            d1 = pl["d1"]
+        else:
+            d1 = ops.subsample(depth_prev.contiguous(), 3, 3, 8)  # depth[:, 3::8, 3::8] (raft3d.py:213-216)
         d2 = ops.subsample(depth_curr.contiguous(), 3, 3, 8)
         mask = weight = None
         zr = pl["zr"] if pl is not None else None
@@ -566,9 +569,24 @@ class Motion(ops.RuntimeState, nn.Module):
         self.raft3d = MODELS.build(raft3d)
         self.loss = build_loss(loss) if loss is not None else None
 
-    def prefetch(self, left_img, state=None):
-        """Issue the image-only parts of the motion stage (fnet [+ the correlation pyramid], cnet) on side streams."""
+    def prefetch(self, left_img, state=None, img_metas=None):
+        """Issue the image-only parts of the motion stage (fnet [+ the correlation pyramid], cnet) on side streams, and
+        behind them the state-only ones: the previous frame's depth map and its 1/8 sub-sampling (motion.py:154-159,
+        raft3d.py:213-216) -- same launches as in ``forward``, off the frame's critical path."""
         self.raft3d.prefetch(left_img, state)
+        pend = getattr(self.raft3d, "_pending", None)
+        if PRELOOP_SIDE and pend and "pre" in pend and img_metas is not None and len(state.get("memory", ())) == 3:
+            disp_prev = state["memory"][2]
+            bf = self._bf(img_metas)
+            with torch.cuda.stream(self.raft3d._side[0]):
+                depth_prev = ops.disp_to_depth(disp_prev.contiguous(), bf)
+                pend["pre"].update(disp_src=disp_prev, bf=bf, depth_prev=depth_prev,
+                                   d1=ops.subsample(depth_prev.contiguous(), 3, 3, 8))
+
+    @staticmethod
+    def _bf(img_metas):
+        fx = np.float32(img_metas[0]["intrinsics"][0])
+        return float(np.float32(np.float32(BF_DEFAULT) / fx) * fx)  # depth_scale * fx in fp32 (motion.py:154-159)
 
     def forward(self, state, outputs, img_metas, train_mode=False, **kwargs):
         img_curr = outputs["left_img"]
@@ -576,12 +594,15 @@ class Motion(ops.RuntimeState, nn.Module):
             self.raft3d(img_curr, None, None, None, state, outputs, train_mode=train_mode)
             return
         intr = [np.float32(v) for v in img_metas[0]["intrinsics"]]
-        fx = intr[0]
-        bf = float(np.float32(np.float32(BF_DEFAULT) / fx) * fx)  # depth_scale * fx in fp32 (motion.py:154-159)
+        bf = self._bf(img_metas)
         K = [float(v) for v in intr]
         img_prev, feat_prev, disp_prev = state["memory"]
         disp_curr = outputs["pred_disp"]
-        depth_prev = ops.disp_to_depth(disp_prev.contiguous(), bf)  # [B,H,W]
+        pl = (getattr(self.raft3d, "_pending", None) or {}).get("pre")
+        if pl is not None and pl.get("disp_src") is disp_prev and pl.get("bf") == bf:
+            depth_prev = pl["depth_prev"]  # (made on the feature encoder's side stream: joined in RAFT3D.forward)
+        else:
+            depth_prev = ops.disp_to_depth(disp_prev.contiguous(), bf)  # [B,H,W]
         depth_curr = ops.disp_to_depth(disp_curr, bf).squeeze(1)
         self.raft3d(img_curr, depth_prev, depth_curr, intr, state, outputs, iters=self.iters, train_mode=train_mode)
         T_up = outputs["Ts"]
