@@ -356,11 +356,15 @@ __global__ __launch_bounds__(256) void disp_metrics_partial_kernel(const float* 
 }
 __global__ void disp_metrics_finish_kernel(const double* __restrict__ partial, int nblk, int B,
                                            double* __restrict__ meters) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // one wave: lane l adds partials l, l + 64, ... in index order, then a butterfly (fixed order: deterministic)
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
   for (int b = 0; b < B; ++b) {
     double se = 0.0, st = 0.0, sc = 0.0;
-    for (int i = 0; i < nblk; ++i) { const double* p = partial + ((size_t)b * nblk + i) * 3; se += p[0]; st += p[1]; sc += p[2]; }
-    if (sc > 0.0) { meters[0] += se / sc; meters[1] += st / sc; meters[2] += 1.0; }
+    for (int i = lane; i < nblk; i += 64) { const double* p = partial + ((size_t)b * nblk + i) * 3; se += p[0]; st += p[1]; sc += p[2]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { se += __shfl_xor(se, o, 64); st += __shfl_xor(st, o, 64); sc += __shfl_xor(sc, o, 64); }
+    if (lane == 0 && sc > 0.0) { meters[0] += se / sc; meters[1] += st / sc; meters[2] += 1.0; }
   }
 }
 
