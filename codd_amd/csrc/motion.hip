@@ -460,18 +460,24 @@ extern "C" int codd_raft_geometry(const float* T, const float* depth1, const flo
 // normalised image coordinates ((u - cx) / fx, (v - cy) / fy) and inverse depth, weights (wx fx^2, wy fy^2, wz), |a|^2;
 // the phantom partner of the last pixel of an odd-width row is written as zeros (depth 0 = masked, finite)
 static __device__ __forceinline__ void gn_geo2_store(float* __restrict__ geo2, int b, int h, int w, int yj, int xj, V3 X,
-                                                      float tx, float ty, float tz, float wx, float wy, float wz, float a2,
+                                                      float tx, float ty, float tz, float wx, float wy, float wz,
                                                       float fx, float fy, float cx, float cy) {
   if (!geo2) return;
   const int wp2 = (w + 1) >> 1;
   float* gp = geo2 + (((size_t)b * h + yj) * wp2 + (xj >> 1)) * 24 + (xj & 1);
-  const float v[12] = {X.x, X.y, X.z, (tx - cx) / fx, (ty - cy) / fy, tz, wx * fx * fx, wy * fy * fy, wz, a2, 0.f, 0.f};
+  const float v[9] = {X.x, X.y, X.z, (tx - cx) / fx, (ty - cy) / fy, tz, wx * fx * fx, wy * fy * fy, wz};
 #pragma unroll
-  for (int k = 0; k < 12; ++k) gp[2 * k] = v[k];
+  for (int k = 0; k < 9; ++k) gp[2 * k] = v[k];
+  gp[20] = 0.f; gp[22] = 0.f;
   if (xj == w - 1 && !(xj & 1)) {
 #pragma unroll
     for (int k = 0; k < 12; ++k) gp[2 * k + 1] = 0.f;
   }
+}
+static __device__ __forceinline__ void gn_geo2_store_a2(float* __restrict__ geo2, int b, int h, int w, int yj, int xj, float a2) {
+  if (!geo2) return;
+  const int wp2 = (w + 1) >> 1;
+  geo2[(((size_t)b * h + yj) * wp2 + (xj >> 1)) * 24 + (xj & 1) + 18] = a2;
 }
 __global__ void se3_gn_prep_kernel(const float* __restrict__ ae, int ae_c, const float* __restrict__ xyz,
                                    const float* __restrict__ delta, const float* __restrict__ wgt,
@@ -507,7 +513,8 @@ __global__ void se3_gn_prep_kernel(const float* __restrict__ ae, int ae_c, const
   rp[35] = xb[0] + db[0]; rp[36] = xb[1] + db[N]; rp[37] = xb[2] + db[2 * N];
   rp[38] = wb[0]; rp[39] = wb[N]; rp[40] = wb[2 * N];
   rp[41] = a2; rp[42] = 0.f; rp[43] = 0.f;
-  gn_geo2_store(geo2, b, h, w, yj, xj, X, rp[35], rp[36], rp[37], rp[38], rp[39], rp[40], a2, fx, fy, cx, cy);
+  gn_geo2_store(geo2, b, h, w, yj, xj, X, rp[35], rp[36], rp[37], rp[38], rp[39], rp[40], fx, fy, cx, cy);
+  gn_geo2_store_a2(geo2, b, h, w, yj, xj, a2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -524,7 +531,10 @@ __global__ void se3_gn_prep_kernel(const float* __restrict__ ae, int ae_c, const
 // [32 (tile, k-step) blocks][plane hi|lo][lane][8 bf16] (64 KB, L2-resident).  Same 3-term split arithmetic as the
 // convolution kernel (conv_bf16_kernel.h).  Lane (g = lane / 16) ends up with rows 4g..4g+3 of every tile for its
 // pixel = 4 consecutive floats of the record.
-__global__ __launch_bounds__(64) void gn_heads_prep_kernel(const codd_xs_view hs, const uint4* __restrict__ Wp,
+// Workgroup = TWO waves over the same 16 pixels: wave 0 owns the two ae tiles (hidden channels 0..255: 8 k-steps),
+// wave 1 the delta | weight tile (channels 256..767: 16 k-steps) -- every accumulator chain is the single-wave kernel's
+// own (same order, same bits), the launch has twice the waves and two thirds of the longest dependent chain.
+__global__ __launch_bounds__(128) void gn_heads_prep_kernel(const codd_xs_view hs, const uint4* __restrict__ Wp,
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ xyz, const float* __restrict__ d1,
                                                           int h, int w, float fx, float fy, float cx, float cy,
@@ -532,8 +542,9 @@ __global__ __launch_bounds__(64) void gn_heads_prep_kernel(const codd_xs_view hs
                                                           int* __restrict__ cnt, int ntiles,
                                                           unsigned short* __restrict__ aeq, float* __restrict__ geo2) {
   const int N = h * w;
-  const int lane = threadIdx.x, px = lane & 15, g = lane >> 4, b = blockIdx.y;
-  if (lane == 0)  // arrival counters of the builder launched next
+  const int lane = threadIdx.x & 63, px = lane & 15, g = lane >> 4, b = blockIdx.y;
+  const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (threadIdx.x == 0)  // arrival counters of the builder launched next
     for (int i = blockIdx.x; i < ntiles; i += gridDim.x) cnt[b * ntiles + i] = 0;
   const int n = blockIdx.x * 16 + px;
   const bool ok = n < N;
@@ -576,23 +587,43 @@ __global__ __launch_bounds__(64) void gn_heads_prep_kernel(const codd_xs_view hs
     }                                                                                                   \
     acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[T], 0, 0, 0);                          \
   }
+  float* rp = jd + ((size_t)b * N + j) * GN_JS;
+  if (role == 1) {
+    HEADS_LOAD(1, 1)
+    HEADS_LOAD(2, 0)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) HEADS_MMA(2, s, 1, s)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) HEADS_MMA(2, s, 0, s)
+    // tile 2: g = 0 holds (delta0, delta1, delta2, weight0), g = 1 holds (weight1, weight2, 0, 0)
+    const float w1 = __shfl_down(acc[2][0], 16, 64), w2 = __shfl_down(acc[2][1], 16, 64);
+    if (g == 0 && ok) {
+      const V3 X = inv_project(d1[(size_t)b * N + j], xj, yj, fx, fy, cx, cy);
+      const float* xb = xyz + ((size_t)b * N + j) * 3;
+      const float dl0 = acc[2][0] + bias[32], dl1 = acc[2][1] + bias[33], dl2 = acc[2][2] + bias[34];
+      float wv[3] = {acc[2][3] + bias[35], w1 + bias[36], w2 + bias[37]};
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        wv[r] = 1.f / (1.f + expf(-wv[r]));
+        wout[((size_t)b * 3 + r) * N + j] = wv[r];
+      }
+      *(f32x4*)(rp + 32) = f32x4{X.x, X.y, X.z, xb[0] + dl0};
+      *(f32x4*)(rp + 36) = f32x4{xb[1] + dl1, xb[2] + dl2, wv[0], wv[1]};
+      rp[40] = wv[2];  // (rp[41] = |a|^2: wave 0)
+      *(float2*)(rp + 42) = float2{0.f, 0.f};
+      gn_geo2_store(geo2, b, h, w, yj, xj, X, xb[0] + dl0, xb[1] + dl1, xb[2] + dl2, wv[0], wv[1], wv[2], fx, fy, cx, cy);
+    }
+    return;
+  }
   HEADS_LOAD(0, 0)
-  HEADS_LOAD(1, 1)
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     HEADS_MMA(0, s, 0, s)
     HEADS_MMA(1, 8 + s, 0, s)
   }
-  __builtin_amdgcn_sched_barrier(0);
-  HEADS_LOAD(2, 0)
-#pragma unroll
-  for (int s = 0; s < 8; ++s) HEADS_MMA(2, s, 1, s)
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int s = 0; s < 8; ++s) HEADS_MMA(2, s, 0, s)
 #undef HEADS_LOAD
 #undef HEADS_MMA
-  float* rp = jd + ((size_t)b * N + j) * GN_JS;
   // ae rows 16 t + 4 g + r -> record floats [16 t + 4 g, +4)
   float a2 = 0.f;
 #pragma unroll
@@ -620,22 +651,9 @@ __global__ __launch_bounds__(64) void gn_heads_prep_kernel(const codd_xs_view hs
   }
   a2 += __shfl_xor(a2, 16, 64);
   a2 += __shfl_xor(a2, 32, 64);
-  // tile 2: g = 0 holds (delta0, delta1, delta2, weight0), g = 1 holds (weight1, weight2, 0, 0)
-  const float w1 = __shfl_down(acc[2][0], 16, 64), w2 = __shfl_down(acc[2][1], 16, 64);
   if (g == 0 && ok) {
-    const V3 X = inv_project(d1[(size_t)b * N + j], xj, yj, fx, fy, cx, cy);
-    const float* xb = xyz + ((size_t)b * N + j) * 3;
-    const float dl0 = acc[2][0] + bias[32], dl1 = acc[2][1] + bias[33], dl2 = acc[2][2] + bias[34];
-    float wv[3] = {acc[2][3] + bias[35], w1 + bias[36], w2 + bias[37]};
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      wv[r] = 1.f / (1.f + expf(-wv[r]));
-      wout[((size_t)b * 3 + r) * N + j] = wv[r];
-    }
-    *(f32x4*)(rp + 32) = f32x4{X.x, X.y, X.z, xb[0] + dl0};
-    *(f32x4*)(rp + 36) = f32x4{xb[1] + dl1, xb[2] + dl2, wv[0], wv[1]};
-    *(f32x4*)(rp + 40) = f32x4{wv[2], a2, 0.f, 0.f};
-    gn_geo2_store(geo2, b, h, w, yj, xj, X, xb[0] + dl0, xb[1] + dl1, xb[2] + dl2, wv[0], wv[1], wv[2], a2, fx, fy, cx, cy);
+    rp[41] = a2;
+    gn_geo2_store_a2(geo2, b, h, w, yj, xj, a2);
   }
 }
 
@@ -1338,7 +1356,7 @@ extern "C" int codd_se3_gn_step_heads(float* T, codd_xs_view hidden, const void*
   const int ntiles = cdiv(w, 8) * cdiv(h, 8);
   float* jd = Hb + (size_t)B * ntiles * gn_gmax(radius) * 27 * 64;
   hipStream_t s = (hipStream_t)stream;
-  gn_heads_prep_kernel<<<dim3(cdiv(h * w, 16), B), 64, 0, s>>>(hidden, (const uint4*)head_w, head_b, xyz, depth1, h, w, fx, fy, cx, cy,
+  gn_heads_prep_kernel<<<dim3(cdiv(h * w, 16), B), 128, 0, s>>>(hidden, (const uint4*)head_w, head_b, xyz, depth1, h, w, fx, fy, cx, cy,
                                                                jd, weight_out, gn_counters(Hb, B, h, w, radius), ntiles,
                                                                (unsigned short*)(Hb + gn_aeq_offset(B, h, w, radius)),
                                                              Hb + gn_geo2_offset(B, h, w, radius));
