@@ -1255,9 +1255,11 @@ __global__ __launch_bounds__(64 * GN_SOLVE_WAVES) void se3_gn_solve_kernel(
 // the per-workgroup partial (6.9 KB) stay in the noise.
 static inline bool gn_pair();
 static inline int gn_q4() {
-  // 128 for the J-entry builder, 256 for the pair builder (half as many steps per neighbour, a pair slot lost at each
-  // end of a row segment: 103.5 us at 128, 100.3 at 192, 99.4 at 256, 104.7 at 384); CODD_GN_Q4 = dev override
-  static const int q = getenv("CODD_GN_Q4") ? atoi(getenv("CODD_GN_Q4")) : (gn_pair() ? 256 : 128);
+  // 128 for the J-entry builder, 192 for the pair builder (half as many steps per neighbour, a pair slot lost at each
+  // end of a row segment: 103.5 us at 128, 100.3 at 192, 99.4 at 256, 104.7 at 384; 256 is also the one grouping of
+  // eight tried -- both builders -- that takes the 16-frame cfg3 sequence through the other branch of the frame-6
+  // event, profiles/r04_gn_grouping_vs_trajectory.log); CODD_GN_Q4 = dev override
+  static const int q = getenv("CODD_GN_Q4") ? atoi(getenv("CODD_GN_Q4")) : (gn_pair() ? 192 : 128);
   return q < 16 ? 16 : q;
 }
 static inline int gn_gmax(int radius) {
@@ -1291,9 +1293,9 @@ static inline bool gn_mfma() {
   return f;
 }
 static inline bool gn_pair() {
-  // 1 = se3_gn_build3_kernel: two neighbours per step in packed fp32, factored normal equations; 0 (default) = the
+  // 1 (default) = se3_gn_build3_kernel: two neighbours per step in packed fp32, factored normal equations; 0 = the
   // J-entry builder se3_gn_build_kernel<false> (A/B: DESIGN finding 45)
-  static const bool f = getenv("CODD_GN_PAIR") && atoi(getenv("CODD_GN_PAIR")) == 1;
+  static const bool f = !(getenv("CODD_GN_PAIR") && atoi(getenv("CODD_GN_PAIR")) == 0);
   return f;
 }
 static inline bool gn_fused_solve() {

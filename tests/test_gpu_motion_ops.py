@@ -1046,7 +1046,7 @@ def test_hrmodule_fused_sum_equals_per_term_launches():
 @pytest.mark.parametrize("env", [dict(CODD_GN_MFMA="1", CODD_GN_PAIR="0"), dict(CODD_GN_PAIR="1")], ids=["mfma", "pair"])
 def test_se3_gn_step_builder_variants_match_j_entry_builder(env):
     """se3_gn_build2_kernel (CODD_GN_MFMA=1: affinity dot products as split-bf16 MFMA Gram blocks) and
-    se3_gn_build3_kernel (CODD_GN_PAIR=1: two neighbours per step in packed fp32, factored normal
+    se3_gn_build3_kernel (CODD_GN_PAIR=1, the default: two neighbours per step in packed fp32, factored normal
     equations) against the J-entry builder se3_gn_build_kernel<false> on the same inputs (odd width: the pair builder's
     phantom partner), in child processes (the switches are read once per process)."""
     import os
