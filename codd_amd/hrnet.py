@@ -393,7 +393,7 @@ class HRNet(ops.RuntimeState, nn.Module):
         ops.Fork.prefork)."""
         fk = self.__dict__.get("_fk")
         if fk is None or fk.dev != device:
-            fk = self.__dict__["_fk"] = ops.Fork(device, len(self.out_channels) - 1)
+            fk = self.__dict__["_fk"] = ops.Fork(device, len(self.out_channels) - 1, critical=False)
         return fk
 
 

@@ -455,7 +455,7 @@ class RAFT3D(ops.RuntimeState, nn.Module):
             return
         dev = image.device
         if getattr(self, "_side", None) is None or self._side[0].device != dev:
-            self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            self._side = (ops.new_stream(dev), ops.new_stream(dev, critical=False))
         cur = torch.cuda.current_stream(dev)
         out = {}
         from . import hrnet as _hr

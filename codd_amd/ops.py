@@ -1672,6 +1672,15 @@ def gru_gate_q(t1, t2, inp, cor, mot, zr, h):
     return ho
 
 
+# (A/B, off) HIP stream priorities: the streams of the frame's critical path (capture stream, stereo decoder, update-loop
+# forks, feature encoder) at high priority, the context network's (read by the next frame only) at normal
+STREAM_PRIO = __import__("os").environ.get("CODD_STREAM_PRIO", "0") == "1"
+
+
+def new_stream(device, critical=True):
+    return torch.cuda.Stream(device=device, priority=-1 if (STREAM_PRIO and critical) else 0)
+
+
 class Fork:
     """Fork / join of independent launch chains over side HIP streams (parallel branches of the
     captured frame graph).  Discipline: every branch starts by waiting on the caller's stream, only
@@ -1680,9 +1689,9 @@ class Fork:
 
     serial = False  # debugging / per-launch timing: run every branch on the caller's stream
 
-    def __init__(self, device, n):
+    def __init__(self, device, n, critical=True):
         self.dev = device
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(n)]
+        self.streams = [new_stream(device, critical) for _ in range(n)]
         self.used = []
         self.inline = False  # this fork only: run the branches on the caller's stream (A/B switches of call sites)
 

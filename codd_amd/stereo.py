@@ -475,7 +475,7 @@ class HITNetMF(ops.RuntimeState, nn.Module):
         L, R = (lambda i: feas[i][:B]), (lambda i: feas[i][B:])
         rt = self.__dict__.get("_pipe")
         if rt is None or rt[0].device != dev:
-            rt = self.__dict__["_pipe"] = (torch.cuda.Stream(device=dev), torch.cuda.Event(), torch.cuda.Event())
+            rt = self.__dict__["_pipe"] = (ops.new_stream(dev), torch.cuda.Event(), torch.cuda.Event())
         side, ev3, ev2 = rt
         cur = torch.cuda.current_stream(dev)
         side.wait_stream(cur)
