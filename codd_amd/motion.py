@@ -446,7 +446,7 @@ class RAFT3D(ops.RuntimeState, nn.Module):
     # ~200 small launches fill the CUs that HITNet's coarse levels and the GRU loop's 576-block
     # convolutions leave idle; under stream capture this becomes two parallel branches of the frame
     # graph.
-    def prefetch(self, image, state=None):  # noqa: C901
+    def prefetch(self, image, state=None, fork_event=None):  # noqa: C901
         """``state``: the recurrent state of the sequence; when it holds the previous frame's feature map the all-pairs
         correlation pyramid (reference blocks/corr.py:28-45: a function of the two feature maps only) is built on the
         fnet side stream as well, i.e. beside the stereo network instead of in front of the update loop."""
@@ -462,7 +462,10 @@ class RAFT3D(ops.RuntimeState, nn.Module):
         if _hr.FORK_BRANCHES and hasattr(self.cnet[0], "fork") and getattr(self.cnet[0], "fork_branches", True):
             self.cnet[0].fork(dev).prefork(cur)  # HRNet's branch streams join the frame graph through THIS stream
         for key, stream, fn in (("fmap", self._side[0], self.fnet), ("netinp", self._side[1], self.context)):
-            stream.wait_stream(cur)
+            if fork_event is not None:
+                stream.wait_event(fork_event)  # (forks from the frame's start, not from the caller's last launch)
+            else:
+                stream.wait_stream(cur)
             if key == "netinp" and CNET_AFTER_FNET:
                 stream.wait_stream(self._side[0])  # (A/B) the context network yields to the feature encoder + pyramid
             with torch.cuda.stream(stream):
@@ -569,11 +572,11 @@ class Motion(ops.RuntimeState, nn.Module):
         self.raft3d = MODELS.build(raft3d)
         self.loss = build_loss(loss) if loss is not None else None
 
-    def prefetch(self, left_img, state=None, img_metas=None):
+    def prefetch(self, left_img, state=None, img_metas=None, fork_event=None):
         """Issue the image-only parts of the motion stage (fnet [+ the correlation pyramid], cnet) on side streams, and
         behind them the state-only ones: the previous frame's depth map and its 1/8 sub-sampling (motion.py:154-159,
         raft3d.py:213-216) -- same launches as in ``forward``, off the frame's critical path."""
-        self.raft3d.prefetch(left_img, state)
+        self.raft3d.prefetch(left_img, state, fork_event=fork_event)
         pend = getattr(self.raft3d, "_pending", None)
         if PRELOOP_SIDE and pend and "pre" in pend and img_metas is not None and len(state.get("memory", ())) == 3:
             disp_prev = state["memory"][2]
