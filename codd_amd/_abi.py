@@ -117,6 +117,7 @@ SIGNATURES = {
     "codd_add_relu": (_i, [_p, _p, _ll, _i, _p, _p]),
     "codd_hr_fuse_sum": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "codd_copy_many": (_i, [_p, _p, _p, _i, _p]),
+    "codd_timestamp": (_i, [_p, _p]),
     "codd_gru_gate_zr": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
     "codd_gru_gate_q": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p, _p]),
     "codd_gru_gate_zr_xs": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p, XsView, _p]),
@@ -141,7 +142,7 @@ SIGNATURES = {
     "codd_fusion_blend": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 8  # CODD_ABI_VERSION of include/codd_hip.h
+ABI_VERSION = 9  # CODD_ABI_VERSION of include/codd_hip.h
 _lib = None
 MISSING = []
 

@@ -368,6 +368,14 @@ __global__ void disp_metrics_finish_kernel(const double* __restrict__ partial, i
   }
 }
 
+__global__ void timestamp_kernel(long long* slot) { *slot = wall_clock64(); }
+extern "C" int codd_timestamp(long long* slot, void* stream) {
+  if (!slot) return CODD_EINVAL;
+  timestamp_kernel<<<1, 1, 0, (hipStream_t)stream>>>(slot);
+  CODD_LAUNCH_CHECK();
+  return CODD_OK;
+}
+
 extern "C" int codd_disp_metrics(const float* pred, const float* gt, int B, int H, int W, int h, int w, float lo,
                                  float hi, float thr, double* scratch, double* meters, void* stream) {
   if (!pred || !gt || !scratch || !meters || h > H || w > W || h < 1 || w < 1) return CODD_EINVAL;

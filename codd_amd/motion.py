@@ -32,6 +32,10 @@ FNET_CORESIDENT = os.environ.get("CODD_FNET_CORESIDENT", "0") == "1"
 # the context network (read by the NEXT frame only) starts after the feature encoder + correlation pyramid (which the
 # update loop of THIS frame waits for) instead of beside them (A/B)
 CNET_AFTER_FNET = os.environ.get("CODD_CNET_AFTER_FNET", "0") == "1"
+# (A/B) the context network -- read by the NEXT frame only -- issued in portions from inside the update loop (one portion
+# in front of every CNET_LOOP_EVERY-th Gauss-Newton step, on its own stream) instead of beside the stereo network
+CNET_IN_LOOP = os.environ.get("CODD_CNET_IN_LOOP", "0") == "1"
+CNET_LOOP_EVERY = int(os.environ.get("CODD_CNET_LOOP_EVERY", "2"))
 # the state-only launches in front of the first update (RAFT3D._preloop) on the fnet side stream behind the pyramid
 PRELOOP_SIDE = os.environ.get("CODD_PRELOOP_SIDE", "1") == "1"
 # the flow encoder's 7x7 convolution beside the correlation encoder's first 3x3: 1 = small-footprint configurations for
@@ -461,7 +465,11 @@ class RAFT3D(ops.RuntimeState, nn.Module):
         from . import hrnet as _hr
         if _hr.FORK_BRANCHES and hasattr(self.cnet[0], "fork") and getattr(self.cnet[0], "fork_branches", True):
             self.cnet[0].fork(dev).prefork(cur)  # HRNet's branch streams join the frame graph through THIS stream
+        in_loop = CNET_IN_LOOP and state is not None and "memory" in state and not getattr(self, "_nowait", False)
         for key, stream, fn in (("fmap", self._side[0], self.fnet), ("netinp", self._side[1], self.context)):
+            if key == "netinp" and in_loop:
+                out["netinp_chunks"] = self._context_chunks(image)  # resumed from RAFT3D.forward's update loop
+                continue
             if fork_event is not None:
                 stream.wait_event(fork_event)  # (forks from the frame's start, not from the caller's last launch)
             else:
@@ -481,6 +489,30 @@ class RAFT3D(ops.RuntimeState, nn.Module):
                     if PRELOOP_SIDE and state.get("raft_netinp") is not None:
                         out["pre"] = self._preloop(state["raft_netinp"])
         self._pending = out
+
+    def _context_chunks(self, image):
+        """``context`` as a generator of portions (HRNet.chunks + the resize / concat / 1x1 head); the LAST value is
+        the result.  The exact-fp32 stage policy is entered per portion by the caller (it is a process-wide switch)."""
+        ys = None
+        for ys in self.cnet[0].chunks(image):
+            if ys is None:
+                yield None
+        yield None
+        yield self.cnet[1](ys)
+
+    def _resume_context(self, pend, dev, first):
+        """One portion of the context network on its side stream (forked from the caller's stream at the first one)."""
+        gen = pend.get("netinp_chunks")
+        if gen is None:
+            return
+        side = self._side[1]
+        if first:
+            side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), ops.stage("context"):
+            r = next(gen)
+        if r is not None:
+            pend["netinp"] = r
+            del pend["netinp_chunks"]
 
     def _preloop(self, net_inp):
         """The launches in front of the first update that only read the PREVIOUS frame's state (the context network's
@@ -547,10 +579,14 @@ class RAFT3D(ops.RuntimeState, nn.Module):
             xyz, minfo, corr = ops.raft_geometry_lookup(T, d1, d2, K8, pyr, minfo_xs=mxs, corr_xs=cxs)
             net, mask, ae, delta, weight, zr, hid = self.update_block.run(
                 net, inp, corr, minfo, need_mask=it == iters - 1, zr=zr, prefetch_next=it < iters - 1, fuse_heads=True)
+            if it % CNET_LOOP_EVERY == 0:
+                self._resume_context(pend, dev, first=it == 0)
             if hid is not None:  # split-bf16 path: heads + record packing in one launch
                 weight = ops.se3_gn_step_heads(T, hid, *self.update_block.head_matrix(), xyz, d1, K8, radius=32)
             else:
                 ops.se3_gn_step(T, ae, xyz, delta, weight, d1, K8, radius=32)
+        while "netinp_chunks" in pend:  # (fewer updates than portions)
+            self._resume_context(pend, dev, first=False)
         self.update_block._forks(dev)[0].join()  # the mask head's 1x1 convolution (forked beside the last Gauss-Newton step)
         T_up, outputs["weight"] = ops.cvx_upsample_se3_weight(T, weight.contiguous(), mask)  # one pass over the mask
         outputs["Ts"] = T_up

@@ -1770,6 +1770,13 @@ def fusion_blend(pred_curr, pred_warp, wf_lr, wr, ds=4):
     return fused, wf, wro
 
 
+def timestamp(buf, idx):
+    """(diagnostics) buf[idx] (int64, device) = device wall clock (100 MHz) when this launch runs on the current stream."""
+    lib = _abi.load()
+    _require_gpu(buf)
+    _abi.check(lib.codd_timestamp(buf.data_ptr() + 8 * idx, _stream()), "timestamp")
+
+
 def disp_metrics(pred, gt, crop_hw, lo, hi, thr, meters, scratch=None):
     """Accumulate EPE / threshold-rate of one frame into ``meters`` ([3] fp64 on the device)."""
     lib = _abi.load()

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CODD_ABI_VERSION 8
+#define CODD_ABI_VERSION 9
 
 #define CODD_OK 0
 #define CODD_EINVAL (-1)
@@ -429,6 +429,10 @@ int codd_hr_fuse_sum(const codd_hr_term* terms, int n, int B, int C, int H, int 
 /* dst[k][0..n[k]) = src[k][0..n[k]) for k < count <= 8 in ONE launch (the recurrent-state write-back at the end of a
  * captured frame); every n[k] a multiple of 4, every pointer 16-byte aligned. */
 int codd_copy_many(const float* const* src, float* const* dst, const long long* n, int count, void* stream);
+
+/* Diagnostics: *slot = the device's constant-rate wall clock (100 MHz ticks) when this one-thread launch runs -- a
+ * marker inside a captured frame that does not perturb the replay the way a profiler does (tools/frame_marks.py). */
+int codd_timestamp(long long* slot, void* stream);
 
 /* ConvGRU gate fusions (blocks/gru.py:17-34).  t1, t2: the two gate convolutions of a gate pair
  * (3x3 and dilated 3x3, bias included); inp / cor / mot [B,384,hw]: the three input streams.
