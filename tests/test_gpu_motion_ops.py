@@ -1163,3 +1163,17 @@ def test_hrnet_launch_reductions_keep_every_bit():
     finally:
         for f, v in saved.items():
             setattr(hrnet, f, v)
+
+
+def test_timestamp_marks_are_ordered():
+    """codd_timestamp (diagnostics, ABI v9): two marks around a launch on one stream are ordered, 100 MHz ticks."""
+    from codd_amd import ops
+    marks = torch.zeros(4, dtype=torch.int64, device=DEV)
+    ops.timestamp(marks, 0)
+    x = torch.randn(1 << 22, device=DEV)
+    for _ in range(20):
+        x = x * 1.0001
+    ops.timestamp(marks, 1)
+    torch.cuda.synchronize()
+    t0, t1 = marks[0].item(), marks[1].item()
+    assert t0 > 0 and 0 < t1 - t0 < 100e6 * 5  # (positive, and less than five seconds of ticks)
