@@ -687,9 +687,12 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
 #define CONVB_GROUP_I(X) X(4, 1, 3, 2, 2) X(4, 1, 3, 4, 2)
 #define CONVB_GROUP_J(X) X(4, 2, 4, 2, 1)
 #define CONVB_GROUP_K(X) X(4, 2, 3, 2, 1)
+//   (8,1,4,4): 32-unit tiles (16 x 32 px) x 64 channels on 8 consumer waves of 64 px x 64 co each (the largest
+//   per-wave tile: 8 fragment reads per 16 MFMAs against 6 per 8 for (4,2,4,2); two-deep ring)
+#define CONVB_GROUP_L(X) X(8, 1, 4, 4, 1)
 #define CONVB_ALL(X)                                                                                   \
   CONVB_GROUP_A(X) CONVB_GROUP_B(X) CONVB_GROUP_C(X) CONVB_GROUP_D(X) CONVB_GROUP_E(X) CONVB_GROUP_F(X) \
-  CONVB_GROUP_G(X) CONVB_GROUP_H(X) CONVB_GROUP_I(X) CONVB_GROUP_J(X) CONVB_GROUP_K(X)
+  CONVB_GROUP_G(X) CONVB_GROUP_H(X) CONVB_GROUP_I(X) CONVB_GROUP_J(X) CONVB_GROUP_K(X) CONVB_GROUP_L(X)
 #define CONVB_DECLARE(PGW, CGW, A, B, KS)                                                        \
   extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, 0, KS>(const ConvB);      \
   extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 0, KS>(const ConvB);      \

@@ -288,7 +288,8 @@ def _small_footprint(cands):
 _B_INST = ((2, 2, 5, 2, 1), (4, 1, 4, 4, 1), (4, 1, 4, 2, 1), (4, 1, 4, 1, 1), (4, 1, 8, 1, 1), (4, 1, 2, 2, 1),
            (4, 1, 2, 1, 1), (4, 1, 3, 4, 1), (4, 1, 3, 2, 1),
            # 8 consumer waves (two per SIMD): k-split pairs (ks = 2) and 4x2 wave grids that split the tile
-           (2, 2, 5, 2, 2), (4, 1, 4, 2, 2), (4, 1, 3, 2, 2), (4, 1, 3, 4, 2), (4, 2, 4, 2, 1), (4, 2, 3, 2, 1))
+           (2, 2, 5, 2, 2), (4, 1, 4, 2, 2), (4, 1, 3, 2, 2), (4, 1, 3, 4, 2), (4, 2, 4, 2, 1), (4, 2, 3, 2, 1),
+           (8, 1, 4, 4, 1))
 _B_TILES = {5: ((9, 1), (10, 1), (5, 2)), 4: ((8, 2), (16, 1)), 8: ((16, 2),), 2: ((4, 2), (8, 1)), 3: ((12, 1), (6, 2))}
 
 
@@ -301,7 +302,7 @@ def _bf16_candidates(pc, Hout, Wout, B, taps, terms):
         mb = b * cgw
         if mb > 1 and mb // 2 >= nblk:  # a channel group at least twice as wide as the layer
             continue
-        for (th, xb) in _B_TILES[a]:
+        for (th, xb) in _B_TILES[a * pgw // 4 if pgw == 8 else a]:  # (tiles are listed by pixel units per 4 waves)
             grid = -(-Hout // th) * -(-Wout // (16 * xb)) * -(-pc.cout_eff // (16 * mb)) * B
             rounds = -(-grid // 256)
             cost = rounds * (pgw * a) * mb

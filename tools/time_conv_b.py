@@ -21,6 +21,10 @@ LAYERS = [  # cin, cout, k, stride, pad, dil, H, W
 ]
 
 
+if os.environ.get("LAYER"):  # dev: one extra layer "cin,cout,k,stride,pad,dil,H,W" (becomes index 0)
+    LAYERS.insert(0, tuple(int(v) for v in os.environ["LAYER"].split(",")))
+
+
 def timeit(fn, n=5):
     fn()
     torch.cuda.synchronize()
@@ -81,8 +85,8 @@ def main():
             t = timeit(lambda: ops.conv2d(xd, pc, stride=s, pad=p, dil=d, out=out))
             res.append((t, c, err))
         res.sort(key=lambda r: r[0])
-        for t, c, err in res[:6]:
-            print(f"      {t:7.1f} us {gflop / t * 1e3:6.1f} TF  cfg(xb,th,ck,mb,_,pgw,cgw)={c[:7]} err {err:.1e}")
+        for t, c, err in res[:6] + [r for r in res[6:] if r[1][5] == 8]:
+            print(f"      {t:7.1f} us {gflop / t * 1e3:6.1f} TF  cfg(xb,th,ck,mb,_,pgw,cgw,terms,ks)={c} err {err:.1e}")
         bad = [r for r in res if not r[2] < (1e-4 if terms == 3 else 2e-2)]
         if bad:
             print("      !!! WRONG:", [(c[:7], e) for _, c, e in bad][:5])
