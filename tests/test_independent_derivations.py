@@ -102,6 +102,63 @@ def test_gauss_newton_builder_against_autograd_jacobians():
         assert (bo - bi).abs().max() < 2e-4 * max(1.0, bi.abs().max()), (i, (bo - bi).abs().max())
 
 
+def test_factored_normal_equations_of_the_pair_builder_equal_jt_w_j():
+    """se3_gn_build3_kernel (csrc/motion.hip) never forms the 3x6 Jacobian: it accumulates
+        S^ = a A^T W A^  (A^ = [fx 0 -fx xn; 0 fy -fy yn; 0 0 -d], Y = (xn, yn, 1) / d),   N = S^ Q,   Q = -[(xn, yn, 1)]x,
+        H_tt = d^2 S^,  H_tr = d N,  H_rr = Q^T N,   g^ = a A^T W r,  b_t = d g^,  b_r = Q^T g^
+    with the pixel residuals taken in units of fx, fy (normalised targets, weights x f^2: the record image ``geo2``).  Here
+    the same formulas in fp64, entry by entry as the kernel writes them, against J^T W J / J^T W r with J obtained by
+    automatic differentiation through the matrix exponential."""
+    torch.manual_seed(3)
+    fx, fy, cx, cy = 9.0, 8.5, 3.2, 2.4
+    for trial in range(6):
+        Mi = _mat(se3.exp(torch.randn(6) * 0.2))
+        X = torch.tensor([0.4, -0.3, 2.5], dtype=torch.float64) + torch.randn(3, dtype=torch.float64) * 0.3
+        tgt = torch.randn(3, dtype=torch.float64) * torch.tensor([3.0, 3.0, 0.2], dtype=torch.float64)
+        w = torch.rand(3, dtype=torch.float64)
+        a = float(torch.rand(1)) * 0.9 + 0.05
+
+        def proj_of_twist(xi):
+            Y = (torch.linalg.matrix_exp(_hat6(xi)) @ Mi @ torch.cat([X, X.new_ones(1)]))[:3]
+            return torch.stack([fx * Y[0] / Y[2] + cx, fy * Y[1] / Y[2] + cy, 1.0 / Y[2]])
+
+        z6 = torch.zeros(6, dtype=torch.float64)
+        J = torch.autograd.functional.jacobian(proj_of_twist, z6)
+        r = tgt - proj_of_twist(z6)
+        Wm = torch.diag(a * w)
+        H_ref, b_ref = J.t() @ Wm @ J, J.t() @ Wm @ r
+
+        # the kernel's formulas (names as in se3_gn_build3_kernel)
+        Y = (Mi @ torch.cat([X, X.new_ones(1)]))[:3]
+        d = 1.0 / Y[2]
+        xn, yn = Y[0] * d, Y[1] * d
+        tnx, tny, tz = (tgt[0] - cx) / fx, (tgt[1] - cy) / fy, tgt[2]  # geo2: normalised target
+        Wx, Wy, wz = w[0] * fx * fx, w[1] * fy * fy, w[2]               # geo2: weights x f^2
+        rx, ry, rz = tnx - xn, tny - yn, tz - d
+        S00, S11, t = a * Wx, a * Wy, a * wz * d
+        S02, S12 = -(S00 * xn), -(S11 * yn)
+        S22 = t * d - (S12 * yn + S02 * xn)
+        g0, g1 = S00 * rx, S11 * ry
+        g2 = -(t * rz + g1 * yn + g0 * xn)
+        dd = d * d
+        N00, N01, N02 = yn * S02, -xn * S02 + S00, -(yn * S00)
+        N10, N11, N12 = yn * S12 - S11, -(xn * S12), xn * S11
+        N20, N21, N22 = yn * S22 - S12, -xn * S22 + S02, xn * S12 - N00
+        H = torch.zeros(6, 6, dtype=torch.float64)
+        H[0, 0], H[1, 1], H[0, 2], H[1, 2], H[2, 2] = dd * S00, dd * S11, dd * S02, dd * S12, dd * S22
+        H[0, 3], H[0, 4], H[0, 5] = d * N00, d * N01, d * N02
+        H[1, 3], H[1, 4], H[1, 5] = d * N10, d * N11, d * N12
+        H[2, 3], H[2, 4], H[2, 5] = d * N20, d * N21, d * N22
+        H[3, 3], H[3, 4], H[3, 5] = yn * N20 - N10, yn * N21 - N11, yn * N22 - N12
+        H[4, 4], H[4, 5] = -xn * N21 + N01, -xn * N22 + N02
+        H[5, 5] = xn * N12 - yn * N02
+        H = torch.triu(H) + torch.triu(H, 1).t()
+        b = torch.stack([d * g0, d * g1, d * g2, yn * g2 - g1, -xn * g2 + g0, xn * g1 - yn * g0])
+        assert (H - H_ref).abs().max() < 1e-10 * max(1.0, H_ref.abs().max()), (trial, (H - H_ref).abs().max())
+        assert (b - b_ref).abs().max() < 1e-10 * max(1.0, b_ref.abs().max()), (trial, (b - b_ref).abs().max())
+        assert abs(H_ref[0, 1]) < 1e-12  # (the structural zero the builders do not accumulate)
+
+
 def test_gauss_newton_solve_is_the_damped_normal_equation():
     torch.manual_seed(2)
     J = torch.randn(1, 4, 5, 12, 6)
