@@ -14,7 +14,7 @@ from .registry import MODELS, register
 
 
 # (A/B) issue order of the frame: 1 = stereo network first, image-only branches forked from a frame-start event
-STEREO_FIRST = __import__("os").environ.get("CODD_STEREO_FIRST", "0") == "1"
+STEREO_FIRST = int(__import__("os").environ.get("CODD_STEREO_FIRST", "0"))  # 2: feature encoder, stereo, context network
 
 
 @register
@@ -47,9 +47,12 @@ class ConsistentOnlineDynamicDepth(RuntimeState, nn.Module):
                 # follows the issue order: DESIGN finding 47)
                 ev0 = torch.cuda.Event()
                 ev0.record(torch.cuda.current_stream(left_img.device))
+            if pre and STEREO_FIRST == 2:
+                self.motion.prefetch(left_img, state, img_metas, fork_event=ev0 if left_img.is_cuda else None, part="fmap")
             outputs = self.stereo.stereo_matching(left_img, right_img, img_metas, state)
             if pre and STEREO_FIRST:
-                self.motion.prefetch(left_img, state, img_metas, fork_event=ev0 if left_img.is_cuda else None)
+                self.motion.prefetch(left_img, state, img_metas, fork_event=ev0 if left_img.is_cuda else None,
+                                     part="netinp" if STEREO_FIRST == 2 else None)
             if self.motion is not None:
                 if self.fusion is not None and hasattr(self.fusion, "prefetch_key"):
                     self.fusion.prefetch_key(outputs["left_feat"])  # key projection beside the motion stage

@@ -450,7 +450,7 @@ class RAFT3D(ops.RuntimeState, nn.Module):
     # ~200 small launches fill the CUs that HITNet's coarse levels and the GRU loop's 576-block
     # convolutions leave idle; under stream capture this becomes two parallel branches of the frame
     # graph.
-    def prefetch(self, image, state=None, fork_event=None):  # noqa: C901
+    def prefetch(self, image, state=None, fork_event=None, part=None):  # noqa: C901
         """``state``: the recurrent state of the sequence; when it holds the previous frame's feature map the all-pairs
         correlation pyramid (reference blocks/corr.py:28-45: a function of the two feature maps only) is built on the
         fnet side stream as well, i.e. beside the stereo network instead of in front of the update loop."""
@@ -461,12 +461,14 @@ class RAFT3D(ops.RuntimeState, nn.Module):
         if getattr(self, "_side", None) is None or self._side[0].device != dev:
             self._side = (ops.new_stream(dev), ops.new_stream(dev, critical=False))
         cur = torch.cuda.current_stream(dev)
-        out = {}
+        out = self._pending if part == "netinp" and getattr(self, "_pending", None) else {}
         from . import hrnet as _hr
         if _hr.FORK_BRANCHES and hasattr(self.cnet[0], "fork") and getattr(self.cnet[0], "fork_branches", True):
             self.cnet[0].fork(dev).prefork(cur)  # HRNet's branch streams join the frame graph through THIS stream
         in_loop = CNET_IN_LOOP and state is not None and "memory" in state and not getattr(self, "_nowait", False)
         for key, stream, fn in (("fmap", self._side[0], self.fnet), ("netinp", self._side[1], self.context)):
+            if part is not None and key != part:
+                continue
             if key == "netinp" and in_loop:
                 out["netinp_chunks"] = self._context_chunks(image)  # resumed from RAFT3D.forward's update loop
                 continue
@@ -477,7 +479,20 @@ class RAFT3D(ops.RuntimeState, nn.Module):
             if key == "netinp" and CNET_AFTER_FNET:
                 stream.wait_stream(self._side[0])  # (A/B) the context network yields to the feature encoder + pyramid
             with torch.cuda.stream(stream):
-                out[key] = fn(image)
+                if key == "netinp" and fork_event is not None:
+                    # (stereo-first issue order) the update loop is made to wait for the context network's FIRST portion,
+                    # so that the replay -- which walks the captured branches depth-first in issue order -- places the
+                    # whole context network in front of the update loop instead of behind it (DESIGN finding 47)
+                    with ops.stage("context"):
+                        gen = self._context_chunks(image)
+                        r = next(gen)
+                        out["netinp_head"] = torch.cuda.Event()
+                        out["netinp_head"].record(stream)
+                        while r is None:
+                            r = next(gen)
+                    out[key] = r
+                else:
+                    out[key] = fn(image)
                 if key == "netinp" and _DUMMY_LAUNCHES:  # (dev what-if: tiny dependent launches on the context stream)
                     t_ = out[key][:, :1, :8, :8].contiguous()
                     u_ = torch.empty_like(t_)
@@ -563,6 +578,9 @@ class RAFT3D(ops.RuntimeState, nn.Module):
         fmap_curr = self._join("fmap", dev)
         if fmap_curr is None:
             fmap_curr = self.fnet(image_curr)
+        head = pend.pop("netinp_head", None)
+        if head is not None:
+            torch.cuda.current_stream(dev).wait_event(head)
         pyr = pre[1] if pre is not None and pre[0] is fmap_prev else ops.allpairs_corr(fmap_prev, fmap_curr)
         net, inp = (pl["net"], pl["inp"]) if pl is not None else ops.context_split(net_inp)
         if pl is not None and pl.get("depth_prev") is depth_prev:
@@ -608,12 +626,14 @@ class Motion(ops.RuntimeState, nn.Module):
         self.raft3d = MODELS.build(raft3d)
         self.loss = build_loss(loss) if loss is not None else None
 
-    def prefetch(self, left_img, state=None, img_metas=None, fork_event=None):
+    def prefetch(self, left_img, state=None, img_metas=None, fork_event=None, part=None):
         """Issue the image-only parts of the motion stage (fnet [+ the correlation pyramid], cnet) on side streams, and
         behind them the state-only ones: the previous frame's depth map and its 1/8 sub-sampling (motion.py:154-159,
         raft3d.py:213-216) -- same launches as in ``forward``, off the frame's critical path."""
-        self.raft3d.prefetch(left_img, state, fork_event=fork_event)
+        self.raft3d.prefetch(left_img, state, fork_event=fork_event, part=part)
         pend = getattr(self.raft3d, "_pending", None)
+        if part == "netinp":
+            return
         if PRELOOP_SIDE and pend and "pre" in pend and img_metas is not None and len(state.get("memory", ())) == 3:
             disp_prev = state["memory"][2]
             bf = self._bf(img_metas)
