@@ -1014,6 +1014,158 @@ __global__ __launch_bounds__(64 * GN_WAVES) void se3_gn_build3_kernel(
   for (int k = wave; k < 27; k += GN_WAVES) pp[k * 64] = red[k][lane];
 }
 
+#ifndef GN_CH2
+#define GN_CH2 8
+#endif
+// GN_CH2: pairs per chunk of the two-pass builder (4 KB of affinities per wave)
+__global__ __launch_bounds__(64 * GN_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void se3_gn_build4_kernel(
+    const float* __restrict__ T, const float* __restrict__ jd, const float* __restrict__ geo2, int h, int w, float fx,
+    float fy, float cx, float cy, int radius, int tiles_x, int ntiles, int q4, int gmax, float* __restrict__ part) {
+  __shared__ float red[27][64];
+  __shared__ v2f abuf[GN_WAVES][GN_CH2][64];  // per wave: the affinities of a chunk of pairs, [pair][lane] = (a_j0, a_j1)
+  const int N = h * w, wp2 = (w + 1) >> 1;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+  const int tx0 = (tile % tiles_x) * 8, ty0 = (tile / tiles_x) * 8;
+  const int ylo = max(ty0 - radius, 0), yhi = min(ty0 + 7 + radius, h - 1);
+  const int xlo = max(tx0 - radius, 0), xhi = min(tx0 + 7 + radius, w - 1);
+  const int ncols = xhi - xlo + 1, nj = (yhi - ylo + 1) * ncols;
+  const int G = gn_groups(nj, q4, gmax);
+  if (g >= G) return;
+  const int slot = g * GN_WAVES + wave, nslots = G * GN_WAVES;
+  const int s0 = (int)((long long)nj * slot / nslots), s1 = (int)((long long)nj * (slot + 1) / nslots);
+  const int ys = ylo + s0 / ncols, xs = xlo + s0 % ncols;
+  const int ye = ylo + (s1 - 1) / ncols, xe = xlo + (s1 - 1) % ncols;
+
+  const int xi = tx0 + (lane & 7), yi = ty0 + (lane >> 3);
+  const bool vi = xi < w && yi < h;
+  const int i = vi ? yi * w + xi : 0;
+  const int xim = xi - radius, yim = yi - radius;
+  const unsigned twor = 2u * (unsigned)radius;
+  const float* rec = jd + (size_t)b * N * GN_JS;
+  const float* aip = rec + (size_t)i * GN_JS;
+  const SE3T Ti = se3_load(T + ((size_t)b * N + i) * 7);
+  const V3 c0 = qrot(Ti.q, V3{1.f, 0.f, 0.f}), c1 = qrot(Ti.q, V3{0.f, 1.f, 0.f}), c2 = qrot(Ti.q, V3{0.f, 0.f, 1.f});
+  const v2f Z = {0.f, 0.f};
+  v2f H00 = Z, H11 = Z, H02 = Z, H12 = Z, H22 = Z, H03 = Z, H04 = Z, H05 = Z, H13 = Z, H14 = Z, H15 = Z, H23 = Z, H24 = Z,
+      H25 = Z, H33 = Z, H34 = Z, H35 = Z, H44 = Z, H45 = Z, H55 = Z, b0 = Z, b1 = Z, b2 = Z, b3 = Z, b4 = Z, b5 = Z;
+#define BC(s) ((v2f){(s), (s)})
+
+  // TWO-PASS walk over the wave's pairs, row by row, in chunks of GN_CH2 pairs (DESIGN finding 51).  Pass 1 needs the
+  // pixel's own embedding (32 VGPRs) and the pair's two embeddings (64 SGPRs) and leaves the unmasked affinities
+  // sigmoid(-|a_i - a_j|^2) in the wave's LDS slice; pass 2 needs the geometry pairs (20 SGPRs), the 52 accumulators and
+  // the geometry's temporaries -- not the embeddings.  Neither pass holds the other's registers: <= 128 VGPRs (4 waves
+  // per SIMD instead of 3) and one awaited group of scalar loads per pair and pass instead of three or four per pair.
+  v2f(*const ab)[64] = abuf[wave];
+  if (s1 > s0)
+  for (int yj = ys; yj <= ye; ++yj) {
+    const bool rowin = vi && (unsigned)(yj - yim) <= twor;
+    const float* rrow = rec + (size_t)yj * w * GN_JS;
+    const v2f* grow = (const v2f*)(geo2 + ((size_t)b * h + yj) * wp2 * GN_G2);
+    const int xa = yj == ys ? xs : xlo, xb = yj == ye ? xe : xhi;
+    for (int pc = xa >> 1; pc <= (xb >> 1); pc += GN_CH2) {
+      const int np = min(GN_CH2, (xb >> 1) - pc + 1);
+      unsigned skip = 0;
+      {  // ---- pass 1: affinities
+        // the pixel's embedding is re-read per chunk (L2-resident) through a pointer the compiler cannot hoist the
+        // loads of: kept in registers over pass 2 it would cost the fourth wave per SIMD
+        const float* aq = aip;
+        asm("" : "+v"(aq) : "s"(pc), "s"(yj));
+        v2f ai[GN_AE / 2];
+#pragma unroll
+        for (int c = 0; c < GN_AE / 2; ++c) ai[c] = *(const v2f*)(aq + 2 * c);
+        const float ai2 = aq[41];
+        for (int pl = 0; pl < np; ++pl) {
+          const int x0 = 2 * (pc + pl);
+          const float4* e0 = (const float4*)(rrow + (size_t)x0 * GN_JS);
+          const float4* e1 = (const float4*)(rrow + (size_t)min(x0 + 1, w - 1) * GN_JS);
+          float4 r0[8], r1[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) r0[q] = e0[q];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) r1[q] = e1[q];
+          const v2f a2 = {((const float*)e0)[41], ((const float*)e1)[41]};
+          v2f p0 = Z, p1 = Z, q0 = Z, q1 = Z;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            p0 = GN_PK(ai[2 * q], (v2f){r0[q].x, r0[q].y}, p0);
+            p1 = GN_PK(ai[2 * q + 1], (v2f){r0[q].z, r0[q].w}, p1);
+            q0 = GN_PK(ai[2 * q], (v2f){r1[q].x, r1[q].y}, q0);
+            q1 = GN_PK(ai[2 * q + 1], (v2f){r1[q].z, r1[q].w}, q1);
+          }
+          p0 += p1;
+          q0 += q1;
+          const v2f dot = {p0.x + p0.y, q0.x + q0.y};
+          const v2f e2 = GN_PK(BC(-2.f), dot, BC(ai2) + a2);
+          const v2f au = {__builtin_amdgcn_rcpf(1.f + __expf(fmaxf(e2.x, 0.f))),
+                          __builtin_amdgcn_rcpf(1.f + __expf(fmaxf(e2.y, 0.f)))};  // sigmoid(-d2)
+          ab[pl][lane] = au;
+          // the affinity of far neighbours underflows against the accumulated sums (as in se3_gn_build_kernel; decided
+          // here, on the unmasked value, so that pass 2's step is one basic block)
+          skip |= __ballot(au.x > 1e-9f || au.y > 1e-9f) == 0ull ? 1u << pl : 0u;
+        }
+      }
+      // ---- pass 2: geometry (a wave reads back what it wrote: no barrier)
+      for (int pl = 0; pl < np; ++pl) {
+        if (skip >> pl & 1) continue;
+        const int x0 = 2 * (pc + pl), x1 = x0 + 1;
+        const bool own0 = x0 >= xa, own1 = x1 <= xb;  // (x0 <= xb and x1 >= xa always hold)
+        const v2f* gp = grow + (size_t)(pc + pl) * (GN_G2 / 2);
+        v2f G2[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) G2[k] = gp[k];
+        const v2f au = ab[pl][lane];
+        const v2f Xx = G2[0], Xy = G2[1], Xz = G2[2];
+        const v2f Yz = GN_PK(BC(c0.z), Xx, GN_PK(BC(c1.z), Xy, GN_PK(BC(c2.z), Xz, BC(Ti.t.z))));
+        const bool in0 = rowin & own0 & ((unsigned)(x0 - xim) <= twor) & (Xz.x >= MIN_DEPTH) & (Yz.x >= MIN_DEPTH);
+        const bool in1 = rowin & own1 & ((unsigned)(x1 - xim) <= twor) & (Xz.y >= MIN_DEPTH) & (Yz.y >= MIN_DEPTH);
+        const v2f a = {in0 ? au.x : 0.f, in1 ? au.y : 0.f};
+        const v2f Yx = GN_PK(BC(c0.x), Xx, GN_PK(BC(c1.x), Xy, GN_PK(BC(c2.x), Xz, BC(Ti.t.x))));
+        const v2f Yy = GN_PK(BC(c0.y), Xx, GN_PK(BC(c1.y), Xy, GN_PK(BC(c2.y), Xz, BC(Ti.t.y))));
+        const v2f d = {__builtin_amdgcn_rcpf(fmaxf(Yz.x, MIN_DEPTH)), __builtin_amdgcn_rcpf(fmaxf(Yz.y, MIN_DEPTH))};
+        const v2f xn = Yx * d, yn = Yy * d;
+        const v2f rx = G2[3] - xn, ry = G2[4] - yn, rz = G2[5] - d;  // (rx, ry in units of fx, fy: folded into S00, S11)
+        const v2f S00 = a * G2[6], S11 = a * G2[7], t = (a * G2[8]) * d;
+        const v2f S02 = -(S00 * xn), S12 = -(S11 * yn);
+        const v2f S22 = GN_PK(t, d, -GN_PK(S12, yn, S02 * xn));
+        const v2f g0 = S00 * rx, g1 = S11 * ry;
+        const v2f g2 = -GN_PK(t, rz, GN_PK(g1, yn, g0 * xn));
+        const v2f dd = d * d;
+        H00 = GN_PK(dd, S00, H00); H11 = GN_PK(dd, S11, H11); H02 = GN_PK(dd, S02, H02); H12 = GN_PK(dd, S12, H12);
+        H22 = GN_PK(dd, S22, H22);
+        const v2f N00 = yn * S02, N01 = GN_PK(-xn, S02, S00), N02 = -(yn * S00);
+        const v2f N10 = GN_PK(yn, S12, -S11), N11 = -(xn * S12), N12 = xn * S11;
+        const v2f N20 = GN_PK(yn, S22, -S12), N21 = GN_PK(-xn, S22, S02), N22 = GN_PK(xn, S12, -N00);
+        H03 = GN_PK(d, N00, H03); H04 = GN_PK(d, N01, H04); H05 = GN_PK(d, N02, H05);
+        H13 = GN_PK(d, N10, H13); H14 = GN_PK(d, N11, H14); H15 = GN_PK(d, N12, H15);
+        H23 = GN_PK(d, N20, H23); H24 = GN_PK(d, N21, H24); H25 = GN_PK(d, N22, H25);
+        H33 = GN_PK(yn, N20, H33) - N10; H34 = GN_PK(yn, N21, H34) - N11; H35 = GN_PK(yn, N22, H35) - N12;
+        H44 = GN_PK(-xn, N21, H44) + N01; H45 = GN_PK(-xn, N22, H45) + N02;
+        H55 = GN_PK(xn, N12, GN_PK(-yn, N02, H55));
+        b0 = GN_PK(d, g0, b0); b1 = GN_PK(d, g1, b1); b2 = GN_PK(d, g2, b2);
+        b3 = GN_PK(yn, g2, b3) - g1; b4 = GN_PK(-xn, g2, b4) + g0; b5 = GN_PK(xn, g1, GN_PK(-yn, g0, b5));
+      }
+    }
+  }
+#undef BC
+#define S2(v) ((v).x + (v).y)
+  const float Hs[27] = {S2(H00), 0.f, S2(H02), S2(H03), S2(H04), S2(H05), S2(H11), S2(H12), S2(H13), S2(H14), S2(H15),
+                        S2(H22), S2(H23), S2(H24), S2(H25), S2(H33), S2(H34), S2(H35), S2(H44), S2(H45), S2(H55),
+                        S2(b0), S2(b1), S2(b2), S2(b3), S2(b4), S2(b5)};
+#undef S2
+  float* pp = part + (((size_t)b * ntiles + tile) * gmax + g) * 27 * 64 + lane;
+#pragma unroll
+  for (int w_ = 0; w_ < GN_WAVES; ++w_) {  // (same one-image reduction in wave order as se3_gn_build_kernel<false>)
+    if (wave == w_) {
+#pragma unroll
+      for (int k = 0; k < 27; ++k) red[k][lane] = w_ == 0 ? Hs[k] : red[k][lane] + Hs[k];
+    }
+    __syncthreads();
+  }
+  for (int k = wave; k < 27; k += GN_WAVES) pp[k * 64] = red[k][lane];
+}
+
 // MFMA builder (round 4, CODD_GN_MFMA=1; off by default, see gn_mfma()): the 32-term affinity dot products -- 18 of the scalar builder's 110
 // VALU instructions per neighbour -- move to the bf16 matrix pipe, which this VALU-bound kernel leaves idle.
 //   * neighbours are taken 16 at a time; Gram block G[j][i] = <ae_j, ae_i> for the tile's 64 pixels by
@@ -1292,6 +1444,11 @@ static inline bool gn_mfma() {
   static const bool f = getenv("CODD_GN_MFMA") && atoi(getenv("CODD_GN_MFMA")) == 1;
   return f;
 }
+static inline bool gn_two_pass() {
+  // (with the pair builder) 1 = se3_gn_build4_kernel: affinities and geometry in two passes per chunk of 8 pairs
+  static const bool f = getenv("CODD_GN_TWO_PASS") && atoi(getenv("CODD_GN_TWO_PASS")) == 1;
+  return f;
+}
 static inline bool gn_pair() {
   // 1 (default) = se3_gn_build3_kernel: two neighbours per step in packed fp32, factored normal equations; 0 = the
   // J-entry builder se3_gn_build_kernel<false> (A/B: DESIGN finding 45)
@@ -1317,7 +1474,10 @@ static int gn_build_solve(float* T, int B, int h, int w, float fx, float fy, flo
     CODD_LAUNCH_CHECK();
     return CODD_OK;
   }
-  if (gn_pair() && !gn_mfma())
+  if (gn_pair() && !gn_mfma() && gn_two_pass())
+    se3_gn_build4_kernel<<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, s>>>(T, jd, Hb + gn_geo2_offset(B, h, w, radius), h, w, fx, fy,
+                                                                        cx, cy, radius, tiles_x, ntiles, q4, gmax, part);
+  else if (gn_pair() && !gn_mfma())
     se3_gn_build3_kernel<<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, s>>>(T, jd, Hb + gn_geo2_offset(B, h, w, radius), h, w, fx, fy,
                                                                         cx, cy, radius, tiles_x, ntiles, q4, gmax, part);
   else if (gn_mfma())

@@ -1043,7 +1043,8 @@ def test_hrmodule_fused_sum_equals_per_term_launches():
         assert a.shape == b.shape and (a - b).abs().max().item() < 1e-4 * max(1.0, a.abs().max().item())
 
 
-@pytest.mark.parametrize("env", [dict(CODD_GN_MFMA="1", CODD_GN_PAIR="0"), dict(CODD_GN_PAIR="1")], ids=["mfma", "pair"])
+@pytest.mark.parametrize("env", [dict(CODD_GN_MFMA="1", CODD_GN_PAIR="0"), dict(CODD_GN_PAIR="1", CODD_GN_TWO_PASS="0"),
+                                 dict(CODD_GN_PAIR="1", CODD_GN_TWO_PASS="1")], ids=["mfma", "pair", "pair_two_pass"])
 def test_se3_gn_step_builder_variants_match_j_entry_builder(env):
     """se3_gn_build2_kernel (CODD_GN_MFMA=1: affinity dot products as split-bf16 MFMA Gram blocks) and
     se3_gn_build3_kernel (CODD_GN_PAIR=1, the default: two neighbours per step in packed fp32, factored normal

@@ -32,6 +32,11 @@ int main() {
   const float* jd = Hb + (size_t)B * ntiles * gmax * 27 * 64;
   const bool pair = getenv("GN3") && atoi(getenv("GN3")) == 1;  // the pair builder (se3_gn_build3_kernel)
   auto launch = [&]() {
+    if (pair && getenv("GN4") && atoi(getenv("GN4")) == 1) {  // the two-pass pair builder
+      se3_gn_build4_kernel<<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, 0>>>(dT, jd, Hb + gn_geo2_offset(B, h, w, radius), h, w, fx, fy, cx,
+                                                                          cy, radius, tiles_x, ntiles, q4, gmax, Hb);
+      return;
+    }
     if (pair) {
       se3_gn_build3_kernel<<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, 0>>>(dT, jd, Hb + gn_geo2_offset(B, h, w, radius), h, w, fx, fy, cx,
                                                                           cy, radius, tiles_x, ntiles, q4, gmax, Hb);
