@@ -2,7 +2,8 @@
 """bench.py -- frames/sec of the full CODD forward (stereo -> motion -> fusion) at 960x540.
 
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 launched with
-``python -m torch.distributed.run --nproc-per-node N ...`` (one rank per GPU, RCCL).
+``python -m torch.distributed.run --nproc-per-node N ...`` (one rank per GPU, RCCL); a plain ``python bench.py --gpus N``
+launches itself that way (self_launch).
 
 A "step" is ONE steady-state frame (frame index >= 1, so motion and fusion run; the reference's own
 benchmark_speed.py:36-65 only ever times frame 0) of full CODD on a synthetic 960x540 stereo
@@ -136,7 +137,50 @@ def parse():
                          "rocprofv3 run whose per-kernel averages are compared with the roofline numbers")
     ap.add_argument("--height", type=int, default=PAD_H)
     ap.add_argument("--width", type=int, default=PAD_W)
+    ap.add_argument("--dry-run-cpu", action="store_true", help=argparse.SUPPRESS)  # tests/test_bench_dist.py: launch path on gloo / CPU with a stub runner
     return ap.parse_args()
+
+
+def self_launch(args):
+    """``python bench.py --gpus N`` with N > 1 and no launcher around it: re-execute this script under
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N`` (one rank per GPU, rendezvous on 127.0.0.1 and a
+    free port) -- what the reference's scripts/inference_dist.sh:11-12 does for inference.py:88,130-135 -- and pass the
+    children's stdout (rank 0's single JSON line) and exit code through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("self-launch: " + " ".join(cmd))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run_cpu(args, rank, local, world):
+    """The launch path and the timed region's control flow without a GPU (gloo, stub runner): what
+    tests/test_bench_dist.py drives at N = 2 to check that ``--gpus N`` launches itself and rank 0 prints ONE line."""
+    import torch.distributed as dist
+    from codd_amd import metrics
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    seqm = metrics.SequenceMetrics(dict(disp_range=(1, 210)), dev)
+    gt = torch.full((1, 1, 8, 12), 20.0)
+
+    def step(l, r):
+        time.sleep(0.002)
+        return gt + (1.0 + rank)
+
+    dt, red = timed_region(step, lambda i: (None, None, gt), args.steps, lambda d, g: seqm.update(d, g), seqm.row, dev, True)
+    mine = torch.tensor([rank, local, args.steps], dtype=torch.int64)
+    allr = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (CPU stub runner, gloo)", "value": round(world * args.steps / dt, 3), "unit": "frames/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
+                          "epe_vs_synthetic_gt": red["epe"][0], "config": {"ranks_seen": [t.tolist() for t in allr]}}), flush=True)
+    dist.destroy_process_group()
 
 
 def build_model(args, device):
@@ -446,8 +490,10 @@ def main():
     use_dist = world > 1 or "RANK" in os.environ  # launched by torch.distributed.run -> RCCL even at N = 1
     if world != args.gpus and "RANK" in os.environ:
         raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: one rank per GPU is the contract")
-    if args.gpus > 1 and "RANK" not in os.environ:
-        raise SystemExit(f"bench.py --gpus {args.gpus} must be launched by torch.distributed.run (one rank per GPU)")
+    if args.gpus > 1 and "RANK" not in os.environ:  # plain `python bench.py --gpus N`: become the launcher
+        raise SystemExit(self_launch(args))
+    if args.dry_run_cpu:
+        return dry_run_cpu(args, rank, local, world)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")

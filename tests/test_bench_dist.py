@@ -56,6 +56,28 @@ def test_bench_timed_region_world_size_2():
     assert n == 2 and abs(mean - 1.5) < 1e-9 and abs(std - 0.5) < 1e-9 and r1["epe"] == r0["epe"]  # one video per rank
 
 
+def test_bench_gpus_n_launches_itself():
+    """`python bench.py --gpus 2` WITHOUT a launcher around it: the script must re-execute itself under
+    torch.distributed.run, one rank per GPU, and rank 0 must print exactly one JSON line for the whole job.  Driven on
+    gloo / CPU through the hidden --dry-run-cpu mode (stub runner; same self_launch(), timed_region() and rank plumbing)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--dry-run-cpu"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
+    assert sorted(out["config"]["ranks_seen"]) == [[0, 0, 4], [1, 1, 4]]
+    # launched WITH a world size that contradicts --gpus: refused, not silently run
+    env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu"], env=env2,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
+
+
 def test_rank_core_pinning_partitions_the_host():
     import bench
     before = os.sched_getaffinity(0)
