@@ -13,10 +13,6 @@ from .ops import RuntimeState
 from .registry import MODELS, register
 
 
-# (A/B) issue order of the frame: 1 = stereo network first, image-only branches forked from a frame-start event
-STEREO_FIRST = int(__import__("os").environ.get("CODD_STEREO_FIRST", "0"))  # 2: feature encoder, stereo, context network
-
-
 @register
 class ConsistentOnlineDynamicDepth(RuntimeState, nn.Module):
     def __init__(self, stereo=None, motion=None, fusion=None, train_cfg=None, test_cfg=None, init_cfg=None,
@@ -39,20 +35,11 @@ class ConsistentOnlineDynamicDepth(RuntimeState, nn.Module):
         """reference model/codd.py:80-126 (eval: everything under no_grad)."""
         with torch.no_grad():
             pre = self.motion is not None and hasattr(self.motion, "prefetch")
-            if pre and not STEREO_FIRST:
-                self.motion.prefetch(left_img, state, img_metas)  # image-only work (+ correlation pyramid) overlaps the stereo network
-            elif pre and left_img.is_cuda:
-                # (A/B) the stereo network's launches are ISSUED first; the image-only branches fork from an event recorded
-                # at the frame's start, so they still depend on nothing but the image (the replay of a captured frame
-                # follows the issue order: DESIGN finding 47)
-                ev0 = torch.cuda.Event()
-                ev0.record(torch.cuda.current_stream(left_img.device))
-            if pre and STEREO_FIRST == 2:
-                self.motion.prefetch(left_img, state, img_metas, fork_event=ev0 if left_img.is_cuda else None, part="fmap")
+            if pre:
+                # image-only work (+ the correlation pyramid) on side streams beside the stereo network; issued FIRST: the
+                # replay of a captured frame follows the issue order of its branches (DESIGN.md finding 47)
+                self.motion.prefetch(left_img, state, img_metas)
             outputs = self.stereo.stereo_matching(left_img, right_img, img_metas, state)
-            if pre and STEREO_FIRST:
-                self.motion.prefetch(left_img, state, img_metas, fork_event=ev0 if left_img.is_cuda else None,
-                                     part="netinp" if STEREO_FIRST == 2 else None)
             if self.motion is not None:
                 if self.fusion is not None and hasattr(self.fusion, "prefetch_key"):
                     self.fusion.prefetch_key(outputs["left_feat"])  # key projection beside the motion stage

@@ -77,7 +77,7 @@ class Fusion(ops.RuntimeState, nn.Module):
         dev = left_feat.device
         side = self.__dict__.get("_kside")
         if side is None or side.device != dev:
-            side = self.__dict__["_kside"] = ops.new_stream(dev)
+            side = self.__dict__["_kside"] = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side), ops.stage("fusion"):
             self.__dict__["_pending"] = (left_feat, self._key(left_feat), side)

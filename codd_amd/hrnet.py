@@ -369,14 +369,6 @@ class HRNet(ops.RuntimeState, nn.Module):
         self.out_channels = s4
 
     def forward(self, x):
-        for ys in self.chunks(x):
-            pass
-        return ys
-
-    def chunks(self, x):
-        """The forward pass as a generator over 8 portions of ~14 launches (stem + layer1 + transition1, then one
-        HRModule each); yields None after each portion but the last, which yields the branch outputs.  A caller that
-        spreads the network over another launch sequence resumes it portion by portion (RAFT3D.forward)."""
         x = cbn(self.conv1, self.bn1, x, "relu")
         x = cbn(self.conv2, self.bn2, x, "relu")
         for blk in self.layer1:
@@ -384,29 +376,24 @@ class HRNet(ops.RuntimeState, nn.Module):
         t0, t1 = self.transition1[0], self.transition1[1][0]
         ys = [cbn(t0[0], t0[1], x, "relu"), cbn(t1[0], t1[1], x, "relu")]
         fk = self.fork(x.device) if FORK_BRANCHES and getattr(self, "fork_branches", True) else None
-        yield None
         for m in self.stage2:
             ys = m.run(ys, fk)
-            yield None
         t = self.transition2[2][0]
         ys = ys + [cbn(t[0], t[1], ys[-1], "relu")]
         for m in self.stage3:
             ys = m.run(ys, fk)
-            yield None
         t = self.transition3[3][0]
         ys = ys + [cbn(t[0], t[1], ys[-1], "relu")]
-        for i, m in enumerate(self.stage4):
+        for m in self.stage4:
             ys = m.run(ys, fk)
-            if i + 1 < len(self.stage4):
-                yield None
-        yield ys
+        return ys
 
     def fork(self, device):
         """The branch streams (callers that run this network on a side stream pre-fork them from their origin stream:
         ops.Fork.prefork)."""
         fk = self.__dict__.get("_fk")
         if fk is None or fk.dev != device:
-            fk = self.__dict__["_fk"] = ops.Fork(device, len(self.out_channels) - 1, critical=False)
+            fk = self.__dict__["_fk"] = ops.Fork(device, len(self.out_channels) - 1)
         return fk
 
 

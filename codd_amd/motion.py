@@ -13,7 +13,6 @@ import os
 
 import numpy as np
 import torch
-_DUMMY_LAUNCHES = int(__import__("os").environ.get("CODD_DUMMY_LAUNCHES", "0"))
 import torch.nn as nn
 
 from . import ops
@@ -29,13 +28,6 @@ FUSE_NORM_RECORDS = os.environ.get("CODD_FUSE_NORM_RECORDS", "1") == "1"  # (A/B
 FUSE_GATES = os.environ.get("CODD_FUSE_GATES", "1") == "1"
 # the feature encoder runs on a side stream beside the stereo network: small-footprint launch configurations (A/B)
 FNET_CORESIDENT = os.environ.get("CODD_FNET_CORESIDENT", "0") == "1"
-# the context network (read by the NEXT frame only) starts after the feature encoder + correlation pyramid (which the
-# update loop of THIS frame waits for) instead of beside them (A/B)
-CNET_AFTER_FNET = os.environ.get("CODD_CNET_AFTER_FNET", "0") == "1"
-# (A/B) the context network -- read by the NEXT frame only -- issued in portions from inside the update loop (one portion
-# in front of every CNET_LOOP_EVERY-th Gauss-Newton step, on its own stream) instead of beside the stereo network
-CNET_IN_LOOP = os.environ.get("CODD_CNET_IN_LOOP", "0") == "1"
-CNET_LOOP_EVERY = int(os.environ.get("CODD_CNET_LOOP_EVERY", "2"))
 # the state-only launches in front of the first update (RAFT3D._preloop) on the fnet side stream behind the pyramid
 PRELOOP_SIDE = os.environ.get("CODD_PRELOOP_SIDE", "1") == "1"
 # the flow encoder's 7x7 convolution beside the correlation encoder's first 3x3: 1 = small-footprint configurations for
@@ -450,84 +442,32 @@ class RAFT3D(ops.RuntimeState, nn.Module):
     # ~200 small launches fill the CUs that HITNet's coarse levels and the GRU loop's 576-block
     # convolutions leave idle; under stream capture this becomes two parallel branches of the frame
     # graph.
-    def prefetch(self, image, state=None, fork_event=None, part=None):  # noqa: C901
+    def prefetch(self, image, state=None):
         """``state``: the recurrent state of the sequence; when it holds the previous frame's feature map the all-pairs
         correlation pyramid (reference blocks/corr.py:28-45: a function of the two feature maps only) is built on the
-        fnet side stream as well, i.e. beside the stereo network instead of in front of the update loop."""
+        fnet side stream as well, i.e. beside the stereo network instead of in front of the update loop.
+        (Issue orders that were measured and dropped -- stereo network first, context network after the feature encoder or in
+        portions inside the update loop, stream priorities: DESIGN.md findings 46-48, 50.)"""
         if ops.Fork.serial:
             self._pending = None
             return
         dev = image.device
         if getattr(self, "_side", None) is None or self._side[0].device != dev:
-            self._side = (ops.new_stream(dev), ops.new_stream(dev, critical=False))
+            self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
         cur = torch.cuda.current_stream(dev)
-        out = self._pending if part == "netinp" and getattr(self, "_pending", None) else {}
+        out = {}
         from . import hrnet as _hr
         if _hr.FORK_BRANCHES and hasattr(self.cnet[0], "fork") and getattr(self.cnet[0], "fork_branches", True):
             self.cnet[0].fork(dev).prefork(cur)  # HRNet's branch streams join the frame graph through THIS stream
-        in_loop = CNET_IN_LOOP and state is not None and "memory" in state and not getattr(self, "_nowait", False)
         for key, stream, fn in (("fmap", self._side[0], self.fnet), ("netinp", self._side[1], self.context)):
-            if part is not None and key != part:
-                continue
-            if key == "netinp" and in_loop:
-                out["netinp_chunks"] = self._context_chunks(image)  # resumed from RAFT3D.forward's update loop
-                continue
-            if fork_event is not None:
-                stream.wait_event(fork_event)  # (forks from the frame's start, not from the caller's last launch)
-            else:
-                stream.wait_stream(cur)
-            if key == "netinp" and CNET_AFTER_FNET:
-                stream.wait_stream(self._side[0])  # (A/B) the context network yields to the feature encoder + pyramid
+            stream.wait_stream(cur)
             with torch.cuda.stream(stream):
-                if key == "netinp" and fork_event is not None:
-                    # (stereo-first issue order) the update loop is made to wait for the context network's FIRST portion,
-                    # so that the replay -- which walks the captured branches depth-first in issue order -- places the
-                    # whole context network in front of the update loop instead of behind it (DESIGN finding 47)
-                    with ops.stage("context"):
-                        gen = self._context_chunks(image)
-                        r = next(gen)
-                        out["netinp_head"] = torch.cuda.Event()
-                        out["netinp_head"].record(stream)
-                        while r is None:
-                            r = next(gen)
-                    out[key] = r
-                else:
-                    out[key] = fn(image)
-                if key == "netinp" and _DUMMY_LAUNCHES:  # (dev what-if: tiny dependent launches on the context stream)
-                    t_ = out[key][:, :1, :8, :8].contiguous()
-                    u_ = torch.empty_like(t_)
-                    for _ in range(_DUMMY_LAUNCHES):
-                        ops.add_relu(t_, None, relu=False, out=u_)
-                        t_, u_ = u_, t_
+                out[key] = fn(image)
                 if key == "fmap" and state is not None and "memory" in state and state.get("raft_feat") is not None:
                     out["pyr"] = (state["raft_feat"], ops.allpairs_corr(state["raft_feat"], out["fmap"]))
                     if PRELOOP_SIDE and state.get("raft_netinp") is not None:
                         out["pre"] = self._preloop(state["raft_netinp"])
         self._pending = out
-
-    def _context_chunks(self, image):
-        """``context`` as a generator of portions (HRNet.chunks + the resize / concat / 1x1 head); the LAST value is
-        the result.  The exact-fp32 stage policy is entered per portion by the caller (it is a process-wide switch)."""
-        ys = None
-        for ys in self.cnet[0].chunks(image):
-            if ys is None:
-                yield None
-        yield None
-        yield self.cnet[1](ys)
-
-    def _resume_context(self, pend, dev, first):
-        """One portion of the context network on its side stream (forked from the caller's stream at the first one)."""
-        gen = pend.get("netinp_chunks")
-        if gen is None:
-            return
-        side = self._side[1]
-        if first:
-            side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side), ops.stage("context"):
-            r = next(gen)
-        if r is not None:
-            pend["netinp"] = r
-            del pend["netinp_chunks"]
 
     def _preloop(self, net_inp):
         """The launches in front of the first update that only read the PREVIOUS frame's state (the context network's
@@ -578,9 +518,6 @@ class RAFT3D(ops.RuntimeState, nn.Module):
         fmap_curr = self._join("fmap", dev)
         if fmap_curr is None:
             fmap_curr = self.fnet(image_curr)
-        head = pend.pop("netinp_head", None)
-        if head is not None:
-            torch.cuda.current_stream(dev).wait_event(head)
         pyr = pre[1] if pre is not None and pre[0] is fmap_prev else ops.allpairs_corr(fmap_prev, fmap_curr)
         net, inp = (pl["net"], pl["inp"]) if pl is not None else ops.context_split(net_inp)
         if pl is not None and pl.get("depth_prev") is depth_prev:
@@ -597,14 +534,10 @@ class RAFT3D(ops.RuntimeState, nn.Module):
             xyz, minfo, corr = ops.raft_geometry_lookup(T, d1, d2, K8, pyr, minfo_xs=mxs, corr_xs=cxs)
             net, mask, ae, delta, weight, zr, hid = self.update_block.run(
                 net, inp, corr, minfo, need_mask=it == iters - 1, zr=zr, prefetch_next=it < iters - 1, fuse_heads=True)
-            if it % CNET_LOOP_EVERY == 0:
-                self._resume_context(pend, dev, first=it == 0)
             if hid is not None:  # split-bf16 path: heads + record packing in one launch
                 weight = ops.se3_gn_step_heads(T, hid, *self.update_block.head_matrix(), xyz, d1, K8, radius=32)
             else:
                 ops.se3_gn_step(T, ae, xyz, delta, weight, d1, K8, radius=32)
-        while "netinp_chunks" in pend:  # (fewer updates than portions)
-            self._resume_context(pend, dev, first=False)
         self.update_block._forks(dev)[0].join()  # the mask head's 1x1 convolution (forked beside the last Gauss-Newton step)
         T_up, outputs["weight"] = ops.cvx_upsample_se3_weight(T, weight.contiguous(), mask)  # one pass over the mask
         outputs["Ts"] = T_up
@@ -626,14 +559,12 @@ class Motion(ops.RuntimeState, nn.Module):
         self.raft3d = MODELS.build(raft3d)
         self.loss = build_loss(loss) if loss is not None else None
 
-    def prefetch(self, left_img, state=None, img_metas=None, fork_event=None, part=None):
+    def prefetch(self, left_img, state=None, img_metas=None):
         """Issue the image-only parts of the motion stage (fnet [+ the correlation pyramid], cnet) on side streams, and
         behind them the state-only ones: the previous frame's depth map and its 1/8 sub-sampling (motion.py:154-159,
         raft3d.py:213-216) -- same launches as in ``forward``, off the frame's critical path."""
-        self.raft3d.prefetch(left_img, state, fork_event=fork_event, part=part)
+        self.raft3d.prefetch(left_img, state)
         pend = getattr(self.raft3d, "_pending", None)
-        if part == "netinp":
-            return
         if PRELOOP_SIDE and pend and "pre" in pend and img_metas is not None and len(state.get("memory", ())) == 3:
             disp_prev = state["memory"][2]
             bf = self._bf(img_metas)

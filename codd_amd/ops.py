@@ -540,23 +540,30 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
     p.terms = 0
     p.wpacked = pc.packed(ck, mb, 1 if layout == 3 else layout).data_ptr()  # (layout 3 = layout 1 weights, persistent kernel)
     p.mb, p.npb, p.nw, p.ck, p.layout = mb, npb, nw, ck, layout
+    heur = (key, (Hout, Wout, B, sy, sx, dy, dx, pl))
     if _DEFERRED is not None and layout == 1 and npb == 1 and nw == 4 and mb == 1:
         # inside ``with deferred_convs():`` -- recorded, launched on exit together with its independent neighbours
-        _DEFERRED.append((ConvParams.from_buffer_copy(p), (x, x2, res1, res2, post, out, pc)))
+        _DEFERRED.append((ConvParams.from_buffer_copy(p), (x, x2, res1, res2, post, out), pc, heur))
         return out
+    _launch_fp32(lib, p, pc, heur)
+    return out
+
+
+def _launch_fp32(lib, p, pc, heur):
+    """Launch one exact-fp32 convolution; a tuned / loaded configuration this build does not support (rc -2, e.g. a tune
+    db from another version) falls back to the heuristic configuration for this launch shape, loudly.  Shared by conv2d
+    and by deferred_convs' single-launch path."""
     rc = _launch_conv(lib, p, _stream())
     if rc == -2:
-        # a tuned / loaded configuration this build does not support (e.g. a tune db from another version):
-        # fall back to the heuristic for this launch shape, loudly
         import warnings
+        key, geom = heur
         warnings.warn("codd_amd: launch configuration %s rejected for conv %dx%d %d->%d, using the heuristic" % (
-            (npb, nw, ck, mb, layout), pc.kh, pc.kw, pc.cin, pc.cout))
-        npb, nw, ck = pc.tuned[key] = _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl)
+            (p.npb, p.nw, p.ck, p.mb, p.layout), pc.kh, pc.kw, pc.cin, pc.cout))
+        npb, nw, ck = pc.tuned[key] = _conv_cfg(pc, *geom)
         p.wpacked = pc.packed(ck, pc.mb, 0).data_ptr()
         p.mb, p.npb, p.nw, p.ck, p.layout = pc.mb, npb, nw, ck, 0
         rc = _launch_conv(lib, p, _stream())
     _abi.check(rc, "codd_conv2d")
-    return out
 
 
 def _db_cfg_ok(lib, p, c, sig):
@@ -616,9 +623,9 @@ class deferred_convs:
                 rc = _launch_conv_multi(lib, arr, len(chunk), _stream())
                 if rc not in (0, -2):
                     _abi.check(rc, "codd_conv2d_multi (deferred)")
-            if rc != 0:
-                for pp, _ in chunk:
-                    _abi.check(_launch_conv(lib, pp, _stream()), "codd_conv2d (deferred)")
+            if rc != 0:  # one job, or a multi-job launch this build rejects: single launches with conv2d's own fallback
+                for pp, _, pc, heur in chunk:
+                    _launch_fp32(lib, pp, pc, heur)
         return False
 
 
@@ -1104,8 +1111,11 @@ ROLL_C32 = _os.environ.get("CODD_ROLL_C32", "0") == "1"  # (dev: the 32-channel 
 def use_roll(C, B, Cin_unused, H, W):
     """Rolling-window launch for a C-channel stride-1 layer (pair) on a [B, *, H, W] map?  Measured on MI355X
     (tools/time_roll.py): 16 channels at >= 288x480x2 pixels 1.4-1.8x the tile kernels; the 32-channel class has too
-    few 64-column strips on HITNet's half-resolution maps to fill 256 CUs and stays on the tile kernels."""
-    return USE_ROLL and (C == 16 or (C == 32 and ROLL_C32)) and B * H * W >= ROLL_MIN_PIXELS
+    few 64-column strips on HITNet's half-resolution maps to fill 256 CUs and stays on the tile kernels.  The kernel is
+    exact fp32: under the plain bf16 mode (bf16 operands EVERYWHERE, BASELINE.json configs[4]) the layers stay on the bf16
+    tile kernels so that the mode's dtype description holds."""
+    return (USE_ROLL and CONV_PRECISION in ("split", "fp32") and (C == 16 or (C == 32 and ROLL_C32))
+            and B * H * W >= ROLL_MIN_PIXELS)
 
 
 class PackedRoll:
@@ -1505,8 +1515,11 @@ def subsample(x, oy, ox, step):
 
 
 def batch_pair(a, b):
-    """torch.cat([a, b], 0) of two contiguous fp32 tensors of one shape as ONE copy kernel of this library."""
-    assert a.shape == b.shape and a.dtype == b.dtype == torch.float32
+    """torch.cat([a, b], 0) of two contiguous fp32 tensors of one shape as ONE copy kernel of this library (other dtypes:
+    torch.cat, as before round 4)."""
+    assert a.shape == b.shape and a.dtype == b.dtype
+    if a.dtype != torch.float32:
+        return torch.cat([a, b], 0)
     out = torch.empty((2 * a.shape[0],) + tuple(a.shape[1:]), device=a.device, dtype=torch.float32)
     copy_many([(out[:a.shape[0]], a.contiguous()), (out[a.shape[0]:], b.contiguous())])
     return out
@@ -1673,15 +1686,6 @@ def gru_gate_q(t1, t2, inp, cor, mot, zr, h):
     return ho
 
 
-# (A/B, off) HIP stream priorities: the streams of the frame's critical path (capture stream, stereo decoder, update-loop
-# forks, feature encoder) at high priority, the context network's (read by the next frame only) at normal
-STREAM_PRIO = __import__("os").environ.get("CODD_STREAM_PRIO", "0") == "1"
-
-
-def new_stream(device, critical=True):
-    return torch.cuda.Stream(device=device, priority=-1 if (STREAM_PRIO and critical) else 0)
-
-
 class Fork:
     """Fork / join of independent launch chains over side HIP streams (parallel branches of the
     captured frame graph).  Discipline: every branch starts by waiting on the caller's stream, only
@@ -1690,9 +1694,9 @@ class Fork:
 
     serial = False  # debugging / per-launch timing: run every branch on the caller's stream
 
-    def __init__(self, device, n, critical=True):
+    def __init__(self, device, n):
         self.dev = device
-        self.streams = [new_stream(device, critical) for _ in range(n)]
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(n)]
         self.used = []
         self.inline = False  # this fork only: run the branches on the caller's stream (A/B switches of call sites)
 

@@ -58,7 +58,7 @@ class FrameRunner:
             dst.copy_(src)
         st["l"].copy_(left)
         st["r"].copy_(right)
-        stream = ops.new_stream(dev)
+        stream = torch.cuda.Stream(device=dev)
         stream.wait_stream(torch.cuda.current_stream(dev))
         g = torch.cuda.CUDAGraph()
 
@@ -195,7 +195,7 @@ class FrameRunner:
         """Stereo-only estimator (no motion / fusion, BASELINE.json configs[1]): no recurrent state."""
         dev = left.device
         st = dict(l=left.clone(), r=right.clone(), primed=True, state=[])
-        stream = ops.new_stream(dev)
+        stream = torch.cuda.Stream(device=dev)
         stream.wait_stream(torch.cuda.current_stream(dev))
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(stream):

@@ -132,8 +132,8 @@ class HITUNet(nn.Module):
         def seq(s, t):
             for m in s:
                 if isinstance(m, nn.Conv2d):
-                    if (m.kernel_size == (3, 3) and m.stride == (1, 1) and m.in_channels == m.out_channels and
-                            ops.use_roll(m.out_channels, *t.shape)):
+                    if (m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.dilation == (1, 1)
+                            and m.in_channels == m.out_channels and ops.use_roll(m.out_channels, *t.shape)):
                         t = ops.conv_roll(t, roll(m, "single", [(m, "lrelu")]))
                     else:
                         t = cv(m, t, act="lrelu")
@@ -284,7 +284,8 @@ class BasicBlock(nn.Module):
         """lrelu(conv2(lrelu(conv1(x))) + x): the trailing LeakyReLU of the enclosing Sequential is
         fused into the second conv's epilogue."""
         c1, c2 = self.conv1[0][0], self.conv2[0]
-        if c1.dilation[0] == 1 and ops.use_roll(c1.out_channels, *x.shape) and c1.in_channels == c1.out_channels:
+        same3 = all(c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1) and c.dilation == (1, 1) for c in (c1, c2))
+        if same3 and ops.use_roll(c1.out_channels, *x.shape) and c1.in_channels == c1.out_channels:
             # both convolutions + residual + LeakyReLU in one rolling-window launch (intermediate in LDS)
             return ops.conv_roll(x, roll(self, "block", [(c1, "lrelu"), (c2, "lrelu")], residual=True))
         t = cv(c1, x, act="lrelu")
@@ -475,7 +476,7 @@ class HITNetMF(ops.RuntimeState, nn.Module):
         L, R = (lambda i: feas[i][:B]), (lambda i: feas[i][B:])
         rt = self.__dict__.get("_pipe")
         if rt is None or rt[0].device != dev:
-            rt = self.__dict__["_pipe"] = (ops.new_stream(dev), torch.cuda.Event(), torch.cuda.Event())
+            rt = self.__dict__["_pipe"] = (torch.cuda.Stream(device=dev), torch.cuda.Event(), torch.cuda.Event())
         side, ev3, ev2 = rt
         cur = torch.cuda.current_stream(dev)
         side.wait_stream(cur)
