@@ -33,6 +33,9 @@ def needs_build():
 
 def build(force=False, verbose=True):
     if not force and not needs_build():
+        if verbose:  # (the driver's "does it build" check: say which of the two happened)
+            print(f"codd_amd.build: REUSED {os.path.relpath(LIB, ROOT)} -- up to date against {len(sources())} .hip sources and "
+                  f"{len(headers())} headers (nothing compiled; build(force=True) or `python -m codd_amd.build --force` recompiles)", flush=True)
         return LIB
     from concurrent.futures import ThreadPoolExecutor
     objs, jobs = [], []
@@ -64,6 +67,9 @@ def build(force=False, verbose=True):
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     os.replace(tmp, LIB)
+    if verbose:
+        print(f"codd_amd.build: COMPILED {len(jobs)} of {len(objs)} translation units with {HIPCC} --offload-arch=gfx950 and linked "
+              f"{os.path.relpath(LIB, ROOT)} ({os.path.getsize(LIB)} bytes)", flush=True)
     return LIB
 
 
