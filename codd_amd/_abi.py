@@ -152,7 +152,8 @@ class CoddHipError(RuntimeError):
 
 
 def lib_path():
-    return _build.LIB
+    # CODD_LIB_AB (dev, same-lease A/B of two builds of the library): load this prebuilt libcodd_hip.so instead of the in-tree one
+    return os.environ.get("CODD_LIB_AB") or _build.LIB
 
 
 def load():
@@ -164,7 +165,7 @@ def load():
     # One process at a time decides / rebuilds (torchrun starts every rank at once on a fresh checkout); a rebuild
     # that is needed but fails is an error -- a stale library is never loaded silently against newer sources.  The
     # lock file is only opened when a build is needed, so a current library loads from a read-only install.
-    if not os.path.exists(path) or _build.needs_build():
+    if path == _build.LIB and (not os.path.exists(path) or _build.needs_build()):
         import fcntl
         try:
             lock = open(os.path.join(os.path.dirname(path), ".build.lock"), "w")

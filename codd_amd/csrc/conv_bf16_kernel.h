@@ -58,7 +58,15 @@ struct ConvB {
   int gpf;                        // gate epilogues: 1 = prefetch the channel-quad operands per pixel unit (A/B: CODD_GATE_PREFETCH)
   int xcd;                        // 1: XCD-contiguous work-item walk (workgroup b, placed on XCD b % 8, takes a
                                   // contiguous range of tiles of one channel group: conv_kernel.h conv_xcd_item)
+  // magic multipliers ceil(2^32 / d) of the producers' prologue divisions (convb_div; exact for the < 2^16 operands of
+  // the slot / entry arithmetic): a 32-bit udiv is ~35 VALU instructions, and 20 of them stood between the start of a
+  // producer wave and its first LDS-DMA -- ~1.2 us of every launch's exposed ring fill (round 5)
+  unsigned m_iplane16, m_os16, m_twi, m_noct, m_kw;
 };
+static inline unsigned convb_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); }
+// n / d for 0 <= n < 2^16, 1 <= d < 2^16 with M = convb_magic(d): floor(n M / 2^32) = floor(n / d) (the error term
+// n (M d - 2^32) / (d 2^32) < 2^-16 never reaches the next integer: frac(n / d) <= 1 - 1/d)
+__device__ __forceinline__ int convb_div(int n, unsigned M, int d) { return d == 1 ? n : (int)__umulhi((unsigned)n, M); }
 
 constexpr int CONVB_NWP = 4;  // producer waves per workgroup
 constexpr int CONVB_MAXP = 6; // input DMA pieces per producer wave whose source offsets are kept in registers
@@ -125,6 +133,9 @@ static inline int convb_geometry(const codd_conv_params* pp, ConvB& k, size_t& l
   // DMA pieces a producer wave issues per chunk; nring - 1 chunks are in flight and vmcnt counts to 63
   if ((k.nring - 1) * (cdiv(k.wslots >> 6, CONVB_NWP) + cdiv(k.ibuf16 >> 6, CONVB_NWP)) > 56) return CODD_EUNSUPPORTED;
   k.xplane = p.xs_c8 * p.xs_hp * p.xs_wp;
+  if (k.nring * (k.wslots + k.ibuf16) + 64 >= 65536 || (k.nk + 2) * 4 >= 65536) return CODD_EUNSUPPORTED;  // (convb_div's operand range; LDS bounds it far below)
+  k.m_iplane16 = convb_magic(k.iplane16); k.m_os16 = convb_magic(k.os16); k.m_twi = convb_magic(k.twi);
+  k.m_noct = convb_magic(k.noct); k.m_kw = convb_magic(p.kw);
   // the split input must hold every halo tile (codd_split_bf16_dims gives a sufficient size)
   if (need_xs && (!p.xs || p.xs_o8 < 0 || p.xs_c8 < p.xs_o8 + k.nchunks * k.noct || p.xs_bt < p.pad_t ||
                   p.xs_bl < p.pad_l || p.xs_hp < p.xs_bt + p.Hin || p.xs_wp < p.xs_bl + p.Win ||
@@ -264,50 +275,44 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
   if (wave >= NWC) {
     // =============================== producers ===============================
     const int pt = tid - NWC * 64;
-    for (int e = pt; e < (k.nk + 2) * 4; e += NTP) {  // spare rows: the consumers fetch one (k-split: two) k-steps ahead
-      const int tap = e / k.noct, oct = e - tap * k.noct;
-      int off = 0;
-      if (e < k.nk * 4 && tap < k.ntaps) {
-        const int ky = tap / p.kw, kx = tap - ky * p.kw;
-        if (p.dil2 > 0 && ky < k.khe)  // the small-dilation tap set, centred inside the halo of the large one
-          off = oct * k.os16 + ((k.khe >> 1) * (p.dil_y - p.dil2) + ky * p.dil2) * k.twi +
-                (p.kw >> 1) * (p.dil_x - p.dil2) + kx * p.dil2;
-        else
-          off = oct * k.os16 + (ky - (p.dil2 > 0 ? k.khe : 0)) * p.dil_y * k.twi + kx * p.dil_x;
-      }
-      etab[e] = off;
-    }
     const int pw = wave - NWC;                      // producer wave index
     const int nwv = k.wslots >> 6, niv = k.ibuf16 >> 6;  // 1 KiB pieces of a weight / an input image
     const int nd = (nwv - pw + CONVB_NWP - 1) / CONVB_NWP + (niv - pw + CONVB_NWP - 1) / CONVB_NWP;  // pieces per chunk, this wave
     const unsigned wl_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint4*)wl;
     const unsigned il_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) uint4*)il;
-    // first record of this tile in an octet plane of the split input (its border makes every halo tile in-bounds)
-    const int oct_rec = p.xs_hp * p.xs_wp;  // records per octet plane
-    const uint4* xs0 = (const uint4*)p.xs + (size_t)b * NPL * k.xplane + (size_t)p.xs_o8 * oct_rec +
-                       (size_t)(ty * k.th * p.sy + p.xs_bt - p.pad_t) * p.xs_wp + tx * k.tw * p.sx + p.xs_bl - p.pad_l;
-    // per-lane record offset of this wave's input pieces (chunk-independent; the first CONVB_MAXP pieces live in
-    // registers, configurations with more fall back to recomputing the two divisions per piece)
-    auto piece_off = [&](int i_) -> int {
-      const int s_ = i_ * 64 + lane;
-      const int pl_ = s_ / k.iplane16, r_ = s_ - pl_ * k.iplane16;
-      const int oc_ = r_ / k.os16;
-      int px_ = r_ - oc_ * k.os16;
-      px_ = px_ < k.npix ? px_ : 0;  // slots in the octet padding re-read pixel 0 (never consumed)
-      const int y_ = px_ / k.twi, x_ = px_ - y_ * k.twi;
-      return pl_ * k.xplane + oc_ * oct_rec + y_ * p.xs_wp + x_;
-    };
-    int ioff[CONVB_MAXP];
-#pragma unroll
-    for (int q_ = 0; q_ < CONVB_MAXP; ++q_) ioff[q_] = piece_off(pw + q_ * CONVB_NWP);
     // Chunk CH -> ring slot BUF: weights are a linear copy; an input piece is 64 consecutive LDS slots
     // s = (plane, octet, pixel) gathered from per-lane record addresses
-#define BF_DMA(CH, BUF)                                                                                   \
+#define BF_DMA_W(CH, BUF)                                                                                 \
   {                                                                                                       \
     const uint4* wsrc_ = (const uint4*)p.wpacked + ((size_t)(cog * k.nchunks + (CH))) * k.wslots + lane;  \
     const unsigned wdst_ = wl_lds + (unsigned)(BUF) * (unsigned)k.wslots * 16u;                           \
     for (int i_ = pw; i_ < nwv; i_ += CONVB_NWP)                                                          \
       convb_dma16(wsrc_ + i_ * 64, __builtin_amdgcn_readfirstlane(wdst_ + (unsigned)i_ * 1024u));         \
+  }
+#ifndef CONVB_NO_PRODUCER
+    // the weights of chunk 0 need no per-lane address arithmetic: their DMA is in flight before anything else happens
+    BF_DMA_W(0, 0);
+#endif
+    // first record of this tile in an octet plane of the split input (its border makes every halo tile in-bounds)
+    const int oct_rec = p.xs_hp * p.xs_wp;  // records per octet plane
+    const uint4* xs0 = (const uint4*)p.xs + (size_t)b * NPL * k.xplane + (size_t)p.xs_o8 * oct_rec +
+                       (size_t)(ty * k.th * p.sy + p.xs_bt - p.pad_t) * p.xs_wp + tx * k.tw * p.sx + p.xs_bl - p.pad_l;
+    // per-lane record offset of this wave's input pieces (chunk-independent; the first CONVB_MAXP pieces live in
+    // registers, configurations with more fall back to recomputing the divisions per piece)
+    auto piece_off = [&](int i_) -> int {
+      const int s_ = i_ * 64 + lane;
+      const int pl_ = convb_div(s_, k.m_iplane16, k.iplane16), r_ = s_ - pl_ * k.iplane16;
+      const int oc_ = convb_div(r_, k.m_os16, k.os16);
+      int px_ = r_ - oc_ * k.os16;
+      px_ = px_ < k.npix ? px_ : 0;  // slots in the octet padding re-read pixel 0 (never consumed)
+      const int y_ = convb_div(px_, k.m_twi, k.twi), x_ = px_ - y_ * k.twi;
+      return pl_ * k.xplane + oc_ * oct_rec + y_ * p.xs_wp + x_;
+    };
+    int ioff[CONVB_MAXP];
+#pragma unroll
+    for (int q_ = 0; q_ < CONVB_MAXP; ++q_) ioff[q_] = piece_off(pw + q_ * CONVB_NWP);
+#define BF_DMA_I(CH, BUF)                                                                                 \
+  {                                                                                                       \
     const uint4* xsrc_ = xs0 + (size_t)(CH) * k.noct * oct_rec;                                           \
     const unsigned idst_ = il_lds + (unsigned)(BUF) * (unsigned)k.ibuf16 * 16u;                           \
     _Pragma("unroll") for (int q_ = 0; q_ < CONVB_MAXP; ++q_) {                                           \
@@ -317,14 +322,31 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
     for (int i_ = pw + CONVB_MAXP * CONVB_NWP; i_ < niv; i_ += CONVB_NWP)                                 \
       convb_dma16(xsrc_ + piece_off(i_), __builtin_amdgcn_readfirstlane(idst_ + (unsigned)i_ * 1024u));   \
   }
+#define BF_DMA(CH, BUF) { BF_DMA_W(CH, BUF) BF_DMA_I(CH, BUF) }
     // Phase c (the consumers compute chunk c from ring slot c % nring): issue the DMA of chunk c + nring - 1 into the
     // slot last read in phase c-1, then wait until the DMA of chunk c+1 has landed -- vmcnt counts in order, so "at
     // most the younger chunks' pieces outstanding" -- and meet the consumers at the barrier.  With a ring of three
     // every global access has two full phases to complete (round trip measured here ~1.7 us, a phase ~1.4 us).
 #ifndef CONVB_NO_PRODUCER
     const int ahead = k.nring - 1;
-    BF_DMA(0, 0);
+    BF_DMA_I(0, 0);
     if (ahead > 1 && k.nchunks > 1) BF_DMA(1, 1);
+#endif
+    // entry table (slot offset of every (tap, octet) entry inside an input plane), built while the ring fills
+    for (int e = pt; e < (k.nk + 2) * 4; e += NTP) {  // spare rows: the consumers fetch one (k-split: two) k-steps ahead
+      const int tap = convb_div(e, k.m_noct, k.noct), oct = e - tap * k.noct;
+      int off = 0;
+      if (e < k.nk * 4 && tap < k.ntaps) {
+        const int ky = convb_div(tap, k.m_kw, p.kw), kx = tap - ky * p.kw;
+        if (p.dil2 > 0 && ky < k.khe)  // the small-dilation tap set, centred inside the halo of the large one
+          off = oct * k.os16 + ((k.khe >> 1) * (p.dil_y - p.dil2) + ky * p.dil2) * k.twi +
+                (p.kw >> 1) * (p.dil_x - p.dil2) + kx * p.dil2;
+        else
+          off = oct * k.os16 + (ky - (p.dil2 > 0 ? k.khe : 0)) * p.dil_y * k.twi + kx * p.dil_x;
+      }
+      etab[e] = off;
+    }
+#ifndef CONVB_NO_PRODUCER
     convb_wait_vmcnt(ahead > 1 && k.nchunks > 1 ? nd : 0);  // chunk 0 landed (chunk 1 may still fly)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // entry table
     __builtin_amdgcn_s_barrier();
@@ -340,6 +362,8 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
     }
 #endif
 #undef BF_DMA
+#undef BF_DMA_W
+#undef BF_DMA_I
     return;
   }
 

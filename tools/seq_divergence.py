@@ -18,11 +18,14 @@ from codd_amd.runtime import FrameRunner
 DEV = "cuda:0"
 N = int(os.environ.get("N", "16"))
 name = os.environ.get("CASE", "cfg3_codd_960x576")
-PREFIX = {"cfg3_codd_960x576": "cfg3_long", "cfg5_tartanair_640x512": "cfg5_long"}[name]
+# LONG=<case of T.LONG_CASES> (e.g. cfg3_50: the second synthetic video + its own golden file) overrides CASE
+PREFIX = os.environ.get("LONG") or {"cfg3_codd_960x576": "cfg3_long", "cfg5_tartanair_640x512": "cfg5_long"}[name]
+_case = T.LONG_CASES[PREFIX]
+name = _case[0]
 H, W, intr, img_shape, _, _ = T.CASES[name]
-z = np.load(T.LONG_GOLDEN)
-sub = int(z["sub"])
-img, r_img, _ = synth.stereo_sequence(H, W, N)
+z, sub = T._long_golden(PREFIX)
+N = min(N, sum(1 for k_ in z.files if k_.startswith(PREFIX + "_f")))
+img, r_img, _ = synth.stereo_sequence(H, W, N, **({"flow": _case[3]} if len(_case) > 3 else {}))
 metas = synth.default_metas(H, W, img_shape=img_shape, intrinsics=intr)
 
 
@@ -41,8 +44,9 @@ def run(tag, roll=True, precision="split", noise=0.0, graph=True, exact=()):
         elif what == "update": r3.update_block.run = _fp32(r3.update_block.run)
         elif what == "fusion": est.fusion.memory_query = _fp32(est.fusion.memory_query)
         elif what == "motion": est.motion.forward = _fp32(est.motion.forward)
-    prev_roll, prev_p = ops.USE_ROLL, ops.set_conv_precision(precision)
+    prev_roll, prev_p, prev_ap = ops.USE_ROLL, ops.set_conv_precision(precision), ops.ALLPAIRS_SPLIT
     ops.USE_ROLL = roll
+    ops.ALLPAIRS_SPLIT = prev_ap and "allpairs" not in exact
     ops.enable_autotune(True, shipped=True)
     out = []
     try:
@@ -57,6 +61,7 @@ def run(tag, roll=True, precision="split", noise=0.0, graph=True, exact=()):
     finally:
         ops.enable_autotune(False)
         ops.USE_ROLL = prev_roll
+        ops.ALLPAIRS_SPLIT = prev_ap
         ops.set_conv_precision(prev_p)
     return out
 
@@ -75,7 +80,8 @@ def line(tag, xs, ys):
 ALL = dict(default=dict(), no_roll=dict(roll=False), fp32_convs=dict(precision="fp32"),
            input_noise_1e_7=dict(noise=1e-7), eager=dict(graph=False), fnet_exact=dict(exact=("fnet",)),
            update_exact=dict(exact=("update",)), fusion_exact=dict(exact=("fusion",)), motion_exact=dict(exact=("motion",)),
-           fnet_fusion_exact=dict(exact=("fnet", "fusion")))
+           fnet_fusion_exact=dict(exact=("fnet", "fusion")), allpairs_exact=dict(exact=("allpairs",)),
+           fnet_allpairs_exact=dict(exact=("fnet", "allpairs")))
 want = [a for a in sys.argv[1:] if a in ALL] or ["default", "no_roll", "fp32_convs", "input_noise_1e_7", "eager"]
 if "default" not in want:
     want = ["default"] + want
