@@ -132,14 +132,47 @@ def shard_loader(videos, rank=None, world_size=None):
     return [videos[i] for i in metrics.shard_videos(len(videos), rank, world_size)]
 
 
-def load_checkpoint(model, filename, map_location="cpu", strict=False, log=print):
+def _apply_key_map(sd, key_map):
+    """``key_map``: a callable ``name -> new name | None`` (None drops the tensor), or a sequence of
+    ``(regex, replacement)`` pairs applied in order with ``re.sub`` (mmcv's ``revise_keys`` convention,
+    mmcv/runner/checkpoint.py ``load_checkpoint(revise_keys=[(r'^module\\.', '')])``).  Two checkpoint names landing
+    on one key is an error, not a silent overwrite."""
+    import re
+    if key_map is None:
+        return sd
+    out = {}
+    for k, v in sd.items():
+        if callable(key_map):
+            nk = key_map(k)
+        else:
+            nk = k
+            for pat, rep in key_map:
+                nk = re.sub(pat, rep, nk)
+        if nk is None:
+            continue
+        if nk in out:
+            raise RuntimeError("key_map sends two checkpoint tensors to %r (second: %r)" % (nk, k))
+        out[nk] = v
+    return out
+
+
+def load_checkpoint(model, filename, map_location="cpu", strict=False, log=print, key_map=None):
     """Load a published CODD ``.pth`` by key name (reference inference.py:123 -> mmcv load_checkpoint).
     Tolerates the ``state_dict`` wrapper, a ``module.`` prefix and keys that only exist for training
     (``stereo.loss.*``); BatchNorm statistics of the HRNet are folded when the packed convolutions are
-    built (codd_amd/hrnet.py), so they load like any other tensor."""
+    built (codd_amd/hrnet.py), so they load like any other tensor.
+
+    ``key_map`` renames checkpoint keys before they are matched (see ``_apply_key_map``).  It exists for ONE known
+    risk: the HRNet context network's parameter names (``motion.raft3d.cnet.0.*``) follow mmseg 0.x's ``HRNet``
+    module tree as read from its call site (reference configs/models/codd.py:44-74) -- mmseg is not vendored in the
+    reference, so those 600-odd names were never compared with a real checkpoint (tests/golden/state_dict_keys.json
+    pins everything else against the imported reference).  If a published ``.pth`` reports them under
+    ``missing`` / ``unexpected``, pass the remap instead of editing the module tree, e.g.
+    ``key_map=[(r"^motion\\.raft3d\\.cnet\\.0\\.stage(\\d)\\.", r"motion.raft3d.cnet.0.stage\\1.")]``."""
     ckpt = torch.load(filename, map_location=map_location)
     sd = ckpt.get("state_dict", ckpt) if isinstance(ckpt, dict) else ckpt
     sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+    sd = _apply_key_map(sd, key_map)
     own = model.state_dict()
     train_only = [k for k in sd if ".loss." in k or k.endswith("num_batches_tracked") and k not in own]
     for k in train_only:

@@ -65,3 +65,32 @@ def test_strict_load_rejects_a_renamed_key(tmp_path):
     torch.save(dict(state_dict=sd), path)
     with pytest.raises(RuntimeError):
         apis.load_checkpoint(est, path, strict=True, log=lambda *_: None)
+
+
+def test_key_map_remaps_foreign_hrnet_names(tmp_path):
+    """The HRNet names are unpinned (mmseg is not vendored): a checkpoint that spells them differently loads through
+    ``key_map`` -- (regex, replacement) pairs or a callable --, a collision is an error, None drops a tensor."""
+    from codd_amd import apis
+    est = _build()
+    g = torch.Generator().manual_seed(11)
+    own = est.state_dict()
+    want = {k: torch.randn(v.shape, generator=g).to(v.dtype) if v.is_floating_point() else v.clone() for k, v in own.items()}
+    pre = "motion.raft3d.cnet.0."
+    foreign = {(("backbone." + k[len(pre):]) if k.startswith(pre) else k): v for k, v in want.items()}
+    foreign["aux_head.conv_seg.weight"] = torch.zeros(3)
+    path = str(tmp_path / "foreign.pth")
+    torch.save(dict(state_dict=foreign), path)
+    with pytest.raises(RuntimeError):  # without the map: 864 missing + 865 unexpected
+        apis.load_checkpoint(est, path, strict=True, log=lambda *_: None)
+    res = apis.load_checkpoint(est, path, strict=True, log=lambda *_: None,
+                               key_map=lambda k: None if k.startswith("aux_head.") else (pre + k[9:] if k.startswith("backbone.") else k))
+    assert res["missing"] == [] and res["unexpected"] == []
+    now = est.state_dict()
+    assert all(torch.equal(now[k], want[k]) for k in now)
+    # the (regex, replacement) form
+    foreign.pop("aux_head.conv_seg.weight")
+    torch.save(dict(state_dict=foreign), path)
+    res = apis.load_checkpoint(_build(), path, strict=True, log=lambda *_: None, key_map=[(r"^backbone\.", pre)])
+    assert res["missing"] == [] and res["unexpected"] == []
+    with pytest.raises(RuntimeError, match="two checkpoint tensors"):
+        apis.load_checkpoint(_build(), path, log=lambda *_: None, key_map=lambda k: "x")
