@@ -103,7 +103,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=32)
-    ap.add_argument("--precision", default="split", choices=["split", "fp32", "bf16", "bf16mix"],
+    ap.add_argument("--precision", default="split", choices=["split", "fp32", "bf16", "bf16mix", "fp16", "fp16mix"],
                     help="arithmetic of the convolution family (codd_amd.ops.set_conv_precision): split = split-bf16 "
                          "operands / fp32 accumulate for RAFT3D and exact fp32 for HITNet / context network / Fusion (default, parity-"
                          "tested at 1e-3 px); fp32 = exact-fp32 kernels everywhere; bf16 = bf16 operands / fp32 "
@@ -300,8 +300,8 @@ def conv_roofline(runner, frames, device):
     flops = sum(r[2] for r in recs)
     fam = {}  # kernel family -> [launches, ms, algorithmic flop, issued MFMA flop]
     for s, e, f, _, terms in recs:
-        c = fam.setdefault("split_bf16" if terms == 3 else "bf16" if terms == 1 else "fp32", [0, 0.0, 0.0, 0.0])
-        c[0] += 1; c[1] += s.elapsed_time(e); c[2] += f; c[3] += f * max(terms, 1)
+        c = fam.setdefault("split_bf16" if terms == 3 else "bf16" if terms == 1 else "fp16" if terms == 16 else "fp32", [0, 0.0, 0.0, 0.0])
+        c[0] += 1; c[1] += s.elapsed_time(e); c[2] += f; c[3] += f * (3 if terms == 3 else 1)
     if os.environ.get("CODD_BENCH_VERBOSE"):  # per-shape table (dev aid): count, total ms, TFLOP/s
         by = {}
         for s, e, f, key, terms in recs:
@@ -604,7 +604,7 @@ def main():
             if world == 1 and args.pmc_traffic and not args.serial_streams:
                 # measured by THIS run: two child passes of this script under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE
                 # need separate passes on gfx950), 4 eager serial-stream frames each, ~20 s per pass, hard timeouts
-                pat = {"split_bf16": "conv_bf16_kernel", "bf16": "conv_bf16_kernel", "fp32": "conv_"}[dom]
+                pat = {"split_bf16": "conv_bf16_kernel", "bf16": "conv_bf16_kernel", "fp16": "conv_bf16_kernel", "fp32": "conv_"}[dom]
                 traffic, tsrc = pmc_traffic(args, pat)
                 log(f"pmc traffic passes done: {traffic}")
             for tname in ([] if traffic is not None else sorted((f for f in os.listdir(pdir) if f.endswith("_conv_traffic.json")), reverse=True)):
@@ -614,6 +614,7 @@ def main():
                     break
             kern = {"split_bf16": "conv_bf16_kernel<*, TERMS=3> (split-bf16: 3 bf16 MFMAs per product, fp32 accumulate)",
                     "bf16": "conv_bf16_kernel<*, TERMS=1> (bf16 operands, fp32 accumulate)",
+                    "fp16": "conv_bf16_kernel<*, TERMS=16> (IEEE fp16 operands on v_mfma_f32_16x16x32_f16, fp32 accumulate)",
                     "fp32": "conv_mfma_kernel<*> + conv_quad_kernel<*> (exact fp32 MFMA)"}[dom]
             roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
                         issued_tflops=round(issued, 2), issued_frac=round(issued / peak, 4),
@@ -719,7 +720,10 @@ def main():
             "dtype": {"split": "f32 (split-bf16 MFMA operands, f32 accumulate; HITNet + context network + Fusion exact f32)", "fp32": "f32",
                       "bf16": "bf16 (MFMA operands; f32 accumulate, f32 everywhere outside the convolutions)",
                       "bf16mix": "bf16 MFMA operands / f32 accumulate for RAFT3D's encoder + update block; HITNet + context "
-                                 "network + Fusion exact f32"}[args.precision],
+                                 "network + Fusion exact f32",
+                      "fp16": "f16 (MFMA operands; f32 accumulate, f32 everywhere outside the convolutions)",
+                      "fp16mix": "f16 MFMA operands / f32 accumulate for RAFT3D's encoder + update block (the reference's auto_fp16 "
+                                 "precision); HITNet + context network + Fusion exact f32"}[args.precision],
             "data": "synthetic",
             "config": {"workload": ("HITNetMF stereo-only" if args.stereo_only else
                                     "full CODD (HITNetMF + Motion/RAFT3D iters=%d + Fusion)" % args.iters) +

@@ -33,6 +33,11 @@ __device__ __forceinline__ float act_apply(float v, int act, int co) {
 // 8 consecutive channels of one pixel -> the split-bf16 record(s) of a codd_xs_view (same rounding as
 // split_bf16_kernel: hi = RNE(v), lo = RNE(v - hi))
 typedef __bf16 codd_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 codd_f16x8 __attribute__((ext_vector_type(8)));
+// one fp32 value -> the 16-bit element of a record plane: bf16 (terms 1 | 3) or IEEE fp16 (terms 16), both RNE
+__device__ __forceinline__ unsigned short xs_elem16(float v, bool f16) {
+  return f16 ? __builtin_bit_cast(unsigned short, (_Float16)v) : __builtin_bit_cast(unsigned short, (__bf16)v);
+}
 __device__ __forceinline__ void xs_store8(const codd_xs_view& d, int b, int oct, int y, int x, const float* v) {
   const size_t per = (size_t)d.c8 * d.hp * d.wp;
   const int planes = d.terms == 3 ? 2 : 1;
@@ -44,11 +49,18 @@ __device__ __forceinline__ void xs_store8(const codd_xs_view& d, int b, int oct,
     l[i] = (__bf16)(v[i] - (float)hh);
   }
   uint4* dst = (uint4*)d.ptr + (size_t)b * planes * per + ((size_t)(d.o8 + oct) * d.hp + (y + d.bt)) * d.wp + (x + d.bl);
+  if (d.terms == CODD_TERMS_F16) {
+    codd_f16x8 q;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = (_Float16)v[i];
+    dst[0] = __builtin_bit_cast(uint4, q);
+    return;
+  }
   dst[0] = __builtin_bit_cast(uint4, h);
   if (planes == 2) dst[per] = __builtin_bit_cast(uint4, l);
 }
 static inline bool xs_view_ok(const codd_xs_view& d, int C, int H, int W) {
-  return d.ptr && !((uintptr_t)d.ptr & 15) && (d.terms == 1 || d.terms == 3) && d.o8 >= 0 && 8 * (d.c8 - d.o8) >= C &&
+  return d.ptr && !((uintptr_t)d.ptr & 15) && (d.terms == 1 || d.terms == 3 || d.terms == CODD_TERMS_F16) && d.o8 >= 0 && 8 * (d.c8 - d.o8) >= C &&
          d.bt >= 0 && d.bl >= 0 && d.hp >= d.bt + H && d.wp >= d.bl + W;
 }
 

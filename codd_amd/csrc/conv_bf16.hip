@@ -10,7 +10,7 @@ static inline int nk_of(int ntaps, int ck) { return cdiv((long long)ntaps * (ck 
 // packed image: [cog][chunk][plane (hi, lo)][k-step][g][co (16*mb)][8 bf16]; entry e = kstep*4 + g = tap*noct + oct
 __global__ void conv_pack_bf16_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp, int Cout, int Cin,
                                       int ntaps, int mb, int ck, int nk, int nchunks, int planes, long long total,
-                                      long long co_stride, long long ci_stride, float scale) {
+                                      long long co_stride, long long ci_stride, float scale, int f16) {
   long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= total) return;
   const int nco = 16 * mb, noct = ck >> 3;
@@ -25,13 +25,17 @@ __global__ void conv_pack_bf16_kernel(const float* __restrict__ w, unsigned shor
   const int co = cog * nco + col, ci = chunk * ck + oct * 8 + c8;
   float v = 0.f;
   if (tap < ntaps && co < Cout && ci < Cin) v = w[(size_t)co * co_stride + (size_t)ci * ci_stride + tap] * scale;
+  if (f16) {  // CODD_TERMS_F16: one plane of IEEE fp16
+    wp[e] = __builtin_bit_cast(unsigned short, (_Float16)v);
+    return;
+  }
   const __bf16 hi = (__bf16)v;
   const __bf16 r = plane == 0 ? hi : (__bf16)(v - (float)hi);
   wp[e] = __builtin_bit_cast(unsigned short, r);
 }
 
 extern "C" long long codd_conv2d_packed_bytes_bf16(int Cout, int Cin, int kh, int kw, int mb, int ck, int terms) {
-  if (mb < 1 || ck < 8 || (ck & 7) || !(terms == 1 || terms == 3)) return -1;
+  if (mb < 1 || ck < 8 || (ck & 7) || !(terms == 1 || terms == 3 || terms == CODD_TERMS_F16)) return -1;
   const long long ncog = cdiv(Cout, 16 * mb), nchunks = cdiv(Cin, ck);
   return ncog * nchunks * (terms == 3 ? 2 : 1) * (long long)nk_of(kh * kw, ck) * 4 * 16 * mb * 16;
 }
@@ -44,7 +48,7 @@ extern "C" int codd_conv2d_pack_weights_bf16(const float* w, void* wpacked, int 
   const long long total = bytes / 2;
   conv_pack_bf16_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(
       w, (unsigned short*)wpacked, Cout, Cin, kh * kw, mb, ck, nk_of(kh * kw, ck), cdiv(Cin, ck), terms == 3 ? 2 : 1,
-      total, co_stride, ci_stride, scale);
+      total, co_stride, ci_stride, scale, terms == CODD_TERMS_F16);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }
@@ -75,10 +79,12 @@ int codd_conv2d_bf16(const codd_conv_params* pp, void* stream, int dry_run) {
 #define X(PGW, CGW, A, B, KS)                                                                    \
   if (p.pgw == PGW && p.cgw == CGW && a == A && bb == B && ks == KS)                             \
     return dry_run ? CODD_OK                                                                     \
-           : (p.xso || p.gate) ? (p.terms == 3 ? launch_b<PGW, CGW, A, B, 3, 1, KS>(k, lds, (int)grid, s)    \
-                                   : launch_b<PGW, CGW, A, B, 1, 1, KS>(k, lds, (int)grid, s))   \
-                   : (p.terms == 3 ? launch_b<PGW, CGW, A, B, 3, 0, KS>(k, lds, (int)grid, s)    \
-                                   : launch_b<PGW, CGW, A, B, 1, 0, KS>(k, lds, (int)grid, s));
+           : (p.xso || p.gate) ? (p.terms == 3   ? launch_b<PGW, CGW, A, B, 3, 1, KS>(k, lds, (int)grid, s)   \
+                                  : p.terms == 16 ? launch_b<PGW, CGW, A, B, 16, 1, KS>(k, lds, (int)grid, s)  \
+                                                  : launch_b<PGW, CGW, A, B, 1, 1, KS>(k, lds, (int)grid, s))  \
+                               : (p.terms == 3   ? launch_b<PGW, CGW, A, B, 3, 0, KS>(k, lds, (int)grid, s)   \
+                                  : p.terms == 16 ? launch_b<PGW, CGW, A, B, 16, 0, KS>(k, lds, (int)grid, s)  \
+                                                  : launch_b<PGW, CGW, A, B, 1, 0, KS>(k, lds, (int)grid, s));
   CONVB_ALL(X)
 #undef X
   return CODD_EUNSUPPORTED;
@@ -90,7 +96,7 @@ int codd_conv2d_bf16(const codd_conv_params* pp, void* stream, int dry_run) {
 //   in the channels past C0 + C1.  One thread = one record position: 8 coalesced dword loads, 1-2 16-byte stores.
 // ------------------------------------------------------------------------------------------------------------
 __global__ void split_bf16_kernel(codd_view in0, codd_view in1, int C0, int C1, int B, int H, int W, int bt, int bl,
-                                  int c8, int hp, int wp, int planes, uint4* __restrict__ xs) {
+                                  int c8, int hp, int wp, int planes, uint4* __restrict__ xs, int f16) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long per = (long long)c8 * hp * wp;
   if (e >= (long long)B * per) return;
@@ -120,12 +126,19 @@ __global__ void split_bf16_kernel(codd_view in0, codd_view in1, int C0, int C1, 
     l[i] = (__bf16)(v[i] - (float)hh);
   }
   uint4* dst = xs + (size_t)b * planes * per + ((size_t)oct * hp + yp) * wp + xp;
+  if (f16) {  // CODD_TERMS_F16: one plane of IEEE fp16 records
+    f16x8 q;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = (_Float16)v[i];
+    dst[0] = __builtin_bit_cast(uint4, q);
+    return;
+  }
   dst[0] = __builtin_bit_cast(uint4, h);
   if (planes == 2) dst[per] = __builtin_bit_cast(uint4, l);
 }
 
 extern "C" long long codd_split_bf16_bytes(int B, int c8, int hp, int wp, int terms) {
-  if (B < 1 || c8 < 1 || hp < 1 || wp < 1 || !(terms == 1 || terms == 3)) return -1;
+  if (B < 1 || c8 < 1 || hp < 1 || wp < 1 || !(terms == 1 || terms == 3 || terms == CODD_TERMS_F16)) return -1;
   return (long long)B * (terms == 3 ? 2 : 1) * c8 * hp * wp * 16;
 }
 
@@ -136,7 +149,7 @@ extern "C" int codd_split_bf16(codd_view in0, int C0, codd_view in1, int C1, int
     return CODD_EINVAL;
   const long long total = (long long)B * c8 * hp * wp;
   split_bf16_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(in0, in1, C0, C1, B, H, W, bt, bl, c8, hp, wp,
-                                                                       terms == 3 ? 2 : 1, (uint4*)xs);
+                                                                       terms == 3 ? 2 : 1, (uint4*)xs, terms == CODD_TERMS_F16);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }

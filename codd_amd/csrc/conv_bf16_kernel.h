@@ -8,7 +8,9 @@
 // in the fp32 accumulator; the dropped terms (a_lo*b_lo and the two split residuals) are <= 3 * 2^-18 |a b|
 // (measured on MI355X: max error 1e-6 of sum |w||x| against 3e-7 for the exact-fp32 kernels; TF32, the reference's
 // own CUDA conv arithmetic under torch >= 1.12 defaults, keeps 10 mantissa bits).  TERMS = 1 is the plain
-// bf16-operand / fp32-accumulate path of BASELINE.json configs[4].
+// bf16-operand / fp32-accumulate path of BASELINE.json configs[4]; TERMS = 16 (CODD_TERMS_F16, round 5) the same
+// kernel on ONE plane of IEEE-fp16 records and v_mfma_f32_16x16x32_f16 -- the reference's own reduced precision
+// (auto_fp16, model/codd.py:37,128): 11 mantissa bits at the bf16 rate.
 //
 // GEMM view (same roles as conv_kernel.h):  D[co, pixel] = sum_k W[co, k] X[k, pixel],  k = (tap, ci).
 //   A operand (16 x 32) = weights : lane (j = l&15, g = l>>4) holds W[co = j][entry g][8 channels]
@@ -37,6 +39,7 @@
 #include "conv_kernel.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct ConvB {
   codd_conv_params p;
@@ -89,7 +92,7 @@ constexpr int CONVB_MAXP = 6; // input DMA pieces per producer wave whose source
 static inline int convb_geometry(const codd_conv_params* pp, ConvB& k, size_t& lds, long long& grid, bool need_xs) {
   k.p = *pp;
   const codd_conv_params& p = k.p;
-  if (p.ck < 8 || (p.ck & 7) || !(p.terms == 1 || p.terms == 3) || p.nw < 1 || p.npb < 1 || p.npb > 2 ||
+  if (p.ck < 8 || (p.ck & 7) || !(p.terms == 1 || p.terms == 3 || p.terms == CODD_TERMS_F16) || p.nw < 1 || p.npb < 1 || p.npb > 2 ||
       p.pgw < 1 || p.cgw < 1 || p.mb < 1 || p.mb % p.cgw)
     return CODD_EINVAL;
   const int planes = p.terms == 3 ? 2 : 1;
@@ -155,13 +158,13 @@ static inline int convb_geometry(const codd_conv_params* pp, ConvB& k, size_t& l
     if (p.gate == 1 && (p.xso || p.res1.ptr || p.res2.ptr || p.post.ptr)) return CODD_EUNSUPPORTED;
     if (p.gate == 2 && (!p.xso || !c4ok(p.res1, 3 * G) || !c4ok(p.res2, 2 * G) || !c4ok(p.post, G))) return CODD_EINVAL;
     if (p.gate == 3 && (!p.xso || !c4ok(p.res1, 2 * G) || !c4ok(p.post, G) || p.res2.ptr)) return CODD_EINVAL;
-    if (p.xso && (!(p.xso_terms == 1 || p.xso_terms == 3) || p.xso_o8 < 0 || p.xso_bt < 0 || p.xso_bl < 0 ||
+    if (p.xso && (!(p.xso_terms == 1 || p.xso_terms == 3 || p.xso_terms == CODD_TERMS_F16) || p.xso_o8 < 0 || p.xso_bt < 0 || p.xso_bl < 0 ||
                   p.xso_c8 < p.xso_o8 + cdiv(G, 8) || p.xso_hp < p.xso_bt + p.Hout || p.xso_wp < p.xso_bl + p.Wout))
       return CODD_EINVAL;
   } else if (need_xs && p.xso) {  // split-record output: plain conv only; the tensor must hold the image inside its borders
     if (p.store_mode || p.res1.ptr || p.res2.ptr || p.post.ptr || p.act == CODD_ACT_RELU_CH0) return CODD_EUNSUPPORTED;
     if (p.bias && ((uintptr_t)p.bias & 15)) return CODD_EINVAL;
-    if (!(p.xso_terms == 1 || p.xso_terms == 3) || p.xso_o8 < 0 || p.xso_bt < 0 || p.xso_bl < 0 ||
+    if (!(p.xso_terms == 1 || p.xso_terms == 3 || p.xso_terms == CODD_TERMS_F16) || p.xso_o8 < 0 || p.xso_bt < 0 || p.xso_bl < 0 ||
         p.xso_c8 < p.xso_o8 + cdiv(k.cout_eff, 8) || p.xso_hp < p.xso_bt + p.Hout || p.xso_wp < p.xso_bl + p.Wout)
       return CODD_EINVAL;
   }
@@ -245,7 +248,8 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
   constexpr int NWT = PGW * CGW;          // accumulator-tile sets (one per consumer wave, or per k-split pair)
   constexpr int NWC = NWT * KS;           // consumer waves
   constexpr int NTP = CONVB_NWP * 64;     // producer threads
-  constexpr int NPL = TERMS == 1 ? 1 : 2; // precision planes
+  constexpr int NPL = TERMS == 3 ? 2 : 1; // precision planes (3: hi | lo bf16; 1: bf16; 16: fp16)
+  constexpr bool F16 = TERMS == CODD_TERMS_F16;
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   uint4* wl = smem4;                             // ring of nring weight buffers (the DMA runs nring - 1 chunks ahead)
   uint4* il = smem4 + k.nring * k.wslots;        // ring of nring input buffers
@@ -409,26 +413,30 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
       if (TERMS == 3) F.bl[a_] = __builtin_bit_cast(bf16x8, ib[k.iplane16 + eo_ + pbase[a_]]);            \
     }                                                                                                     \
   }
+  // one MFMA on two 16-byte fragments: bf16 or (TERMS = 16) fp16 operands, fp32 accumulate
+  auto mma = [](bf16x8 x, bf16x8 y, f32x4 c) -> f32x4 {
+    if constexpr (F16)
+      return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
+    else
+      return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
+  };
   // term-major order: consecutive MFMAs go to different accumulators (small terms first)
 #define BF_MFMA(F)                                                                                        \
   {                                                                                                       \
     if (TERMS == 3) {                                                                                     \
       _Pragma("unroll") for (int a = 0; a < A; ++a) _Pragma("unroll") for (int m = 0; m < B; ++m)         \
-        acc[a][m] = OUTF ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.al[m], F.bh[a], acc[a][m], 0, 0, 0)  \
-                         : __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bh[a], F.al[m], acc[a][m], 0, 0, 0); \
+        acc[a][m] = OUTF ? mma(F.al[m], F.bh[a], acc[a][m]) : mma(F.bh[a], F.al[m], acc[a][m]);           \
       _Pragma("unroll") for (int a = 0; a < A; ++a) _Pragma("unroll") for (int m = 0; m < B; ++m)         \
-        acc[a][m] = OUTF ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.ah[m], F.bl[a], acc[a][m], 0, 0, 0)  \
-                         : __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bl[a], F.ah[m], acc[a][m], 0, 0, 0); \
+        acc[a][m] = OUTF ? mma(F.ah[m], F.bl[a], acc[a][m]) : mma(F.bl[a], F.ah[m], acc[a][m]);           \
     }                                                                                                     \
     _Pragma("unroll") for (int a = 0; a < A; ++a) _Pragma("unroll") for (int m = 0; m < B; ++m)           \
-      acc[a][m] = OUTF ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.ah[m], F.bh[a], acc[a][m], 0, 0, 0)    \
-                       : __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.bh[a], F.ah[m], acc[a][m], 0, 0, 0);   \
+      acc[a][m] = OUTF ? mma(F.ah[m], F.bh[a], acc[a][m]) : mma(F.bh[a], F.ah[m], acc[a][m]);             \
   }
 
   __syncthreads();  // chunk 0 and the entry table are in LDS
 #ifndef CONVB_NO_CONSUMER
   const int klast = k.nk - 1;
-  constexpr int NRD = 1 + NPL * (A + B), NMF = TERMS * A * B;  // LDS reads / MFMAs per k-step
+  constexpr int NRD = 1 + NPL * (A + B), NMF = (TERMS == 3 ? 3 : 1) * A * B;  // LDS reads / MFMAs per k-step
   int wsel = 0;
   for (int ch = 0; ch < k.nchunks; ++ch) {
     const uint4* wb = wl + wsel * k.wslots;  // ring slot ch % nring
@@ -612,6 +620,12 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
         unsigned hi2[2], lo2[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
+          if (p.xso_terms == CODD_TERMS_F16) {  // (wave-uniform) one plane of fp16 records
+            const _Float16 h0 = (_Float16)v[2 * q], h1 = (_Float16)v[2 * q + 1];
+            hi2[q] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            lo2[q] = 0u;
+            continue;
+          }
           const __bf16 h0 = (__bf16)v[2 * q], h1 = (__bf16)v[2 * q + 1];
           const __bf16 l0 = (__bf16)(v[2 * q] - (float)h0), l1 = (__bf16)(v[2 * q + 1] - (float)h1);
           hi2[q] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
@@ -721,9 +735,13 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
   extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, 0, KS>(const ConvB);      \
   extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 0, KS>(const ConvB);      \
   extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, 1, KS>(const ConvB);      \
-  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 1, KS>(const ConvB);
+  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 1, KS>(const ConvB);      \
+  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 16, 0, KS>(const ConvB);     \
+  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 16, 1, KS>(const ConvB);
 #define CONVB_DEFINE(PGW, CGW, A, B, KS)                                                         \
   template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, 0, KS>(const ConvB);             \
   template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 0, KS>(const ConvB);             \
   template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, 1, KS>(const ConvB);             \
-  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 1, KS>(const ConvB);
+  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 1, KS>(const ConvB);             \
+  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 16, 0, KS>(const ConvB);            \
+  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 16, 1, KS>(const ConvB);

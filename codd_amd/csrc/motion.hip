@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
       const float v = tile[c - c0][pi];
       const __bf16 hi = (__bf16)v;
       const size_t at = (((size_t)(d.o8 + (c >> 3)) * d.hp + (y + d.bt)) * d.wp + (x + d.bl)) * 8 + (c & 7);
-      base[at] = __builtin_bit_cast(unsigned short, hi);
+      base[at] = xs_elem16(v, d.terms == CODD_TERMS_F16);
       if (d.terms == 3) base[per * 8 + at] = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)hi));
     }
     return;
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(128) void gn_heads_prep_kernel(const codd_xs_view h
   const int j = ok ? n : N - 1;
   const int yj = j / w, xj = j - yj * w;
   const size_t per = (size_t)hs.c8 * hs.hp * hs.wp, ostride = (size_t)hs.hp * hs.wp;
-  const bool three = hs.terms == 3;
+  const bool three = hs.terms == 3, f16 = hs.terms == CODD_TERMS_F16;  // (f16: head_w holds fp16 A operands too)
   const uint4* src = (const uint4*)hs.ptr + (size_t)b * (three ? 2 : 1) * per +
                      ((size_t)(hs.o8 + g) * hs.hp + (yj + hs.bt)) * hs.wp + (xj + hs.bl);
   const uint4* wl = Wp + lane;
@@ -585,7 +585,11 @@ __global__ __launch_bounds__(128) void gn_heads_prep_kernel(const codd_xs_view h
       acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[T], 0, 0, 0);                        \
       acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[T], 0, 0, 0);                        \
     }                                                                                                   \
-    acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[T], 0, 0, 0);                          \
+    if (f16)                                                                                            \
+      acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(codd_f16x8, ah),               \
+                                                      __builtin_bit_cast(codd_f16x8, bh), acc[T], 0, 0, 0); \
+    else                                                                                                \
+      acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[T], 0, 0, 0);                        \
   }
   float* rp = jd + ((size_t)b * N + j) * GN_JS;
   if (role == 1) {
@@ -1823,7 +1827,11 @@ __global__ void splat_fill_kernel(const SplatP p) {
 }
 
 __global__ void splat_gather_kernel(const SplatP p) {
-  const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+  // XCD-contiguous walk (common.h codd_xcd_item): a 256-pixel row segment's candidates are the points that landed within
+  // R of it -- the same uvz records, pose / depth and feature lines the segments of the rows above and below read.
+  // With the dispatcher's block -> XCD b % 8 placement those neighbours sit on eight different L2s (round 4: 75 MB per
+  // launch against 22 MB algorithmic); every XCD now walks one contiguous band of rows.
+  const int pix = codd_xcd_item(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
   const int b = blockIdx.y;
   const int HW = p.H * p.W;
   if (pix >= HW) return;

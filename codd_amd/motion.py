@@ -198,7 +198,7 @@ class BasicUpdateBlock(ops.RuntimeState, nn.Module):
         return t1, t2
 
     def _gates_fused(self, net):
-        return FUSE_GATES and MERGE_ENC_HEADS and ops.CONV_PRECISION in ("split", "bf16")
+        return FUSE_GATES and MERGE_ENC_HEADS and ops.CONV_PRECISION in ("split", "bf16", "fp16")
 
     def _h4(self, net):
         """The hidden state in the channel-quad layout (ops.C4Tensor) of the gate epilogues: written by the q-gate
@@ -380,16 +380,18 @@ class BasicUpdateBlock(ops.RuntimeState, nn.Module):
         codd_se3_gn_step_heads (include/codd_hip.h) + their 38 biases; cached on the module per parameter version."""
         mods = (self.ae[2], self.delta[2], self.weight[2])
         ver = tuple((m.weight.data_ptr(), m.weight._version, m.bias._version) for m in mods)
+        ver = ver + (ops.CONV_PRECISION == "fp16",)  # (fp16 records need fp16 A operands)
         c = self.__dict__.get("_codd_head_matrix")
         if c is None or c[0] != ver:
             Wm = torch.cat([m.weight.detach().reshape(m.weight.shape[0], 256) for m in mods], 0).float()
             bm = torch.cat([m.bias.detach() for m in mods], 0).float().contiguous()
-            c = self.__dict__["_codd_head_matrix"] = (ver, pack_head_matrix(Wm), bm)
+            c = self.__dict__["_codd_head_matrix"] = (ver, pack_head_matrix(Wm, f16=ver[-1]), bm)
         return c[1], c[2]
 
 
-def pack_head_matrix(Wm):
-    """[38, 256] fp32 (ae rows 0..31, delta 32..34, weight 35..37) -> [32, 2, 64, 8] bf16 A-operand blocks."""
+def pack_head_matrix(Wm, f16=False):
+    """[38, 256] fp32 (ae rows 0..31, delta 32..34, weight 35..37) -> [32, 2, 64, 8] bf16 A-operand blocks (hi | lo
+    planes); ``f16``: the hi plane holds IEEE fp16 instead (hidden records of terms = 16; the lo plane is unused)."""
     dev = Wm.device
     full = torch.zeros(48, 768, device=dev)  # rows: 32 ae | delta 3 | weight 3 | 10 zero; columns: hidden channel
     full[:32, :256] = Wm[:32]
@@ -407,6 +409,9 @@ def pack_head_matrix(Wm):
         cols = (256 + 32 * s_ + 8 * kg)[:, None] + k8[None]
         blocks.append(full[(32 + row)[:, None], cols])
     v = torch.stack(blocks, 0)  # [32, 64, 8] fp32
+    if f16:
+        hi = v.half()
+        return torch.stack([hi, torch.zeros_like(hi)], 1).contiguous().view(torch.bfloat16)  # (16-bit payload; dtype is a label)
     hi = v.bfloat16()
     lo = (v - hi.float()).bfloat16()
     return torch.stack([hi, lo], 1).contiguous()  # [32, 2, 64, 8]

@@ -202,24 +202,29 @@ def _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl):
 #                      tests at the benchmarked configurations bound its effect on the disparities)
 #   "fp32"             exact-fp32 MFMA kernels (v_mfma_f32_16x16x4_f32)
 #   "bf16"             bf16 operands, fp32 accumulate (BASELINE.json configs[4]; reference auto_fp16 hook)
+#   "fp16"             IEEE fp16 operands (v_mfma_f32_16x16x32_f16), fp32 accumulate: the reference's own reduced
+#                      precision (auto_fp16 IS .half(), model/codd.py:37,128): 11 mantissa bits at bf16's MFMA rate
 CONV_PRECISION = _os.environ.get("CODD_CONV_PRECISION", "split")
 ALLPAIRS_SPLIT = _os.environ.get("CODD_ALLPAIRS_SPLIT", "1") == "1"  # (A/B switch of allpairs_corr)
-_TERMS = dict(split=3, bf16=1)
+_TERMS = dict(split=3, bf16=1, fp16=16)  # codd_conv_params.terms (CODD_TERMS_*)
 
 
-# "bf16" with BF16_STAGE_POLICY on ("bf16mix" in bench.py / set_conv_precision): the stages of _STAGE_PRECISION keep
-# their exact-fp32 kernels (HITNet, whose output IS the disparity, the context network, Fusion) and only RAFT3D's
-# feature encoder and its 16 update iterations -- 85 % of the frame's convolution FLOPs -- run on plain bf16 operands.
+# "bf16" / "fp16" with BF16_STAGE_POLICY on ("bf16mix" / "fp16mix" in bench.py / set_conv_precision): the stages of
+# _STAGE_PRECISION keep their exact-fp32 kernels (HITNet, whose output IS the disparity, the context network, Fusion) and
+# only RAFT3D's feature encoder and its 16 update iterations -- 85 % of the frame's convolution FLOPs -- run on plain
+# bf16 / fp16 operands.
 BF16_STAGE_POLICY = False
+_HALF_MODES = ("bf16", "fp16")  # one 16-bit operand plane, one MFMA per product
+_MODES = ("split", "fp32", "bf16", "bf16mix", "fp16", "fp16mix")
 
 
 def set_conv_precision(mode):
-    """-> the previous mode (pass it back to restore).  "bf16mix" = "bf16" + the stage policy."""
+    """-> the previous mode (pass it back to restore).  "bf16mix" / "fp16mix" = "bf16" / "fp16" + the stage policy."""
     global CONV_PRECISION, BF16_STAGE_POLICY
-    if mode not in ("split", "fp32", "bf16", "bf16mix"):
-        raise ValueError("conv precision must be 'split', 'fp32', 'bf16' or 'bf16mix'")
-    prev = "bf16mix" if CONV_PRECISION == "bf16" and BF16_STAGE_POLICY else CONV_PRECISION
-    CONV_PRECISION, BF16_STAGE_POLICY = ("bf16", True) if mode == "bf16mix" else (mode, False)
+    if mode not in _MODES:
+        raise ValueError("conv precision must be one of %s" % (_MODES,))
+    prev = CONV_PRECISION + "mix" if CONV_PRECISION in _HALF_MODES and BF16_STAGE_POLICY else CONV_PRECISION
+    CONV_PRECISION, BF16_STAGE_POLICY = (mode[:-3], True) if mode.endswith("mix") else (mode, False)
     return prev
 
 
@@ -247,7 +252,7 @@ class stage:
 
     def __enter__(self):
         self.prev = None
-        if self.name in _STAGE_PRECISION and (CONV_PRECISION == "split" or (CONV_PRECISION == "bf16" and BF16_STAGE_POLICY)):
+        if self.name in _STAGE_PRECISION and (CONV_PRECISION == "split" or (CONV_PRECISION in _HALF_MODES and BF16_STAGE_POLICY)):
             to = _STAGE_PRECISION[self.name]
             if to != "split" or CONV_PRECISION == "split":  # (a "split" stage under bf16mix stays bf16)
                 self.prev = set_conv_precision(to)

@@ -85,6 +85,34 @@ def _texture(x, y, ch):
     return out
 
 
+def _plane_wave_table(n=48, seed=12345):
+    """n plane waves (amp, kx, ky, phase, channel phase step) from a fixed LCG: wave vectors of random direction with
+    |k| log-uniform in [0.03, 1.3] rad/px, amplitude ~ |k|^-0.5.  Unlike _TEX (six x/y-separable sinusoids, nearly
+    periodic along x at the coarse tile scales) the sum has no short self-similarity along the disparity axis, so the
+    tile cost volume's minima are well separated (tools/video_margin_scan.py)."""
+    st, rows = seed, []
+
+    def u():
+        nonlocal st
+        st = (1103515245 * st + 12345) % (1 << 31)
+        return st / float(1 << 31)
+    for _ in range(n):
+        k = 0.03 * math.exp(u() * math.log(1.3 / 0.03))
+        th = 2 * math.pi * u()
+        rows.append((0.5 * (0.03 / k) ** 0.5 * 3.0, k * math.cos(th), k * math.sin(th), 2 * math.pi * u(), 0.3 + 1.7 * u()))
+    return rows
+
+
+_WAVES = _plane_wave_table()
+
+
+def _texture_waves(x, y, ch):
+    out = torch.zeros_like(x)
+    for a, kx, ky, ph, cs in _WAVES:
+        out = out + a * torch.sin(kx * x + ky * y + ph + cs * ch)
+    return out
+
+
 def disparity_field(H, W, t=0.0, dmin=1.0, dmax=48.0):
     """Smooth positive disparity field [H, W] (px) at time ``t``."""
     y, x = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32),
@@ -93,15 +121,19 @@ def disparity_field(H, W, t=0.0, dmin=1.0, dmax=48.0):
     return dmin + (dmax - dmin) * s.clamp(0, 1)
 
 
-def stereo_sequence(H, W, MF, dmax=48.0, flow=(0.75, 0.25)):
+def stereo_sequence(H, W, MF, dmax=48.0, flow=(0.75, 0.25), texture="sines", dphase=1.0):
     """Synthetic stereo video: returns (img, r_img) float32 [1, MF, 3, H, W] and gt disparity
     [1, MF, 1, H, W].  Left frame t samples the texture at (x - t*fx, y - t*fy); the right
-    image samples the same texture at (x + d(x, y)) so that right(x - d) ~ left(x)."""
+    image samples the same texture at (x + d(x, y)) so that right(x - d) ~ left(x).
+    ``texture``: "sines" (the six separable sinusoids every golden up to round 4 was made with) or "waves" (48 plane
+    waves of random direction: no near-periodicity along the disparity axis)."""
+    assert texture in ("sines", "waves"), texture
+    _texture = {"sines": globals()["_texture"], "waves": _texture_waves}[texture]
     y, x = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32),
                           indexing="ij")
     ls, rs, ds = [], [], []
     for t in range(MF):
-        d = disparity_field(H, W, float(t), dmax=dmax)
+        d = disparity_field(H, W, float(t) * dphase, dmax=dmax)  # (dphase: speed of the disparity field's drift, 0.1 rad/frame * dphase)
         xs, ys = x - t * flow[0], y - t * flow[1]
         left = torch.stack([_texture(xs, ys, c) for c in range(3)])
         right = torch.stack([_texture(xs + d, ys, c) for c in range(3)])

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CODD_ABI_VERSION 9
+#define CODD_ABI_VERSION 10
 
 #define CODD_OK 0
 #define CODD_EINVAL (-1)
@@ -45,6 +45,17 @@ typedef struct {
  * (y, x) at (y + bt, x + bl), planes = 2 for terms 3 / 1 for terms 1) as the DESTINATION of a producer kernel: the
  * producer writes the image interior of channels [8*o8, ...) only; border and padding channels stay as they are
  * (zero in a persistent buffer). */
+/* `terms` of a record tensor / a layout-2 convolution: the operand format of the MFMA convolution family.
+ *   CODD_TERMS_BF16  (1)   one plane of bf16 records, v_mfma_f32_16x16x32_bf16
+ *   CODD_TERMS_SPLIT (3)   two planes (hi | lo) of bf16 records, three MFMAs per product: the fp32-grade default
+ *   CODD_TERMS_F16   (16)  one plane of IEEE fp16 records, v_mfma_f32_16x16x32_f16 (ABI v10): 11 mantissa bits instead of
+ *                          bf16's 8 at the same MFMA rate -- the reference's own reduced-precision hook is fp16
+ *                          (auto_fp16, model/codd.py:37,128, enabled by inference.py:120-122).  Range: |x| > 65504
+ *                          saturates to +-inf as in the reference's .half() path; the host policy uses it only for
+ *                          RAFT3D's feature encoder and update block (O(1) activations). */
+#define CODD_TERMS_BF16 1
+#define CODD_TERMS_SPLIT 3
+#define CODD_TERMS_F16 16
 typedef struct codd_xs_view {
   void* ptr;
   int c8, hp, wp, bt, bl, o8, terms;
@@ -95,7 +106,7 @@ typedef struct {
                  weights in LDS and walk the tiles, prefetching the next tile's input); 2: split-bf16 kernel (weights packed by
                  codd_conv2d_pack_weights_bf16 for (mb, ck, terms); here nw = tile rows, npb = 16-pixel units per
                  tile row (1 | 2), ck a multiple of 8) */
-  int terms;  /* layout 2: 1 = bf16 operands, 3 = split-bf16 (hi/lo) operands */
+  int terms;  /* layout 2: 1 = bf16 operands, 3 = split-bf16 (hi/lo) operands, 16 = fp16 operands (CODD_TERMS_*) */
   int pgw, cgw; /* layout 2: wave grid of a workgroup (pixel-unit groups x channel-block groups), mb % cgw == 0 */
   /* layout 2: the input (channel concatenation of C0 + C1 channels; in0 / in1 are not read) re-laid-out by
    * codd_split_bf16 with borders (pad_t, pad_l): [B][plane][xs_c8 octets][xs_hp][xs_wp][8] bf16 */
@@ -154,7 +165,7 @@ int codd_conv2d_pack_weights_quad(const float* w, float* wpacked, int Cout, int 
  * C0 + C1 are zero, so that every halo tile of the convolution is in-bounds row segments of 16-byte records (the
  * kernel's LDS-DMA copies them verbatim).  A conv needs bt >= pad_t, bl >= pad_l, 8 * (c8 - xs_o8) >= ceil(Cin / ck) * ck
  * and hp >= max(bt + H, bt - pad_t + (tiles_y * th - 1) * sy + (kh - 1) * dil_y + 1), wp likewise (th x 16*npb = its tile).
- * terms = 1: hi plane only. */
+ * terms = 1: hi plane only; terms = 16: one plane of fp16 records. */
 long long codd_split_bf16_bytes(int B, int c8, int hp, int wp, int terms);
 int codd_split_bf16(codd_view in0, int C0, codd_view in1, int C1, int B, int H, int W, int bt, int bl,
                     int c8, int hp, int wp, int terms, void* xs, void* stream);

@@ -49,6 +49,38 @@ LONG_CASES = {
 # the test uses to tell an ill-conditioned frame from a product defect
 VARIANT = os.environ.get("CODD_GOLDEN_VARIANT", "")
 FINE_FRAMES = 3
+# Stereo-stage conditioning, recorded per frame beside the frames of the 50-frame case ("<case>_stereo_sens_f<t>" =
+# [mean |delta|, fraction > 0.25 px] over all pixels, the larger of SENS_K seeds): how far the ORACLE's own stereo output
+# (a per-frame function of the two images: tile cost-volume arg-mins of an untrained network) moves when the images
+# carry SENS_NOISE relative noise -- ~10x the differences between two fp32 evaluation orders.  Costs two extra stereo
+# evaluations (~2 x 4 s) per frame.  tools/video_margin_scan.py: 7-10 % of the frames of EVERY synthetic video tried
+# (four flows, two textures) have such a near-tie, so the test reads this record instead of hoping for a clean video.
+SENS_NOISE, SENS_K = 1e-6, 2
+
+
+def stereo_sensitivity(sd, left, right, base, f):
+    from oracle import stereo as ostereo
+    worst = np.zeros(2, np.float32)
+    for k in range(SENS_K):
+        g = torch.Generator().manual_seed(100 * f + k)
+        l = left * (1 + SENS_NOISE * torch.randn(left.shape, generator=g))
+        r = right * (1 + SENS_NOISE * torch.randn(right.shape, generator=g))
+        d = (ostereo.stereo_matching(sd, l, r, 320)["pred_disp"] - base).abs()
+        worst = np.maximum(worst, np.array([d.mean().item(), (d > 0.25).float().mean().item()], np.float32))
+    return worst
+
+
+def merge(dst, src):
+    """python make_long_golden.py --merge DST.npz SRC.npz: copy SRC's "<case>@<variant>_*" frames into DST."""
+    a, b = np.load(dst), np.load(src)
+    arrays = {k: a[k] for k in a.files}
+    n = 0
+    for k in b.files:
+        if "@" in k:
+            arrays[k] = b[k]
+            n += 1
+    np.savez_compressed(dst, **arrays)
+    print(f"merged {n} variant arrays of {src} into {dst} ({os.path.getsize(dst)} bytes)")
 
 
 def main():
@@ -82,6 +114,9 @@ def main():
                 arrays[f"{key}_f{f}"] = a
                 if len(case) > 3 and f < FINE_FRAMES:  # the first frames of the 50-frame case also on the finer sub-grid [::2, ::2]
                     arrays[f"{key}_sub2_f{f}"] = o["pred_disp"][0, 0, ::2, ::2].contiguous().numpy().astype(np.float32)
+                if len(case) > 3 and not VARIANT:
+                    arrays[f"{key}_stereo_sens_f{f}"] = stereo_sensitivity(sd, img[:, f], r_img[:, f], o["pred_curr"] if "pred_curr" in o else o["pred_disp"], f)
+                    print(key, f, "stereo-stage movement under %g input noise: mean %.2e px, flipped %.2e" % (SENS_NOISE, *arrays[f"{key}_stereo_sens_f{f}"]), flush=True)
                 print(key, f, a.shape, float(a.mean()), f"{time.time() - t0:.0f} s", flush=True)
                 # checkpoint after every frame: the run takes an hour
                 np.savez_compressed(OUT, **{**arrays, "sub": np.array(SUB), "src_hash": np.array(T._src_hash())})
@@ -94,4 +129,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) == 4 and sys.argv[1] == "--merge":
+        merge(sys.argv[2], sys.argv[3])
+    else:
+        main()

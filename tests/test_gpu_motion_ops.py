@@ -698,10 +698,20 @@ def test_gru_gates_writing_split_records_equal_gate_plus_relayout():
     assert torch.equal(ops.split_input(h_ref, border=4).buf, hb.buf)
 
 
-def test_gn_step_with_fused_heads_equals_heads_then_step():
-    """codd_se3_gn_step_heads (1x1 heads inside the record packing, hidden channels read in split-bf16 form) against
-    fp32 1x1 convolutions (torch) followed by codd_se3_gn_step."""
+@pytest.mark.parametrize("mode,wtol,ttol", [("split", 1e-4, 2e-3), ("fp16", 4e-3, 6e-2)])
+def test_gn_step_with_fused_heads_equals_heads_then_step(mode, wtol, ttol):
+    """codd_se3_gn_step_heads (1x1 heads inside the record packing, hidden channels read in split-bf16 form -- or, mode
+    "fp16", as one plane of IEEE fp16 records with fp16 head weights on v_mfma_f32_16x16x32_f16) against fp32 1x1
+    convolutions (torch) followed by codd_se3_gn_step."""
     from codd_amd import ops
+    prev = ops.set_conv_precision(mode)
+    try:
+        _gn_step_with_fused_heads(ops, mode, wtol, ttol)
+    finally:
+        ops.set_conv_precision(prev)
+
+
+def _gn_step_with_fused_heads(ops, mode, wtol, ttol):
     B, h, w = 1, 20, 44
     T = _se3_field(B, h, w, 0.03).to(DEV)
     g = torch.Generator().manual_seed(11)
@@ -721,16 +731,27 @@ def test_gn_step_with_fused_heads_equals_heads_then_step():
     ops.se3_gn_step(T_ref, ae.contiguous(), xyz, delta.contiguous(), weight.contiguous(), d1, K8, radius=6)
     T_new = T.clone()
     from codd_amd.motion import pack_head_matrix
-    w_out = ops.se3_gn_step_heads(T_new, hs, pack_head_matrix(Wm), bm, xyz, d1, K8, radius=6)
+    assert hs.terms == ops._TERMS[mode]
+    w_out = ops.se3_gn_step_heads(T_new, hs, pack_head_matrix(Wm, f16=mode == "fp16"), bm, xyz, d1, K8, radius=6)
     step = (T_ref - T).abs().max().item()
     err = (T_new - T_ref).abs().max().item()
-    print("gn step", step, "fused-heads deviation", err, "weight dev", (w_out - weight).abs().max().item())
-    assert (w_out - weight).abs().max().item() < 1e-4
-    assert err < 2e-3 * step
+    print(mode, "gn step", step, "fused-heads deviation", err, "weight dev", (w_out - weight).abs().max().item())
+    assert (w_out - weight).abs().max().item() < wtol
+    assert err < ttol * step
 
 
-def test_geometry_lookup_writing_split_records_equals_lookup_plus_relayout():
+@pytest.mark.parametrize("mode", ["split", "fp16"])
+def test_geometry_lookup_writing_split_records_equals_lookup_plus_relayout(mode):
+    """(mode "fp16": the same writers emit one plane of IEEE fp16 records, CODD_TERMS_F16)"""
     from codd_amd import ops
+    prev = ops.set_conv_precision(mode)
+    try:
+        _geometry_lookup_records(ops)
+    finally:
+        ops.set_conv_precision(prev)
+
+
+def _geometry_lookup_records(ops):
     h, w = 24, 40
     T = ops.se3_identity(1, h, w, DEV)
     T[..., :3] = rnd(1, h, w, 3, seed=3).to(DEV) * 0.05

@@ -46,8 +46,8 @@ def _act(v, act):
 
 
 # precision mode of the conv family -> tolerance relative to the output scale (fp32: fma chains vs MKL-DNN;
-# split: three-term split-bf16 products, ~2^-17 per product; bf16: 2^-9 per operand)
-PRECISIONS = [("fp32", 2e-4), ("split", 2e-4), ("bf16", 3e-2)]
+# split: three-term split-bf16 products, ~2^-17 per product; bf16: 2^-9 per operand; fp16: 2^-12 per operand)
+PRECISIONS = [("fp32", 2e-4), ("split", 2e-4), ("bf16", 3e-2), ("fp16", 4e-3)]
 
 
 @pytest.fixture(params=PRECISIONS, ids=[p[0] for p in PRECISIONS])
@@ -74,7 +74,8 @@ def test_conv2d(case, precision):
 def test_split_bf16_conv_every_launch_configuration():
     """Every (tile, chunk depth, wave grid) the library accepts for a layer gives the same result to the split-bf16
     bound: |err| <= 3 * 2^-18 * sum |w||x| per output (dropped lo*lo term + the two split residuals), checked against
-    an fp64 reference; and terms = 1 (plain bf16 operands) to 2^-8 * sum |w||x|."""
+    an fp64 reference; terms = 1 (plain bf16 operands) to 2^-8 * sum |w||x|; terms = 16 (IEEE fp16 operands on
+    v_mfma_f32_16x16x32_f16, round 5) to 2^-11 * sum |w||x| (two operands rounded to 11 significant bits each)."""
     from codd_amd import _abi, ops
     lib = _abi.load()
     for (cin, cout, k, s, p, d, H, W) in [(40, 64, 3, 1, 1, 1, 27, 40), (16, 16, 3, 1, 1, 1, 48, 64),
@@ -84,8 +85,8 @@ def test_split_bf16_conv_every_launch_configuration():
         mag = F.conv2d(x.abs().double(), w.abs().double(), None, s, p, d)
         Ho, Wo = ref.shape[2:]
         pc = ops.PackedConv(w.to(dev()), b.to(dev()))
-        for terms, bound in ((3, 3.5 * 2.0 ** -18), (1, 2.0 ** -8)):
-            prev = ops.set_conv_precision("split" if terms == 3 else "bf16")
+        for terms, bound in ((3, 3.5 * 2.0 ** -18), (1, 2.0 ** -8), (16, 2.0 ** -11)):
+            prev = ops.set_conv_precision({3: "split", 1: "bf16", 16: "fp16"}[terms])
             try:
                 n = 0
                 for c in ops._bf16_candidates(pc, Ho, Wo, 1, k * k, terms):
@@ -407,7 +408,7 @@ def test_tunable_configurations_with_views_and_two_inputs():
         ops.set_conv_precision(prev)
 
 
-@pytest.mark.parametrize("mode,tol", [("split", 2e-4), ("bf16", 4e-2)])
+@pytest.mark.parametrize("mode,tol", [("split", 2e-4), ("bf16", 4e-2), ("fp16", 5e-3)])
 def test_conv_chain_through_split_records(mode, tol):
     """conv -> conv with the intermediate written by the first kernel's epilogue as split-bf16 records straight into
     the second one's input tensor (ops.split_buffer / xs_out): no fp32 tensor, no re-layout pass.  Output channels that
@@ -435,7 +436,7 @@ def test_conv_chain_through_split_records(mode, tol):
             assert (y1.cpu() - r1).abs().max().item() < tol * r1.abs().max().item(), frame
             assert (y2.cpu() - r2).abs().max().item() < tol * max(1.0, r2.abs().max().item()), frame
         # the record-writing epilogue of the eight-consumer-wave configurations (k-split pairs finish half of the tiles each)
-        terms = 3 if mode == "split" else 1
+        terms = ops._TERMS[mode]
         k0 = (H, W, B, 1, 1, 1, 1, 1, False, terms, "split")
         for cfg in [(1, 10, 8, 4, 2, 2, 2, terms, 2), (2, 8, 16, 2, 2, 4, 1, terms, 2), (1, 12, 8, 4, 2, 4, 1, terms, 2),
                     (1, 16, 8, 4, 2, 4, 2, terms, 1), (2, 6, 16, 4, 2, 4, 2, terms, 1)]:
