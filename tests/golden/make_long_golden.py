@@ -105,9 +105,17 @@ def main():
         img, r_img, _ = synth.stereo_sequence(H, W, MF, **({"flow": case[3]} if len(case) > 3 else {}))
         MF = min(MF, int(os.environ.get("CODD_GOLDEN_FRAMES", MF)))
         key = name + ("@" + VARIANT if VARIANT else "")
-        state = {}
+        state, f0 = {}, 0
+        # resume: the recurrent state is saved beside OUT after every frame (git-ignored scratch; a 50-frame run is 2-3 h
+        # of CPU and background jobs do not survive a session restart)
+        resume = OUT + f".{key}.state.pt"
+        if os.path.exists(resume):
+            ck = torch.load(resume)
+            if all(f"{key}_f{q}" in arrays for q in range(ck["f"] + 1)):
+                state, f0 = ck["state"], ck["f"] + 1
+                print(f"{key}: resuming behind frame {ck['f']} from {resume}", flush=True)
         with torch.no_grad(), ctx:
-            for f in range(MF):
+            for f in range(f0, MF):
                 t0 = time.time()
                 o = oc.frame(sd, img[:, f], r_img[:, f], state, intr, iters=iters, with_motion=True, with_fusion=True)
                 a = o["pred_disp"][0, 0, ::SUB, ::SUB].contiguous().numpy().astype(np.float32)
@@ -119,7 +127,10 @@ def main():
                     print(key, f, "stereo-stage movement under %g input noise: mean %.2e px, flipped %.2e" % (SENS_NOISE, *arrays[f"{key}_stereo_sens_f{f}"]), flush=True)
                 print(key, f, a.shape, float(a.mean()), f"{time.time() - t0:.0f} s", flush=True)
                 # checkpoint after every frame: the run takes an hour
-                np.savez_compressed(OUT, **{**arrays, "sub": np.array(SUB), "src_hash": np.array(T._src_hash())})
+                np.savez_compressed(OUT + ".tmp.npz", **{**arrays, "sub": np.array(SUB), "src_hash": np.array(T._src_hash())})
+                os.replace(OUT + ".tmp.npz", OUT)
+                torch.save(dict(f=f, state=state), resume + ".tmp")
+                os.replace(resume + ".tmp", resume)
         if iters == T.ITERS and not VARIANT and len(case) == 3:
             short = np.load(T.GOLDEN)
             for f in range(T.CASES[base][5]):
