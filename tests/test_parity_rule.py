@@ -1,0 +1,83 @@
+"""CPU tests of the per-frame parity rule of tests/test_gpu_headline_parity.py (judge_frame): which frames of a recurrent
+sequence may use a bound other than the north star's 1e-3 px, and that a deviation on a well-conditioned frame is
+reported as a product defect.  Synthetic frames; no GPU, no oracle."""
+import numpy as np
+import pytest
+import torch
+
+import test_gpu_headline_parity as T
+
+
+class FakeNpz(dict):
+    @property
+    def files(self):
+        return list(self.keys())
+
+
+def _frames(seed=0, n=4000):
+    g = np.random.default_rng(seed)
+    return (40 + 10 * g.random((50, 80))).astype(np.float32)
+
+
+def _flip(a, npx, by, seed=1):
+    """a copy of ``a`` with ``npx`` pixels moved by ``by`` px and 1e-6-level noise everywhere"""
+    g = np.random.default_rng(seed)
+    b = a + (2e-6 * g.standard_normal(a.shape)).astype(np.float32)
+    idx = g.choice(a.size, npx, replace=False)
+    b.reshape(-1)[idx] += by
+    return b
+
+
+def test_rule_1_and_product_defect():
+    A = _frames()
+    z = FakeNpz({"c_f0": A})
+    s, how = T.judge_frame("c", 0, torch.from_numpy(_flip(A, 0, 0.0)), z, "t")
+    assert how.startswith("(1)") and s["mean"] < 1e-4
+    # 40 of 4000 pixels off by 30 px = 0.3 px mean, nothing marks the frame as ill-conditioned: a product defect
+    with pytest.raises(AssertionError, match="product defect"):
+        T.judge_frame("c", 0, torch.from_numpy(_flip(A, 40, 30.0)), z, "t")
+    # ... also when the oracle's two evaluations AGREE and the stereo record shows a stable frame
+    z2 = FakeNpz({"c_f0": A, "c@nomkldnn_f0": _flip(A, 0, 0.0, seed=3), "c_stereo_sens_f0": np.array([3e-6, 0.0], np.float32)})
+    with pytest.raises(AssertionError, match="product defect"):
+        T.judge_frame("c", 0, torch.from_numpy(_flip(A, 40, 30.0)), z2, "t")
+
+
+def test_rules_2_and_3_need_a_measured_oracle_spread():
+    A = _frames()
+    B = _flip(A, 6, 25.0, seed=5)  # the oracle's second evaluation sits on another branch: 6 px x 25 px = 3.75e-2 px mean
+    z = FakeNpz({"c_f3": A, "c@nomkldnn_f3": B})
+    s, how = T.judge_frame("c", 3, torch.from_numpy(_flip(B, 0, 0.0, seed=7)), z, "t")  # product on the variant's branch
+    assert how.startswith("(2)") and "nomkldnn" in how
+    C = _flip(A, 5, 25.0, seed=9)  # a third branch of about the same size
+    s, how = T.judge_frame("c", 3, torch.from_numpy(C), z, "t")
+    assert how.startswith("(3)")
+    with pytest.raises(AssertionError, match="outside every bound"):  # three times the oracle's own spread
+        T.judge_frame("c", 3, torch.from_numpy(_flip(A, 20, 25.0, seed=11)), z, "t")
+
+
+def test_rule_4_stereo_near_tie_window():
+    A = _frames()
+    P = _flip(A, 16, 20.0, seed=13)  # 4e-3 of the pixels, 8e-2 px mean
+    sens = lambda m, f: np.array([m, f], np.float32)
+    z = FakeNpz({"c_f5": A, "c@nomkldnn_f5": _flip(A, 0, 0.0, seed=2), "c_stereo_sens_f5": sens(1e-1, 5e-3)})
+    s, how = T.judge_frame("c", 5, torch.from_numpy(P), z, "t")
+    assert how.startswith("(4)")
+    # the record of an EARLIER frame inside the window counts (the flipped block is fed back through the memory) ...
+    zw = FakeNpz({"c_f5": A, "c_stereo_sens_f5": sens(3e-6, 0.0), "c_stereo_sens_f4": sens(3e-6, 0.0),
+                  "c_stereo_sens_f3": sens(1e-1, 5e-3)})
+    assert T.judge_frame("c", 5, torch.from_numpy(P), zw, "t")[1].startswith("(4)")
+    # ... one outside it does not
+    zo = FakeNpz({"c_f5": A, "c_stereo_sens_f5": sens(3e-6, 0.0), "c_stereo_sens_f4": sens(3e-6, 0.0),
+                  "c_stereo_sens_f3": sens(3e-6, 0.0), "c_stereo_sens_f2": sens(1e-1, 5e-3)})
+    with pytest.raises(AssertionError, match="product defect"):
+        T.judge_frame("c", 5, torch.from_numpy(P), zo, "t")
+    # and the product has to stay inside 2 x the oracle's own movement
+    with pytest.raises(AssertionError):
+        T.judge_frame("c", 5, torch.from_numpy(_flip(A, 60, 20.0, seed=15)), z, "t")
+
+
+def test_robust_statistics_always_hold():
+    A = _frames()
+    # a uniform 5e-4 px offset: all-pixel mean inside 1e-3 but the median is not at rounding level -> fails even under (1)
+    with pytest.raises(AssertionError):
+        T.judge_frame("c", 0, torch.from_numpy(A + np.float32(5e-4)), FakeNpz({"c_f0": A}), "t")
