@@ -76,6 +76,18 @@ def test_rule_4_stereo_near_tie_window():
         T.judge_frame("c", 5, torch.from_numpy(_flip(A, 60, 20.0, seed=15)), z, "t")
 
 
+def test_rule_5_frame_function_record():
+    A = _frames()
+    P = _flip(A, 2, 60.0, seed=17)  # two isolated pixels by 60 px: 3e-2 px mean on a 4000-pixel grid
+    rec = lambda ms, fs: np.array([ms / 16, fs / 16, ms, fs], np.float32)
+    z = FakeNpz({"c_f9": A, "c@nomkldnn_f9": _flip(A, 0, 0.0, seed=2), "c_stereo_sens_f9": np.array([3e-6, 0.0], np.float32),
+                 "c_frame_sens_f9": rec(2e-2, 5e-4)})
+    assert T.judge_frame("c", 9, torch.from_numpy(P), z, "t")[1].startswith("(5)")
+    z["c_frame_sens_f9"] = rec(1e-5, 0.0)  # the probe found the oracle STABLE on this frame: the deviation is a defect
+    with pytest.raises(AssertionError, match="product defect"):
+        T.judge_frame("c", 9, torch.from_numpy(P), z, "t")
+
+
 def test_robust_statistics_always_hold():
     A = _frames()
     # a uniform 5e-4 px offset: all-pixel mean inside 1e-3 but the median is not at rounding level -> fails even under (1)
