@@ -88,6 +88,24 @@ def test_rule_5_frame_function_record():
         T.judge_frame("c", 9, torch.from_numpy(P), z, "t")
 
 
+def test_full_resolution_frame_settles_a_noisy_sub_grid():
+    g = np.random.default_rng(3)
+    full = (40 + 10 * g.random((200, 320))).astype(np.float32)
+    prod = full + (2e-6 * g.standard_normal(full.shape)).astype(np.float32)
+    prod[8, 12] += 100.0  # ONE pixel by 100 px: 1.6e-3 px over all 64 000 pixels ... on the sub-grid 2.5e-2 px
+    prod[9:11, 40:44] += 1.0
+    z = FakeNpz({"c_f4": full[::4, ::4].copy()})
+    with pytest.raises(AssertionError, match="product defect"):
+        T.judge_frame("c", 4, torch.from_numpy(prod[::4, ::4].copy()), z, "t", d_full=torch.from_numpy(prod))
+    prod[8, 12] -= 60.0   # 40 px: 6.3e-4 + 1.3e-4 px over all pixels -- inside the bound at full resolution
+    z["c_full_f4"] = full
+    s, how = T.judge_frame("c", 4, torch.from_numpy(prod[::4, ::4].copy()), z, "t", d_full=torch.from_numpy(prod))
+    assert how.startswith("(1-full)") and s["mean"] > 1e-3
+    prod[8:12, 12:16] += 100.0  # a 4 x 4 block by 100 px fails at full resolution too
+    with pytest.raises(AssertionError, match="product defect"):
+        T.judge_frame("c", 4, torch.from_numpy(prod[::4, ::4].copy()), z, "t", d_full=torch.from_numpy(prod))
+
+
 def test_robust_statistics_always_hold():
     A = _frames()
     # a uniform 5e-4 px offset: all-pixel mean inside 1e-3 but the median is not at rounding level -> fails even under (1)

@@ -24,6 +24,10 @@ LONG = os.environ.get("LONG", "cfg3_50")
 K = int(os.environ.get("K", "3"))
 NOISE = float(os.environ.get("NOISE", "1e-6"))
 OUT = os.environ.get("OUT", "")
+# STATE_NOISE: the same relative noise on every floating tensor of the recurrent state as well (previous fused disparity,
+# feature memory, RAFT3D's feature map / context features): two implementations reach frame F with states that differ at
+# rounding level, and Fusion's weight heads read the warped MEMORY -- an image-only probe cannot see that dependence
+STATE_NOISE = float(os.environ.get("STATE_NOISE", "0"))
 case = T.LONG_CASES[LONG]
 H, W, intr, _, _, _ = T.CASES[case[0]]
 torch.set_num_threads(int(os.environ.get("THREADS", max(1, min(os.cpu_count() or 1, 16)))))
@@ -52,8 +56,19 @@ def main():
         if f - 1 not in snap:
             print(f"frame {f}: no snapshot behind frame {f - 1} in {sdir}")
             continue
-        def run(l, r):
+        def noisy(v, gen):
+            if torch.is_tensor(v):
+                return v * (1 + STATE_NOISE * torch.randn(v.shape, generator=gen)) if v.is_floating_point() else v
+            if isinstance(v, (list, tuple)):
+                return type(v)(noisy(x, gen) for x in v)
+            if isinstance(v, dict):
+                return {k: noisy(x, gen) for k, x in v.items()}
+            return v
+
+        def run(l, r, gen=None):
             st = torch.load(snap[f - 1], map_location="cpu")["state"]
+            if gen is not None and STATE_NOISE:
+                st = noisy(st, gen)
             with torch.no_grad():
                 return oc.frame(sd, l, r, st, intr, iters=case[1])["pred_disp"][0, 0]
         t0 = time.time()
@@ -65,10 +80,10 @@ def main():
             gen = torch.Generator().manual_seed(1000 * f + k)
             l = img[:, f] * (1 + NOISE * torch.randn(img[:, f].shape, generator=gen))
             r = r_img[:, f] * (1 + NOISE * torch.randn(img[:, f].shape, generator=gen))
-            d = (run(l, r) - base).abs()
+            d = (run(l, r, gen) - base).abs()
             ds = d[::sub, ::sub]
             row = np.array([d.mean().item(), (d > 0.25).float().mean().item(), ds.mean().item(), (ds > 0.25).float().mean().item()], np.float32)
-            print(f"{LONG} frame {f} seed {k}: oracle output under {NOISE:g} input noise moves by mean {row[0]:.2e} px, flipped {row[1]:.2e} "
+            print(f"{LONG} frame {f} seed {k}: oracle output under {NOISE:g} input" + (f" + {STATE_NOISE:g} state" if STATE_NOISE else "") + f" noise moves by mean {row[0]:.2e} px, flipped {row[1]:.2e} "
                   f"(all pixels); sub-grid mean {row[2]:.2e}, flipped {row[3]:.2e}", flush=True)
             worst = np.maximum(worst, row)
         res[f] = worst
@@ -77,6 +92,7 @@ def main():
     if OUT:
         old = dict(np.load(OUT)) if os.path.exists(OUT) else {}
         old.update({f"{LONG}_frame_sens_f{f}": v for f, v in res.items()})
+        old["frame_sens_noise"] = np.array([NOISE, STATE_NOISE], np.float32)
         np.savez(OUT, **old)
 
 
