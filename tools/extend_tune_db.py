@@ -12,7 +12,7 @@ from codd_amd.runtime import FrameRunner
 ops.enable_autotune(True, shipped=True)
 before = dict(ops.TUNE_DB)
 for name, (H, W, intr, img_shape, stereo_only, MF) in T.CASES.items():
-    for prec in (("split", "bf16mix") if not stereo_only else ("split",)):
+    for prec in (("split", "bf16mix", "fp16mix") if not stereo_only else ("split",)):
         prev = ops.set_conv_precision(prec)
         try:
             est = T._build(stereo_only)[0].to("cuda:0")
