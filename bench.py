@@ -103,7 +103,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=32)
-    ap.add_argument("--precision", default="split", choices=["split", "fp32", "bf16", "bf16mix", "fp16", "fp16mix"],
+    ap.add_argument("--precision", default="split", choices=["split", "split16", "fp32", "bf16", "bf16mix", "fp16", "fp16mix"],
                     help="arithmetic of the convolution family (codd_amd.ops.set_conv_precision): split = split-bf16 "
                          "operands / fp32 accumulate for RAFT3D and exact fp32 for HITNet / context network / Fusion (default, parity-"
                          "tested at 1e-3 px); fp32 = exact-fp32 kernels everywhere; bf16 = bf16 operands / fp32 "
@@ -300,8 +300,8 @@ def conv_roofline(runner, frames, device):
     flops = sum(r[2] for r in recs)
     fam = {}  # kernel family -> [launches, ms, algorithmic flop, issued MFMA flop]
     for s, e, f, _, terms in recs:
-        c = fam.setdefault("split_bf16" if terms == 3 else "bf16" if terms == 1 else "fp16" if terms == 16 else "fp32", [0, 0.0, 0.0, 0.0])
-        c[0] += 1; c[1] += s.elapsed_time(e); c[2] += f; c[3] += f * (3 if terms == 3 else 1)
+        c = fam.setdefault("split_bf16" if terms == 3 else "split_fp16" if terms == 48 else "bf16" if terms == 1 else "fp16" if terms == 16 else "fp32", [0, 0.0, 0.0, 0.0])
+        c[0] += 1; c[1] += s.elapsed_time(e); c[2] += f; c[3] += f * (3 if terms in (3, 48) else 1)
     if os.environ.get("CODD_BENCH_VERBOSE"):  # per-shape table (dev aid): count, total ms, TFLOP/s
         by = {}
         for s, e, f, key, terms in recs:
@@ -604,7 +604,7 @@ def main():
             if world == 1 and args.pmc_traffic and not args.serial_streams:
                 # measured by THIS run: two child passes of this script under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE
                 # need separate passes on gfx950), 4 eager serial-stream frames each, ~20 s per pass, hard timeouts
-                pat = {"split_bf16": "conv_bf16_kernel", "bf16": "conv_bf16_kernel", "fp16": "conv_bf16_kernel", "fp32": "conv_"}[dom]
+                pat = {"split_bf16": "conv_bf16_kernel", "split_fp16": "conv_bf16_kernel", "bf16": "conv_bf16_kernel", "fp16": "conv_bf16_kernel", "fp32": "conv_"}[dom]
                 traffic, tsrc = pmc_traffic(args, pat)
                 log(f"pmc traffic passes done: {traffic}")
             for tname in ([] if traffic is not None else sorted((f for f in os.listdir(pdir) if f.endswith("_conv_traffic.json")), reverse=True)):
@@ -613,6 +613,7 @@ def main():
                     traffic, tsrc = round(tj["traffic_bytes_per_launch"]), f"profiles/{tname} (committed rocprofv3 --pmc passes, not this run): " + tj["correction"]
                     break
             kern = {"split_bf16": "conv_bf16_kernel<*, TERMS=3> (split-bf16: 3 bf16 MFMAs per product, fp32 accumulate)",
+                    "split_fp16": "conv_bf16_kernel<*, TERMS=48> (split-fp16: 3 fp16 MFMAs per product on 22-bit operands, fp32 accumulate)",
                     "bf16": "conv_bf16_kernel<*, TERMS=1> (bf16 operands, fp32 accumulate)",
                     "fp16": "conv_bf16_kernel<*, TERMS=16> (IEEE fp16 operands on v_mfma_f32_16x16x32_f16, fp32 accumulate)",
                     "fp32": "conv_mfma_kernel<*> + conv_quad_kernel<*> (exact fp32 MFMA)"}[dom]
@@ -637,7 +638,7 @@ def main():
         except Exception as e:  # pragma: no cover
             roof = dict(error=repr(e))
         log(f"roofline pass done: {roof}")
-        if world == 1 and args.precision == "split" and args.fp32_steps > 0 and not args.stereo_only and not pipelined:
+        if world == 1 and args.precision in ("split", "split16") and args.fp32_steps > 0 and not args.stereo_only and not pipelined:
             # secondary figure: the same frame with every convolution on the exact-fp32 MFMA kernels (own graph)
             try:
                 prev = _ops_tune.set_conv_precision("fp32")
@@ -718,6 +719,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": {"split": "f32 (split-bf16 MFMA operands, f32 accumulate; HITNet + context network + Fusion exact f32)", "fp32": "f32",
+                      "split16": "f32 (split-fp16 MFMA operands: 22-bit hi + lo, three MFMAs per product, f32 accumulate; HITNet + context network + Fusion exact f32)",
                       "bf16": "bf16 (MFMA operands; f32 accumulate, f32 everywhere outside the convolutions)",
                       "bf16mix": "bf16 MFMA operands / f32 accumulate for RAFT3D's encoder + update block; HITNet + context "
                                  "network + Fusion exact f32",

@@ -142,7 +142,7 @@ SIGNATURES = {
     "codd_fusion_blend": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 10  # CODD_ABI_VERSION of include/codd_hip.h
+ABI_VERSION = 11  # CODD_ABI_VERSION of include/codd_hip.h
 _lib = None
 MISSING = []
 

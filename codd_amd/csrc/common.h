@@ -40,7 +40,7 @@ __device__ __forceinline__ unsigned short xs_elem16(float v, bool f16) {
 }
 __device__ __forceinline__ void xs_store8(const codd_xs_view& d, int b, int oct, int y, int x, const float* v) {
   const size_t per = (size_t)d.c8 * d.hp * d.wp;
-  const int planes = d.terms == 3 ? 2 : 1;
+  const int planes = CODD_TERMS_PLANES(d.terms);
   codd_bf16x8 h, l;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -49,18 +49,22 @@ __device__ __forceinline__ void xs_store8(const codd_xs_view& d, int b, int oct,
     l[i] = (__bf16)(v[i] - (float)hh);
   }
   uint4* dst = (uint4*)d.ptr + (size_t)b * planes * per + ((size_t)(d.o8 + oct) * d.hp + (y + d.bt)) * d.wp + (x + d.bl);
-  if (d.terms == CODD_TERMS_F16) {
-    codd_f16x8 q;
+  if (CODD_TERMS_IS_F16(d.terms)) {
+    codd_f16x8 q, ql;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) q[i] = (_Float16)v[i];
+    for (int i = 0; i < 8; ++i) {
+      q[i] = (_Float16)v[i];
+      ql[i] = (_Float16)(v[i] - (float)q[i]);
+    }
     dst[0] = __builtin_bit_cast(uint4, q);
+    if (planes == 2) dst[per] = __builtin_bit_cast(uint4, ql);
     return;
   }
   dst[0] = __builtin_bit_cast(uint4, h);
   if (planes == 2) dst[per] = __builtin_bit_cast(uint4, l);
 }
 static inline bool xs_view_ok(const codd_xs_view& d, int C, int H, int W) {
-  return d.ptr && !((uintptr_t)d.ptr & 15) && (d.terms == 1 || d.terms == 3 || d.terms == CODD_TERMS_F16) && d.o8 >= 0 && 8 * (d.c8 - d.o8) >= C &&
+  return d.ptr && !((uintptr_t)d.ptr & 15) && CODD_TERMS_OK(d.terms) && d.o8 >= 0 && 8 * (d.c8 - d.o8) >= C &&
          d.bt >= 0 && d.bl >= 0 && d.hp >= d.bt + H && d.wp >= d.bl + W;
 }
 

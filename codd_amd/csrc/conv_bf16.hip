@@ -25,8 +25,9 @@ __global__ void conv_pack_bf16_kernel(const float* __restrict__ w, unsigned shor
   const int co = cog * nco + col, ci = chunk * ck + oct * 8 + c8;
   float v = 0.f;
   if (tap < ntaps && co < Cout && ci < Cin) v = w[(size_t)co * co_stride + (size_t)ci * ci_stride + tap] * scale;
-  if (f16) {  // CODD_TERMS_F16: one plane of IEEE fp16
-    wp[e] = __builtin_bit_cast(unsigned short, (_Float16)v);
+  if (f16) {  // CODD_TERMS_F16 / _SPLIT_F16: IEEE fp16 (hi | lo) plane(s)
+    const _Float16 h = (_Float16)v;
+    wp[e] = __builtin_bit_cast(unsigned short, plane == 0 ? h : (_Float16)(v - (float)h));
     return;
   }
   const __bf16 hi = (__bf16)v;
@@ -35,9 +36,9 @@ __global__ void conv_pack_bf16_kernel(const float* __restrict__ w, unsigned shor
 }
 
 extern "C" long long codd_conv2d_packed_bytes_bf16(int Cout, int Cin, int kh, int kw, int mb, int ck, int terms) {
-  if (mb < 1 || ck < 8 || (ck & 7) || !(terms == 1 || terms == 3 || terms == CODD_TERMS_F16)) return -1;
+  if (mb < 1 || ck < 8 || (ck & 7) || !CODD_TERMS_OK(terms)) return -1;
   const long long ncog = cdiv(Cout, 16 * mb), nchunks = cdiv(Cin, ck);
-  return ncog * nchunks * (terms == 3 ? 2 : 1) * (long long)nk_of(kh * kw, ck) * 4 * 16 * mb * 16;
+  return ncog * nchunks * CODD_TERMS_PLANES(terms) * (long long)nk_of(kh * kw, ck) * 4 * 16 * mb * 16;
 }
 
 extern "C" int codd_conv2d_pack_weights_bf16(const float* w, void* wpacked, int Cout, int Cin, int kh, int kw, int mb,
@@ -47,8 +48,8 @@ extern "C" int codd_conv2d_pack_weights_bf16(const float* w, void* wpacked, int 
   if (bytes <= 0 || !w || !wpacked) return CODD_EINVAL;
   const long long total = bytes / 2;
   conv_pack_bf16_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(
-      w, (unsigned short*)wpacked, Cout, Cin, kh * kw, mb, ck, nk_of(kh * kw, ck), cdiv(Cin, ck), terms == 3 ? 2 : 1,
-      total, co_stride, ci_stride, scale, terms == CODD_TERMS_F16);
+      w, (unsigned short*)wpacked, Cout, Cin, kh * kw, mb, ck, nk_of(kh * kw, ck), cdiv(Cin, ck), CODD_TERMS_PLANES(terms),
+      total, co_stride, ci_stride, scale, CODD_TERMS_IS_F16(terms));
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }
@@ -80,9 +81,11 @@ int codd_conv2d_bf16(const codd_conv_params* pp, void* stream, int dry_run) {
   if (p.pgw == PGW && p.cgw == CGW && a == A && bb == B && ks == KS)                             \
     return dry_run ? CODD_OK                                                                     \
            : (p.xso || p.gate) ? (p.terms == 3   ? launch_b<PGW, CGW, A, B, 3, 1, KS>(k, lds, (int)grid, s)   \
+                                  : p.terms == 48 ? launch_b<PGW, CGW, A, B, 48, 1, KS>(k, lds, (int)grid, s)  \
                                   : p.terms == 16 ? launch_b<PGW, CGW, A, B, 16, 1, KS>(k, lds, (int)grid, s)  \
                                                   : launch_b<PGW, CGW, A, B, 1, 1, KS>(k, lds, (int)grid, s))  \
                                : (p.terms == 3   ? launch_b<PGW, CGW, A, B, 3, 0, KS>(k, lds, (int)grid, s)   \
+                                  : p.terms == 48 ? launch_b<PGW, CGW, A, B, 48, 0, KS>(k, lds, (int)grid, s)  \
                                   : p.terms == 16 ? launch_b<PGW, CGW, A, B, 16, 0, KS>(k, lds, (int)grid, s)  \
                                                   : launch_b<PGW, CGW, A, B, 1, 0, KS>(k, lds, (int)grid, s));
   CONVB_ALL(X)
@@ -126,11 +129,15 @@ __global__ void split_bf16_kernel(codd_view in0, codd_view in1, int C0, int C1, 
     l[i] = (__bf16)(v[i] - (float)hh);
   }
   uint4* dst = xs + (size_t)b * planes * per + ((size_t)oct * hp + yp) * wp + xp;
-  if (f16) {  // CODD_TERMS_F16: one plane of IEEE fp16 records
-    f16x8 q;
+  if (f16) {  // CODD_TERMS_F16 / _SPLIT_F16: IEEE fp16 records (hi | lo)
+    f16x8 q, ql;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) q[i] = (_Float16)v[i];
+    for (int i = 0; i < 8; ++i) {
+      q[i] = (_Float16)v[i];
+      ql[i] = (_Float16)(v[i] - (float)q[i]);
+    }
     dst[0] = __builtin_bit_cast(uint4, q);
+    if (planes == 2) dst[per] = __builtin_bit_cast(uint4, ql);
     return;
   }
   dst[0] = __builtin_bit_cast(uint4, h);
@@ -138,8 +145,8 @@ __global__ void split_bf16_kernel(codd_view in0, codd_view in1, int C0, int C1, 
 }
 
 extern "C" long long codd_split_bf16_bytes(int B, int c8, int hp, int wp, int terms) {
-  if (B < 1 || c8 < 1 || hp < 1 || wp < 1 || !(terms == 1 || terms == 3 || terms == CODD_TERMS_F16)) return -1;
-  return (long long)B * (terms == 3 ? 2 : 1) * c8 * hp * wp * 16;
+  if (B < 1 || c8 < 1 || hp < 1 || wp < 1 || !CODD_TERMS_OK(terms)) return -1;
+  return (long long)B * CODD_TERMS_PLANES(terms) * c8 * hp * wp * 16;
 }
 
 extern "C" int codd_split_bf16(codd_view in0, int C0, codd_view in1, int C1, int B, int H, int W, int bt, int bl,
@@ -149,7 +156,7 @@ extern "C" int codd_split_bf16(codd_view in0, int C0, codd_view in1, int C1, int
     return CODD_EINVAL;
   const long long total = (long long)B * c8 * hp * wp;
   split_bf16_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(in0, in1, C0, C1, B, H, W, bt, bl, c8, hp, wp,
-                                                                       terms == 3 ? 2 : 1, (uint4*)xs, terms == CODD_TERMS_F16);
+                                                                       CODD_TERMS_PLANES(terms), (uint4*)xs, CODD_TERMS_IS_F16(terms));
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }

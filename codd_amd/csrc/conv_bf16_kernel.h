@@ -92,10 +92,10 @@ constexpr int CONVB_MAXP = 6; // input DMA pieces per producer wave whose source
 static inline int convb_geometry(const codd_conv_params* pp, ConvB& k, size_t& lds, long long& grid, bool need_xs) {
   k.p = *pp;
   const codd_conv_params& p = k.p;
-  if (p.ck < 8 || (p.ck & 7) || !(p.terms == 1 || p.terms == 3 || p.terms == CODD_TERMS_F16) || p.nw < 1 || p.npb < 1 || p.npb > 2 ||
+  if (p.ck < 8 || (p.ck & 7) || !CODD_TERMS_OK(p.terms) || p.nw < 1 || p.npb < 1 || p.npb > 2 ||
       p.pgw < 1 || p.cgw < 1 || p.mb < 1 || p.mb % p.cgw)
     return CODD_EINVAL;
-  const int planes = p.terms == 3 ? 2 : 1;
+  const int planes = CODD_TERMS_PLANES(p.terms);
   k.cin = p.C0 + p.C1;
   k.ntaps = p.kh * p.kw;
   k.noct = p.ck >> 3;
@@ -158,13 +158,13 @@ static inline int convb_geometry(const codd_conv_params* pp, ConvB& k, size_t& l
     if (p.gate == 1 && (p.xso || p.res1.ptr || p.res2.ptr || p.post.ptr)) return CODD_EUNSUPPORTED;
     if (p.gate == 2 && (!p.xso || !c4ok(p.res1, 3 * G) || !c4ok(p.res2, 2 * G) || !c4ok(p.post, G))) return CODD_EINVAL;
     if (p.gate == 3 && (!p.xso || !c4ok(p.res1, 2 * G) || !c4ok(p.post, G) || p.res2.ptr)) return CODD_EINVAL;
-    if (p.xso && (!(p.xso_terms == 1 || p.xso_terms == 3 || p.xso_terms == CODD_TERMS_F16) || p.xso_o8 < 0 || p.xso_bt < 0 || p.xso_bl < 0 ||
+    if (p.xso && (!CODD_TERMS_OK(p.xso_terms) || p.xso_o8 < 0 || p.xso_bt < 0 || p.xso_bl < 0 ||
                   p.xso_c8 < p.xso_o8 + cdiv(G, 8) || p.xso_hp < p.xso_bt + p.Hout || p.xso_wp < p.xso_bl + p.Wout))
       return CODD_EINVAL;
   } else if (need_xs && p.xso) {  // split-record output: plain conv only; the tensor must hold the image inside its borders
     if (p.store_mode || p.res1.ptr || p.res2.ptr || p.post.ptr || p.act == CODD_ACT_RELU_CH0) return CODD_EUNSUPPORTED;
     if (p.bias && ((uintptr_t)p.bias & 15)) return CODD_EINVAL;
-    if (!(p.xso_terms == 1 || p.xso_terms == 3 || p.xso_terms == CODD_TERMS_F16) || p.xso_o8 < 0 || p.xso_bt < 0 || p.xso_bl < 0 ||
+    if (!CODD_TERMS_OK(p.xso_terms) || p.xso_o8 < 0 || p.xso_bt < 0 || p.xso_bl < 0 ||
         p.xso_c8 < p.xso_o8 + cdiv(k.cout_eff, 8) || p.xso_hp < p.xso_bt + p.Hout || p.xso_wp < p.xso_bl + p.Wout)
       return CODD_EINVAL;
   }
@@ -248,8 +248,8 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
   constexpr int NWT = PGW * CGW;          // accumulator-tile sets (one per consumer wave, or per k-split pair)
   constexpr int NWC = NWT * KS;           // consumer waves
   constexpr int NTP = CONVB_NWP * 64;     // producer threads
-  constexpr int NPL = TERMS == 3 ? 2 : 1; // precision planes (3: hi | lo bf16; 1: bf16; 16: fp16)
-  constexpr bool F16 = TERMS == CODD_TERMS_F16;
+  constexpr int NPL = CODD_TERMS_PLANES(TERMS); // precision planes (3: hi | lo bf16; 1: bf16; 16: fp16; 48: hi | lo fp16)
+  constexpr bool F16 = CODD_TERMS_IS_F16(TERMS);
   extern __shared__ __attribute__((aligned(16))) uint4 smem4[];
   uint4* wl = smem4;                             // ring of nring weight buffers (the DMA runs nring - 1 chunks ahead)
   uint4* il = smem4 + k.nring * k.wslots;        // ring of nring input buffers
@@ -406,11 +406,11 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
     const uint4* wp_ = wb + woff + (KSTP) * wstep;                                                          \
     _Pragma("unroll") for (int m_ = 0; m_ < B; ++m_) {                                                    \
       F.ah[m_] = __builtin_bit_cast(bf16x8, wp_[m_ * 16]);                                                \
-      if (TERMS == 3) F.al[m_] = __builtin_bit_cast(bf16x8, wp_[k.wplane16 + m_ * 16]);                   \
+      if (NPL == 2) F.al[m_] = __builtin_bit_cast(bf16x8, wp_[k.wplane16 + m_ * 16]);                   \
     }                                                                                                     \
     _Pragma("unroll") for (int a_ = 0; a_ < A; ++a_) {                                                    \
       F.bh[a_] = __builtin_bit_cast(bf16x8, ib[eo_ + pbase[a_]]);                                         \
-      if (TERMS == 3) F.bl[a_] = __builtin_bit_cast(bf16x8, ib[k.iplane16 + eo_ + pbase[a_]]);            \
+      if (NPL == 2) F.bl[a_] = __builtin_bit_cast(bf16x8, ib[k.iplane16 + eo_ + pbase[a_]]);            \
     }                                                                                                     \
   }
   // one MFMA on two 16-byte fragments: bf16 or (TERMS = 16) fp16 operands, fp32 accumulate
@@ -423,7 +423,7 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
   // term-major order: consecutive MFMAs go to different accumulators (small terms first)
 #define BF_MFMA(F)                                                                                        \
   {                                                                                                       \
-    if (TERMS == 3) {                                                                                     \
+    if (NPL == 2) {                                                                                       \
       _Pragma("unroll") for (int a = 0; a < A; ++a) _Pragma("unroll") for (int m = 0; m < B; ++m)         \
         acc[a][m] = OUTF ? mma(F.al[m], F.bh[a], acc[a][m]) : mma(F.bh[a], F.al[m], acc[a][m]);           \
       _Pragma("unroll") for (int a = 0; a < A; ++a) _Pragma("unroll") for (int m = 0; m < B; ++m)         \
@@ -436,7 +436,7 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
   __syncthreads();  // chunk 0 and the entry table are in LDS
 #ifndef CONVB_NO_CONSUMER
   const int klast = k.nk - 1;
-  constexpr int NRD = 1 + NPL * (A + B), NMF = (TERMS == 3 ? 3 : 1) * A * B;  // LDS reads / MFMAs per k-step
+  constexpr int NRD = 1 + NPL * (A + B), NMF = (NPL == 2 ? 3 : 1) * A * B;  // LDS reads / MFMAs per k-step
   int wsel = 0;
   for (int ch = 0; ch < k.nchunks; ++ch) {
     const uint4* wb = wl + wsel * k.wslots;  // ring slot ch % nring
@@ -517,7 +517,7 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
     // into (hi, lo) bf16, the pair swaps one half through ds_bpermute, the even lane stores the 16-byte HI record and
     // the odd lane the LO record: 16 pixels j -> 256 contiguous bytes per (octet, plane).  No fp32 tensor is written.
     const int orec = p.xso_hp * p.xso_wp;
-    uint4* xo = (uint4*)p.xso + (size_t)b * (p.xso_terms == 3 ? 2 : 1) * p.xso_c8 * orec;
+    uint4* xo = (uint4*)p.xso + (size_t)b * CODD_TERMS_PLANES(p.xso_terms) * p.xso_c8 * orec;
     const bool odd = g & 1;
 #pragma unroll
     for (int a = 0; a < A; ++a) {
@@ -620,10 +620,11 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
         unsigned hi2[2], lo2[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          if (p.xso_terms == CODD_TERMS_F16) {  // (wave-uniform) one plane of fp16 records
+          if (CODD_TERMS_IS_F16(p.xso_terms)) {  // (wave-uniform) fp16 records: one plane, or hi | lo
             const _Float16 h0 = (_Float16)v[2 * q], h1 = (_Float16)v[2 * q + 1];
+            const _Float16 l0 = (_Float16)(v[2 * q] - (float)h0), l1 = (_Float16)(v[2 * q + 1] - (float)h1);
             hi2[q] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-            lo2[q] = 0u;
+            lo2[q] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
             continue;
           }
           const __bf16 h0 = (__bf16)v[2 * q], h1 = (__bf16)v[2 * q + 1];
@@ -636,7 +637,7 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
         const unsigned r0 = __shfl_xor(s0, 16, 64), r1 = __shfl_xor(s1, 16, 64);
         const uint4 rec = odd ? make_uint4(r0, r1, lo2[0], lo2[1]) : make_uint4(hi2[0], hi2[1], r0, r1);
         const int oct = (rco >> 3) + p.xso_o8;  // both lanes of the pair: same octet (co0 differs by 4)
-        if (inb && (co0 & ~7) < k.cout_eff && (!odd || p.xso_terms == 3))
+        if (inb && (co0 & ~7) < k.cout_eff && (!odd || CODD_TERMS_PLANES(p.xso_terms) == 2))
           xo[(size_t)(odd ? p.xso_c8 * orec : 0) + ((size_t)oct * p.xso_hp + oy + p.xso_bt) * p.xso_wp + ox + p.xso_bl] = rec;
       }
     }
@@ -737,11 +738,15 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
   extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, 1, KS>(const ConvB);      \
   extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 1, KS>(const ConvB);      \
   extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 16, 0, KS>(const ConvB);     \
-  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 16, 1, KS>(const ConvB);
+  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 16, 1, KS>(const ConvB);     \
+  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 48, 0, KS>(const ConvB);     \
+  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 48, 1, KS>(const ConvB);
 #define CONVB_DEFINE(PGW, CGW, A, B, KS)                                                         \
   template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, 0, KS>(const ConvB);             \
   template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 0, KS>(const ConvB);             \
   template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, 1, KS>(const ConvB);             \
   template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 1, KS>(const ConvB);             \
   template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 16, 0, KS>(const ConvB);            \
-  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 16, 1, KS>(const ConvB);
+  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 16, 1, KS>(const ConvB);            \
+  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 48, 0, KS>(const ConvB);            \
+  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 48, 1, KS>(const ConvB);

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
     }
     // the octets shared with the neighbouring levels: 2-byte stores of this level's slots
     const size_t per = (size_t)d.c8 * d.hp * d.wp;
-    unsigned short* base = (unsigned short*)d.ptr + (size_t)b * (d.terms == 3 ? 2 : 1) * per * 8;
+    unsigned short* base = (unsigned short*)d.ptr + (size_t)b * CODD_TERMS_PLANES(d.terms) * per * 8;
     const int nhead = of * 8 - c0, ntail = c1 - ol * 8;
     for (int e = tid; e < (nhead + ntail) * NPX; e += 256) {
       const int q = e / NPX, pi = e % NPX, n = n0 + pi;
@@ -306,8 +306,9 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const float* __restric
       const float v = tile[c - c0][pi];
       const __bf16 hi = (__bf16)v;
       const size_t at = (((size_t)(d.o8 + (c >> 3)) * d.hp + (y + d.bt)) * d.wp + (x + d.bl)) * 8 + (c & 7);
-      base[at] = xs_elem16(v, d.terms == CODD_TERMS_F16);
+      base[at] = xs_elem16(v, CODD_TERMS_IS_F16(d.terms));
       if (d.terms == 3) base[per * 8 + at] = __builtin_bit_cast(unsigned short, (__bf16)(v - (float)hi));
+      if (d.terms == CODD_TERMS_SPLIT_F16) base[per * 8 + at] = xs_elem16(v - (float)(_Float16)v, true);
     }
     return;
   }
@@ -551,7 +552,7 @@ __global__ __launch_bounds__(128) void gn_heads_prep_kernel(const codd_xs_view h
   const int j = ok ? n : N - 1;
   const int yj = j / w, xj = j - yj * w;
   const size_t per = (size_t)hs.c8 * hs.hp * hs.wp, ostride = (size_t)hs.hp * hs.wp;
-  const bool three = hs.terms == 3, f16 = hs.terms == CODD_TERMS_F16;  // (f16: head_w holds fp16 A operands too)
+  const bool three = CODD_TERMS_PLANES(hs.terms) == 2, f16 = CODD_TERMS_IS_F16(hs.terms);  // (f16: head_w holds fp16 A operands too)
   const uint4* src = (const uint4*)hs.ptr + (size_t)b * (three ? 2 : 1) * per +
                      ((size_t)(hs.o8 + g) * hs.hp + (yj + hs.bt)) * hs.wp + (xj + hs.bl);
   const uint4* wl = Wp + lane;
@@ -582,8 +583,15 @@ __global__ __launch_bounds__(128) void gn_heads_prep_kernel(const codd_xs_view h
     if (three) {                                                                                        \
       const codd_bf16x8 al = __builtin_bit_cast(codd_bf16x8, wlo[BUF][WQ]);                             \
       const codd_bf16x8 bl = __builtin_bit_cast(codd_bf16x8, xl[BUF][S]);                               \
-      acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[T], 0, 0, 0);                        \
-      acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[T], 0, 0, 0);                        \
+      if (f16) {                                                                                        \
+        acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(codd_f16x8, al),             \
+                                                        __builtin_bit_cast(codd_f16x8, bh), acc[T], 0, 0, 0); \
+        acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(codd_f16x8, ah),             \
+                                                        __builtin_bit_cast(codd_f16x8, bl), acc[T], 0, 0, 0); \
+      } else {                                                                                          \
+        acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[T], 0, 0, 0);                      \
+        acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[T], 0, 0, 0);                      \
+      }                                                                                                 \
     }                                                                                                   \
     if (f16)                                                                                            \
       acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(codd_f16x8, ah),               \

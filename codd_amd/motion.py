@@ -198,7 +198,7 @@ class BasicUpdateBlock(ops.RuntimeState, nn.Module):
         return t1, t2
 
     def _gates_fused(self, net):
-        return FUSE_GATES and MERGE_ENC_HEADS and ops.CONV_PRECISION in ("split", "bf16", "fp16")
+        return FUSE_GATES and MERGE_ENC_HEADS and ops.CONV_PRECISION in ("split", "split16", "bf16", "fp16")
 
     def _h4(self, net):
         """The hidden state in the channel-quad layout (ops.C4Tensor) of the gate epilogues: written by the q-gate
@@ -380,7 +380,7 @@ class BasicUpdateBlock(ops.RuntimeState, nn.Module):
         codd_se3_gn_step_heads (include/codd_hip.h) + their 38 biases; cached on the module per parameter version."""
         mods = (self.ae[2], self.delta[2], self.weight[2])
         ver = tuple((m.weight.data_ptr(), m.weight._version, m.bias._version) for m in mods)
-        ver = ver + (ops.CONV_PRECISION == "fp16",)  # (fp16 records need fp16 A operands)
+        ver = ver + (ops.CONV_PRECISION in ("fp16", "split16"),)  # (fp16 records need fp16 A operands)
         c = self.__dict__.get("_codd_head_matrix")
         if c is None or c[0] != ver:
             Wm = torch.cat([m.weight.detach().reshape(m.weight.shape[0], 256) for m in mods], 0).float()
@@ -411,7 +411,8 @@ def pack_head_matrix(Wm, f16=False):
     v = torch.stack(blocks, 0)  # [32, 64, 8] fp32
     if f16:
         hi = v.half()
-        return torch.stack([hi, torch.zeros_like(hi)], 1).contiguous().view(torch.bfloat16)  # (16-bit payload; dtype is a label)
+        lo = (v - hi.float()).half()  # (read only with split-fp16 records, terms = 48)
+        return torch.stack([hi, lo], 1).contiguous().view(torch.bfloat16)  # (16-bit payload; dtype is a label)
     hi = v.bfloat16()
     lo = (v - hi.float()).bfloat16()
     return torch.stack([hi, lo], 1).contiguous()  # [32, 2, 64, 8]

@@ -202,11 +202,14 @@ def _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl):
 #                      tests at the benchmarked configurations bound its effect on the disparities)
 #   "fp32"             exact-fp32 MFMA kernels (v_mfma_f32_16x16x4_f32)
 #   "bf16"             bf16 operands, fp32 accumulate (BASELINE.json configs[4]; reference auto_fp16 hook)
+#   "split16"          split-FP16 operands (hi | lo IEEE fp16 planes, three v_mfma_f32_16x16x32_f16 per product): the split
+#                      scheme with 22-bit operands, products to ~2^-22 -- fp32's own grade -- at the same MFMA rate as
+#                      "split" (16-bit operands, 2^-17); fp16's range applies (|x| <= 65504)
 #   "fp16"             IEEE fp16 operands (v_mfma_f32_16x16x32_f16), fp32 accumulate: the reference's own reduced
 #                      precision (auto_fp16 IS .half(), model/codd.py:37,128): 11 mantissa bits at bf16's MFMA rate
 CONV_PRECISION = _os.environ.get("CODD_CONV_PRECISION", "split")
 ALLPAIRS_SPLIT = _os.environ.get("CODD_ALLPAIRS_SPLIT", "1") == "1"  # (A/B switch of allpairs_corr)
-_TERMS = dict(split=3, bf16=1, fp16=16)  # codd_conv_params.terms (CODD_TERMS_*)
+_TERMS = dict(split=3, bf16=1, fp16=16, split16=48)  # codd_conv_params.terms (CODD_TERMS_*)
 
 
 # "bf16" / "fp16" with BF16_STAGE_POLICY on ("bf16mix" / "fp16mix" in bench.py / set_conv_precision): the stages of
@@ -215,7 +218,13 @@ _TERMS = dict(split=3, bf16=1, fp16=16)  # codd_conv_params.terms (CODD_TERMS_*)
 # bf16 / fp16 operands.
 BF16_STAGE_POLICY = False
 _HALF_MODES = ("bf16", "fp16")  # one 16-bit operand plane, one MFMA per product
-_MODES = ("split", "fp32", "bf16", "bf16mix", "fp16", "fp16mix")
+_MODES = ("split", "split16", "fp32", "bf16", "bf16mix", "fp16", "fp16mix")
+_SPLIT_MODES = ("split", "split16")  # three MFMAs per product on hi | lo operand planes: the fp32-grade modes
+
+
+def _split_terms():
+    """terms of the all-pairs GEMMs / forced-split re-layouts under the current mode (3 | 48)"""
+    return _TERMS["split16"] if CONV_PRECISION == "split16" else 3
 
 
 def set_conv_precision(mode):
@@ -252,7 +261,7 @@ class stage:
 
     def __enter__(self):
         self.prev = None
-        if self.name in _STAGE_PRECISION and (CONV_PRECISION == "split" or (CONV_PRECISION in _HALF_MODES and BF16_STAGE_POLICY)):
+        if self.name in _STAGE_PRECISION and (CONV_PRECISION in _SPLIT_MODES or (CONV_PRECISION in _HALF_MODES and BF16_STAGE_POLICY)):
             to = _STAGE_PRECISION[self.name]
             if to != "split" or CONV_PRECISION == "split":  # (a "split" stage under bf16mix stays bf16)
                 self.prev = set_conv_precision(to)
@@ -1119,7 +1128,7 @@ def use_roll(C, B, Cin_unused, H, W):
     few 64-column strips on HITNet's half-resolution maps to fill 256 CUs and stays on the tile kernels.  The kernel is
     exact fp32: under the plain bf16 mode (bf16 operands EVERYWHERE, BASELINE.json configs[4]) the layers stay on the bf16
     tile kernels so that the mode's dtype description holds."""
-    return (USE_ROLL and CONV_PRECISION in ("split", "fp32") and (C == 16 or (C == 32 and ROLL_C32))
+    return (USE_ROLL and CONV_PRECISION in ("split", "split16", "fp32") and (C == 16 or (C == 32 and ROLL_C32))
             and B * H * W >= ROLL_MIN_PIXELS)
 
 
@@ -1317,7 +1326,7 @@ def allpairs_corr_split(f1, f2):
         p = ConvParams()
         p.C0, p.C1, p.B, p.Hin, p.Win, p.Cout, p.Hout, p.Wout = D, 0, 1, hh, ww, N, hh, ww
         p.kh = p.kw = p.sy = p.sx = p.dil_y = p.dil_x = 1
-        p.terms, p.out_ctot = 3, N
+        p.terms, p.out_ctot = _split_terms(), N
         key = (D, hh, ww)
         cfg = _ALLPAIRS_PICK.get(key)
         if cfg is None:
@@ -1336,9 +1345,9 @@ def allpairs_corr_split(f1, f2):
         for b in range(B):
             pk = (cfg[3], cfg[2])
             if (pk, b) not in packs:  # weights[co = n1][ci = d] = f1[b, d, n1] / 16 for this (mb, ck)
-                nbytes = lib.codd_conv2d_packed_bytes_bf16(N, D, 1, 1, cfg[3], cfg[2], 3)
+                nbytes = lib.codd_conv2d_packed_bytes_bf16(N, D, 1, 1, cfg[3], cfg[2], p.terms)
                 wp = torch.empty(nbytes, device=f1.device, dtype=torch.uint8)
-                _abi.check(lib.codd_conv2d_pack_weights_bf16(f1[b].data_ptr(), wp.data_ptr(), N, D, 1, 1, cfg[3], cfg[2], 3,
+                _abi.check(lib.codd_conv2d_pack_weights_bf16(f1[b].data_ptr(), wp.data_ptr(), N, D, 1, 1, cfg[3], cfg[2], p.terms,
                                                              1, N, 1.0 / 16.0, _stream()), "pack_weights_bf16")
                 packs[(pk, b)] = wp
             p.wpacked = packs[(pk, b)].data_ptr()
@@ -1356,10 +1365,11 @@ def split_input_as(x, mode, cands, p):
     lib = _abi.load()
     c8, hp, wp = _split_dims(p, cands)
     B, C0, H, W = x.shape
-    buf = torch.empty(lib.codd_split_bf16_bytes(B, c8, hp, wp, 3), device=x.device, dtype=torch.uint8)
-    _abi.check(lib.codd_split_bf16(_view(x), C0, _view(None), 0, B, H, W, 0, 0, c8, hp, wp, 3, buf.data_ptr(), _stream()),
+    t = p.terms if p.terms in (3, 48) else 3
+    buf = torch.empty(lib.codd_split_bf16_bytes(B, c8, hp, wp, t), device=x.device, dtype=torch.uint8)
+    _abi.check(lib.codd_split_bf16(_view(x), C0, _view(None), 0, B, H, W, 0, 0, c8, hp, wp, t, buf.data_ptr(), _stream()),
                "codd_split_bf16")
-    return SplitTensor(buf, B, C0, H, W, 0, 0, hp, wp, c8, 3)
+    return SplitTensor(buf, B, C0, H, W, 0, 0, hp, wp, c8, t)
 
 
 def _allpairs_tune(lib, p, cands, f1b, N, D):
@@ -1368,9 +1378,9 @@ def _allpairs_tune(lib, p, cands, f1b, N, D):
     src = torch.zeros(1, D, p.Hin, p.Win, device=f1b.device)
     for c in cands:
         xs = split_input_as(src, "split", [c], p)
-        nbytes = lib.codd_conv2d_packed_bytes_bf16(N, D, 1, 1, c[3], c[2], 3)
+        nbytes = lib.codd_conv2d_packed_bytes_bf16(N, D, 1, 1, c[3], c[2], p.terms)
         wp = torch.empty(nbytes, device=f1b.device, dtype=torch.uint8)
-        lib.codd_conv2d_pack_weights_bf16(f1b.data_ptr(), wp.data_ptr(), N, D, 1, 1, c[3], c[2], 3, 1, N, 1.0 / 16.0, _stream())
+        lib.codd_conv2d_pack_weights_bf16(f1b.data_ptr(), wp.data_ptr(), N, D, 1, 1, c[3], c[2], p.terms, 1, N, 1.0 / 16.0, _stream())
         p.wpacked, p.xs = wp.data_ptr(), xs.buf.data_ptr()
         p.xs_c8, p.xs_hp, p.xs_wp, p.xs_bt, p.xs_bl, p.xs_o8 = xs.c8, xs.hp, xs.wp, xs.bt, xs.bl, 0
         p.npb, p.nw, p.ck, p.mb, p.layout, p.pgw, p.cgw = c[:7]
@@ -1395,7 +1405,7 @@ def allpairs_corr(f1, f2, split=None):
     """-> 4 pyramid levels [B, h*w, (h>>i)*(w>>i)] (reference blocks/corr.py:28-45).  ``split`` (default: the "split"
     conv precision is active): the GEMMs run on the split-bf16 kernel (allpairs_corr_split), else on exact-fp32 MFMA."""
     if split is None:
-        split = CONV_PRECISION == "split" and ALLPAIRS_SPLIT
+        split = CONV_PRECISION in _SPLIT_MODES and ALLPAIRS_SPLIT
     if split:
         return allpairs_corr_split(f1, f2)
     lib = _abi.load()

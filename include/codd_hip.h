@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CODD_ABI_VERSION 10
+#define CODD_ABI_VERSION 11
 
 #define CODD_OK 0
 #define CODD_EINVAL (-1)
@@ -56,6 +56,15 @@ typedef struct {
 #define CODD_TERMS_BF16 1
 #define CODD_TERMS_SPLIT 3
 #define CODD_TERMS_F16 16
+/*   CODD_TERMS_SPLIT_F16 (48)  two planes (hi | lo) of IEEE-fp16 records, three v_mfma_f32_16x16x32_f16 per product (ABI v11):
+ *                          x = hi + lo to 22 significant bits, products to ~2^-22 -- the split scheme at fp32's own grade
+ *                          (bf16 split: 16 bits, 2^-17), same MFMA rate.  fp16's RANGE applies: |x| > 65504 becomes +-inf and
+ *                          lo parts below 6e-8 vanish (absolute error <= 3e-8 per operand); the host keeps it to stages with
+ *                          O(1)-O(1e3) activations and the parity tests watch for non-finite values. */
+#define CODD_TERMS_SPLIT_F16 48
+#define CODD_TERMS_OK(t) ((t) == 1 || (t) == 3 || (t) == 16 || (t) == 48)
+#define CODD_TERMS_PLANES(t) (((t) == 3 || (t) == 48) ? 2 : 1)
+#define CODD_TERMS_IS_F16(t) ((t) == 16 || (t) == 48)
 typedef struct codd_xs_view {
   void* ptr;
   int c8, hp, wp, bt, bl, o8, terms;
@@ -106,7 +115,7 @@ typedef struct {
                  weights in LDS and walk the tiles, prefetching the next tile's input); 2: split-bf16 kernel (weights packed by
                  codd_conv2d_pack_weights_bf16 for (mb, ck, terms); here nw = tile rows, npb = 16-pixel units per
                  tile row (1 | 2), ck a multiple of 8) */
-  int terms;  /* layout 2: 1 = bf16 operands, 3 = split-bf16 (hi/lo) operands, 16 = fp16 operands (CODD_TERMS_*) */
+  int terms;  /* layout 2: 1 = bf16 operands, 3 = split-bf16 (hi/lo) operands, 16 = fp16 operands, 48 = split-fp16 (CODD_TERMS_*) */
   int pgw, cgw; /* layout 2: wave grid of a workgroup (pixel-unit groups x channel-block groups), mb % cgw == 0 */
   /* layout 2: the input (channel concatenation of C0 + C1 channels; in0 / in1 are not read) re-laid-out by
    * codd_split_bf16 with borders (pad_t, pad_l): [B][plane][xs_c8 octets][xs_hp][xs_wp][8] bf16 */

@@ -698,7 +698,7 @@ def test_gru_gates_writing_split_records_equal_gate_plus_relayout():
     assert torch.equal(ops.split_input(h_ref, border=4).buf, hb.buf)
 
 
-@pytest.mark.parametrize("mode,wtol,ttol", [("split", 1e-4, 2e-3), ("fp16", 4e-3, 6e-2)])
+@pytest.mark.parametrize("mode,wtol,ttol", [("split", 1e-4, 2e-3), ("split16", 1e-4, 2e-3), ("fp16", 4e-3, 6e-2)])
 def test_gn_step_with_fused_heads_equals_heads_then_step(mode, wtol, ttol):
     """codd_se3_gn_step_heads (1x1 heads inside the record packing, hidden channels read in split-bf16 form -- or, mode
     "fp16", as one plane of IEEE fp16 records with fp16 head weights on v_mfma_f32_16x16x32_f16) against fp32 1x1
@@ -732,7 +732,7 @@ def _gn_step_with_fused_heads(ops, mode, wtol, ttol):
     T_new = T.clone()
     from codd_amd.motion import pack_head_matrix
     assert hs.terms == ops._TERMS[mode]
-    w_out = ops.se3_gn_step_heads(T_new, hs, pack_head_matrix(Wm, f16=mode == "fp16"), bm, xyz, d1, K8, radius=6)
+    w_out = ops.se3_gn_step_heads(T_new, hs, pack_head_matrix(Wm, f16=mode in ("fp16", "split16")), bm, xyz, d1, K8, radius=6)
     step = (T_ref - T).abs().max().item()
     err = (T_new - T_ref).abs().max().item()
     print(mode, "gn step", step, "fused-heads deviation", err, "weight dev", (w_out - weight).abs().max().item())
@@ -740,7 +740,7 @@ def _gn_step_with_fused_heads(ops, mode, wtol, ttol):
     assert err < ttol * step
 
 
-@pytest.mark.parametrize("mode", ["split", "fp16"])
+@pytest.mark.parametrize("mode", ["split", "split16", "fp16"])
 def test_geometry_lookup_writing_split_records_equals_lookup_plus_relayout(mode):
     """(mode "fp16": the same writers emit one plane of IEEE fp16 records, CODD_TERMS_F16)"""
     from codd_amd import ops

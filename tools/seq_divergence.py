@@ -77,7 +77,7 @@ def line(tag, xs, ys):
     print(f"{'':34s} flip  " + " ".join(f"{f:.1e}" for f in fs), flush=True)
 
 
-ALL = dict(default=dict(), no_roll=dict(roll=False), fp32_convs=dict(precision="fp32"),
+ALL = dict(default=dict(), no_roll=dict(roll=False), fp32_convs=dict(precision="fp32"), split16=dict(precision="split16"),
            input_noise_1e_7=dict(noise=1e-7), eager=dict(graph=False), fnet_exact=dict(exact=("fnet",)),
            update_exact=dict(exact=("update",)), fusion_exact=dict(exact=("fusion",)), motion_exact=dict(exact=("motion",)),
            fnet_fusion_exact=dict(exact=("fnet", "fusion")), allpairs_exact=dict(exact=("allpairs",)),
