@@ -158,13 +158,14 @@ static inline int convb_geometry(const codd_conv_params* pp, ConvB& k, size_t& l
     if (p.gate == 1 && (p.xso || p.res1.ptr || p.res2.ptr || p.post.ptr)) return CODD_EUNSUPPORTED;
     if (p.gate == 2 && (!p.xso || !c4ok(p.res1, 3 * G) || !c4ok(p.res2, 2 * G) || !c4ok(p.post, G))) return CODD_EINVAL;
     if (p.gate == 3 && (!p.xso || !c4ok(p.res1, 2 * G) || !c4ok(p.post, G) || p.res2.ptr)) return CODD_EINVAL;
-    if (p.xso && (!CODD_TERMS_OK(p.xso_terms) || p.xso_o8 < 0 || p.xso_bt < 0 || p.xso_bl < 0 ||
+    if (p.xso && (p.xso_terms != p.terms || p.xso_o8 < 0 || p.xso_bt < 0 || p.xso_bl < 0 ||
                   p.xso_c8 < p.xso_o8 + cdiv(G, 8) || p.xso_hp < p.xso_bt + p.Hout || p.xso_wp < p.xso_bl + p.Wout))
       return CODD_EINVAL;
   } else if (need_xs && p.xso) {  // split-record output: plain conv only; the tensor must hold the image inside its borders
     if (p.store_mode || p.res1.ptr || p.res2.ptr || p.post.ptr || p.act == CODD_ACT_RELU_CH0) return CODD_EUNSUPPORTED;
     if (p.bias && ((uintptr_t)p.bias & 15)) return CODD_EINVAL;
-    if (!CODD_TERMS_OK(p.xso_terms) || p.xso_o8 < 0 || p.xso_bt < 0 || p.xso_bl < 0 ||
+    // (a kernel writes records in its OWN operand format: the epilogue's conversion is chosen at compile time)
+    if (p.xso_terms != p.terms || p.xso_o8 < 0 || p.xso_bt < 0 || p.xso_bl < 0 ||
         p.xso_c8 < p.xso_o8 + cdiv(k.cout_eff, 8) || p.xso_hp < p.xso_bt + p.Hout || p.xso_wp < p.xso_bl + p.Wout)
       return CODD_EINVAL;
   }
@@ -517,7 +518,7 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
     // into (hi, lo) bf16, the pair swaps one half through ds_bpermute, the even lane stores the 16-byte HI record and
     // the odd lane the LO record: 16 pixels j -> 256 contiguous bytes per (octet, plane).  No fp32 tensor is written.
     const int orec = p.xso_hp * p.xso_wp;
-    uint4* xo = (uint4*)p.xso + (size_t)b * CODD_TERMS_PLANES(p.xso_terms) * p.xso_c8 * orec;
+    uint4* xo = (uint4*)p.xso + (size_t)b * NPL * p.xso_c8 * orec;
     const bool odd = g & 1;
 #pragma unroll
     for (int a = 0; a < A; ++a) {
@@ -620,24 +621,24 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
         unsigned hi2[2], lo2[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          if (CODD_TERMS_IS_F16(p.xso_terms)) {  // (wave-uniform) fp16 records: one plane, or hi | lo
+          if constexpr (F16) {  // fp16 records: one plane, or hi | lo (xso_terms == terms: convb_geometry)
             const _Float16 h0 = (_Float16)v[2 * q], h1 = (_Float16)v[2 * q + 1];
             const _Float16 l0 = (_Float16)(v[2 * q] - (float)h0), l1 = (_Float16)(v[2 * q + 1] - (float)h1);
             hi2[q] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
             lo2[q] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
-            continue;
+          } else {
+            const __bf16 h0 = (__bf16)v[2 * q], h1 = (__bf16)v[2 * q + 1];
+            const __bf16 l0 = (__bf16)(v[2 * q] - (float)h0), l1 = (__bf16)(v[2 * q + 1] - (float)h1);
+            hi2[q] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            lo2[q] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
           }
-          const __bf16 h0 = (__bf16)v[2 * q], h1 = (__bf16)v[2 * q + 1];
-          const __bf16 l0 = (__bf16)(v[2 * q] - (float)h0), l1 = (__bf16)(v[2 * q + 1] - (float)h1);
-          hi2[q] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-          lo2[q] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
         }
         // even lane needs the partner's hi, odd lane the partner's lo
         const unsigned s0 = odd ? hi2[0] : lo2[0], s1 = odd ? hi2[1] : lo2[1];
         const unsigned r0 = __shfl_xor(s0, 16, 64), r1 = __shfl_xor(s1, 16, 64);
         const uint4 rec = odd ? make_uint4(r0, r1, lo2[0], lo2[1]) : make_uint4(hi2[0], hi2[1], r0, r1);
         const int oct = (rco >> 3) + p.xso_o8;  // both lanes of the pair: same octet (co0 differs by 4)
-        if (inb && (co0 & ~7) < k.cout_eff && (!odd || CODD_TERMS_PLANES(p.xso_terms) == 2))
+        if (inb && (co0 & ~7) < k.cout_eff && (!odd || NPL == 2))
           xo[(size_t)(odd ? p.xso_c8 * orec : 0) + ((size_t)oct * p.xso_hp + oy + p.xso_bt) * p.xso_wp + ox + p.xso_bl] = rec;
       }
     }

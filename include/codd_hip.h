@@ -125,7 +125,7 @@ typedef struct {
                        convolutions of the same activation, e.g. a 3x3 and a dilated 3x3) */
   int xs_o8;        /* first channel octet of this conv's input inside the split tensor (channel-slice views) */
   /* layout 2, optional: write the result as split-bf16 records straight into the NEXT convolution's input tensor
-   * (same layout as xs, borders (xso_bt, xso_bl), first octet xso_o8, xso_terms = the consumer's terms) instead of
+   * (same layout as xs, borders (xso_bt, xso_bl), first octet xso_o8, xso_terms = the consumer's terms, which must equal `terms`) instead of
    * fp32 NCHW `out` (then unused; plain convolutions only: no residual / post operand, no deconv).  The border and
    * the octets past the output channels are NOT written: the caller keeps the tensor zero there. */
   void* xso;
