@@ -24,7 +24,7 @@ def main():
         z = np.load(path)
         arrays = {k: z[k] for k in z.files}
         H, W = T.CASES[case[0]][:2]
-        MF = sum(1 for k in z.files if k.startswith(name + "_f"))
+        MF = T.n_frames(z, name)
         sd = T._build(False, case[1])[1]
         img, r_img, _ = synth.stereo_sequence(H, W, MF, **({"flow": case[3]} if len(case) > 3 else {}))
         with torch.no_grad():

@@ -20,7 +20,8 @@ def main():
     out, main_p = sys.argv[1:3]
     m = np.load(main_p)
     arrays = {k: m[k] for k in m.files if "@" not in k}
-    MF = sum(1 for k in arrays if k.startswith(NAME + "_f"))
+    import re
+    MF = sum(1 for k in arrays if re.fullmatch(NAME + r"_f\d+", k))
     for spec in sys.argv[3:]:
         vname, rest = spec.split("=")
         path, _, prefix = rest.partition(":")

@@ -111,3 +111,33 @@ def test_robust_statistics_always_hold():
     # a uniform 5e-4 px offset: all-pixel mean inside 1e-3 but the median is not at rounding level -> fails even under (1)
     with pytest.raises(AssertionError):
         T.judge_frame("c", 0, torch.from_numpy(A + np.float32(5e-4)), FakeNpz({"c_f0": A}), "t")
+
+
+def test_tracked_long_goldens_are_self_consistent():
+    """The committed goldens of the recurrent-sequence tests: every tracked frame finite; the full-resolution frames
+    reproduce their sub-grid frames bit for bit; a variant's per-frame table equals what its kept frames say and every frame
+    whose table entry is >= 1e-3 / 3 IS kept (so rule (2) can look at it); the stereo conditioning record covers every frame."""
+    for name, case in T.LONG_CASES.items():
+        z = np.load(case[4] if len(case) > 4 else T.LONG_GOLDEN)
+        sub = int(z["sub"])
+        MF = T.n_frames(z, name)
+        assert MF == case[2], (name, MF)
+        for f in range(MF):
+            A = z[f"{name}_f{f}"]
+            assert np.isfinite(A).all() and A.dtype == np.float32
+            if f"{name}_full_f{f}" in z.files:
+                assert np.array_equal(z[f"{name}_full_f{f}"][::sub, ::sub], A), (name, f)
+            if name != "cfg5_it1":
+                assert f"{name}_stereo_sens_f{f}" in z.files, (name, f)
+        for v in T.ORACLE_VARIANTS:
+            if f"{name}@{v}_env" not in z.files:
+                continue
+            env = z[f"{name}@{v}_env"]
+            assert env.shape == (MF, 2)
+            for f in range(MF):
+                kept = f"{name}@{v}_f{f}" in z.files
+                if env[f, 0] == env[f, 0]:
+                    assert kept == bool(env[f, 0] >= 1e-3 / 3), (name, v, f, env[f])
+                if kept:
+                    d = np.abs(z[f"{name}@{v}_f{f}"] - z[f"{name}_f{f}"])
+                    assert abs(d.mean() - env[f, 0]) <= 1e-6 * max(1.0, env[f, 0]) and abs((d > 0.25).mean() - env[f, 1]) < 1e-9

@@ -24,7 +24,7 @@ _case = T.LONG_CASES[PREFIX]
 name = _case[0]
 H, W, intr, img_shape, _, _ = T.CASES[name]
 z, sub = T._long_golden(PREFIX)
-N = min(N, sum(1 for k_ in z.files if k_.startswith(PREFIX + "_f")))
+N = min(N, T.n_frames(z, PREFIX))
 img, r_img, _ = synth.stereo_sequence(H, W, N, **({"flow": _case[3]} if len(_case) > 3 else {}))
 metas = synth.default_metas(H, W, img_shape=img_shape, intrinsics=intr)
 
