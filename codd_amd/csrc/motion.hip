@@ -1026,6 +1026,146 @@ __global__ __launch_bounds__(64 * GN_WAVES) void se3_gn_build3_kernel(
   for (int k = wave; k < 27; k += GN_WAVES) pp[k * 64] = red[k][lane];
 }
 
+// The pair builder with the pixel's own embedding in LDS (round 5, CODD_GN_AILDS=1): same instructions on the same values in
+// the same order -- same bits -- but 32 registers fewer live across the step, so that four waves fit a SIMD (the scalar-load
+// waits are 37 % of a wave's life: finding 57) without the 16 KB of affinities per workgroup that the two-pass builder costs
+// the co-scheduled z|r convolution (8 KB per workgroup here, shared with the reduction image).
+__global__ __launch_bounds__(64 * GN_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void se3_gn_build5_kernel(
+    const float* __restrict__ T, const float* __restrict__ jd, const float* __restrict__ geo2, int h, int w, float fx,
+    float fy, float cx, float cy, int radius, int tiles_x, int ntiles, int q4, int gmax, float* __restrict__ part) {
+  // the pixel's own embedding lives in LDS ([quad q][lane] float4: conflict-free 16-byte reads), NOT in 32 registers that
+  // are live across the whole step; the partial-sum image of the reduction aliases it (the loop is over by then)
+  __shared__ float4 aild[8][64];
+  float (*red)[64] = (float (*)[64])&aild[0][0];  // [27][64] floats = 6.9 KB of the 8 KB
+  const int N = h * w, wp2 = (w + 1) >> 1;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+  const int tx0 = (tile % tiles_x) * 8, ty0 = (tile / tiles_x) * 8;
+  const int ylo = max(ty0 - radius, 0), yhi = min(ty0 + 7 + radius, h - 1);
+  const int xlo = max(tx0 - radius, 0), xhi = min(tx0 + 7 + radius, w - 1);
+  const int ncols = xhi - xlo + 1, nj = (yhi - ylo + 1) * ncols;
+  const int G = gn_groups(nj, q4, gmax);
+  if (g >= G) return;
+  const int slot = g * GN_WAVES + wave, nslots = G * GN_WAVES;
+  const int s0 = (int)((long long)nj * slot / nslots), s1 = (int)((long long)nj * (slot + 1) / nslots);
+  const int ys = ylo + s0 / ncols, xs = xlo + s0 % ncols;
+  const int ye = ylo + (s1 - 1) / ncols, xe = xlo + (s1 - 1) % ncols;
+
+  const int xi = tx0 + (lane & 7), yi = ty0 + (lane >> 3);
+  const bool vi = xi < w && yi < h;
+  const int i = vi ? yi * w + xi : 0;
+  const int xim = xi - radius, yim = yi - radius;
+  const unsigned twor = 2u * (unsigned)radius;
+  const float* rec = jd + (size_t)b * N * GN_JS;
+  const float* aip = rec + (size_t)i * GN_JS;
+  const SE3T Ti = se3_load(T + ((size_t)b * N + i) * 7);
+  const V3 c0 = qrot(Ti.q, V3{1.f, 0.f, 0.f}), c1 = qrot(Ti.q, V3{0.f, 1.f, 0.f}), c2 = qrot(Ti.q, V3{0.f, 0.f, 1.f});
+  for (int q = wave; q < 8; q += GN_WAVES) aild[q][lane] = *(const float4*)(aip + 4 * q);  // (every wave of the tile: same pixels)
+  __syncthreads();
+  const float ai2 = aip[41];
+  const v2f Z = {0.f, 0.f};
+  v2f H00 = Z, H11 = Z, H02 = Z, H12 = Z, H22 = Z, H03 = Z, H04 = Z, H05 = Z, H13 = Z, H14 = Z, H15 = Z, H23 = Z, H24 = Z,
+      H25 = Z, H33 = Z, H34 = Z, H35 = Z, H44 = Z, H45 = Z, H55 = Z, b0 = Z, b1 = Z, b2 = Z, b3 = Z, b4 = Z, b5 = Z;
+#define BC(s) ((v2f){(s), (s)})
+
+  // Walk over the wave's pairs, row by row.  The records of a pair occupy 84 SGPRs (2 x 32 embedding values + 10 geometry
+  // pairs): five of the six 16-register tuples a wave has, so the compiler requests them in three or four separately
+  // awaited portions, and they cannot be requested a step ahead -- every attempt (next pair's records loaded into the
+  // registers the step has just finished with; scalar-cache warm-up loads; the embeddings through the wave's own LDS
+  // region with broadcast ds_read_b128) ended in SGPR spills through v_readlane / v_writelane, in vector loads, or at 2
+  // waves per SIMD and slower than this form (ROCm 7.2; DESIGN finding 45).
+  if (s1 > s0)
+  for (int yj = ys; yj <= ye; ++yj) {
+    const bool rowin = vi && (unsigned)(yj - yim) <= twor;
+    const float* rrow = rec + (size_t)yj * w * GN_JS;
+    const v2f* grow = (const v2f*)(geo2 + ((size_t)b * h + yj) * wp2 * GN_G2);
+    const int xa = yj == ys ? xs : xlo, xb = yj == ye ? xe : xhi;
+    for (int xp = xa >> 1; xp <= (xb >> 1); ++xp) {
+      const int x0 = 2 * xp, x1 = x0 + 1;
+      const bool own0 = x0 >= xa, own1 = x1 <= xb;  // (x0 <= xb and x1 >= xa always hold)
+      const float4* e0 = (const float4*)(rrow + (size_t)x0 * GN_JS);
+      const float4* e1 = (const float4*)(rrow + (size_t)min(x1, w - 1) * GN_JS);
+      const v2f* gp = grow + (size_t)xp * (GN_G2 / 2);
+      v2f G2[10];
+#pragma unroll
+      for (int k = 0; k < 10; ++k) G2[k] = gp[k];
+      float4 r0[8], r1[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) r0[q] = e0[q];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) r1[q] = e1[q];
+      const v2f Xx = G2[0], Xy = G2[1], Xz = G2[2];
+      const v2f Yz = GN_PK(BC(c0.z), Xx, GN_PK(BC(c1.z), Xy, GN_PK(BC(c2.z), Xz, BC(Ti.t.z))));
+      const bool in0 = rowin & own0 & ((unsigned)(x0 - xim) <= twor) & (Xz.x >= MIN_DEPTH) & (Yz.x >= MIN_DEPTH);
+      const bool in1 = rowin & own1 & ((unsigned)(x1 - xim) <= twor) & (Xz.y >= MIN_DEPTH) & (Yz.y >= MIN_DEPTH);
+      v2f p0 = Z, p1 = Z, q0 = Z, q1 = Z;
+      float4 a4 = aild[0][lane], a5 = aild[1][lane];  // two quads in flight, the next one requested before this one is used
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4 nx = aild[q + 2 < 8 ? q + 2 : 7][lane];
+        const v2f alo = {a4.x, a4.y}, ahi = {a4.z, a4.w};
+        p0 = GN_PK(alo, (v2f){r0[q].x, r0[q].y}, p0);
+        p1 = GN_PK(ahi, (v2f){r0[q].z, r0[q].w}, p1);
+        q0 = GN_PK(alo, (v2f){r1[q].x, r1[q].y}, q0);
+        q1 = GN_PK(ahi, (v2f){r1[q].z, r1[q].w}, q1);
+        __builtin_amdgcn_sched_barrier(0);  // (keeps the compiler from hoisting all eight reads: 32 registers again)
+        a4 = a5; a5 = nx;
+      }
+      p0 += p1;
+      q0 += q1;
+      const v2f dot = {p0.x + p0.y, q0.x + q0.y};
+      const v2f e2 = GN_PK(BC(-2.f), dot, BC(ai2) + G2[9]);
+      const float ax = __builtin_amdgcn_rcpf(1.f + __expf(fmaxf(e2.x, 0.f)));
+      const float ay = __builtin_amdgcn_rcpf(1.f + __expf(fmaxf(e2.y, 0.f)));
+      const v2f a = {in0 ? ax : 0.f, in1 ? ay : 0.f};  // sigmoid(-d2), masked
+      if (__ballot(a.x > 1e-9f || a.y > 1e-9f) == 0ull) continue;  // (as in se3_gn_build_kernel)
+      const v2f Yx = GN_PK(BC(c0.x), Xx, GN_PK(BC(c1.x), Xy, GN_PK(BC(c2.x), Xz, BC(Ti.t.x))));
+      const v2f Yy = GN_PK(BC(c0.y), Xx, GN_PK(BC(c1.y), Xy, GN_PK(BC(c2.y), Xz, BC(Ti.t.y))));
+      const v2f d = {__builtin_amdgcn_rcpf(fmaxf(Yz.x, MIN_DEPTH)), __builtin_amdgcn_rcpf(fmaxf(Yz.y, MIN_DEPTH))};
+      const v2f xn = Yx * d, yn = Yy * d;
+      const v2f rx = G2[3] - xn, ry = G2[4] - yn, rz = G2[5] - d;  // (rx, ry in units of fx, fy: folded into S00, S11)
+      const v2f S00 = a * G2[6], S11 = a * G2[7], t = (a * G2[8]) * d;
+      const v2f S02 = -(S00 * xn), S12 = -(S11 * yn);
+      const v2f S22 = GN_PK(t, d, -GN_PK(S12, yn, S02 * xn));
+      const v2f g0 = S00 * rx, g1 = S11 * ry;
+      const v2f g2 = -GN_PK(t, rz, GN_PK(g1, yn, g0 * xn));
+      const v2f dd = d * d;
+      H00 = GN_PK(dd, S00, H00); H11 = GN_PK(dd, S11, H11); H02 = GN_PK(dd, S02, H02); H12 = GN_PK(dd, S12, H12);
+      H22 = GN_PK(dd, S22, H22);
+      const v2f N00 = yn * S02, N01 = GN_PK(-xn, S02, S00), N02 = -(yn * S00);
+      const v2f N10 = GN_PK(yn, S12, -S11), N11 = -(xn * S12), N12 = xn * S11;
+      const v2f N20 = GN_PK(yn, S22, -S12), N21 = GN_PK(-xn, S22, S02), N22 = GN_PK(xn, S12, -N00);
+      H03 = GN_PK(d, N00, H03); H04 = GN_PK(d, N01, H04); H05 = GN_PK(d, N02, H05);
+      H13 = GN_PK(d, N10, H13); H14 = GN_PK(d, N11, H14); H15 = GN_PK(d, N12, H15);
+      H23 = GN_PK(d, N20, H23); H24 = GN_PK(d, N21, H24); H25 = GN_PK(d, N22, H25);
+      H33 = GN_PK(yn, N20, H33) - N10; H34 = GN_PK(yn, N21, H34) - N11; H35 = GN_PK(yn, N22, H35) - N12;
+      H44 = GN_PK(-xn, N21, H44) + N01; H45 = GN_PK(-xn, N22, H45) + N02;
+      H55 = GN_PK(xn, N12, GN_PK(-yn, N02, H55));
+      b0 = GN_PK(d, g0, b0); b1 = GN_PK(d, g1, b1); b2 = GN_PK(d, g2, b2);
+      b3 = GN_PK(yn, g2, b3) - g1; b4 = GN_PK(-xn, g2, b4) + g0; b5 = GN_PK(xn, g1, GN_PK(-yn, g0, b5));
+    }
+  }
+#undef BC
+#define S2(v) ((v).x + (v).y)
+  const float Hs[27] = {S2(H00), 0.f, S2(H02), S2(H03), S2(H04), S2(H05), S2(H11), S2(H12), S2(H13), S2(H14), S2(H15),
+                        S2(H22), S2(H23), S2(H24), S2(H25), S2(H33), S2(H34), S2(H35), S2(H44), S2(H45), S2(H55),
+                        S2(b0), S2(b1), S2(b2), S2(b3), S2(b4), S2(b5)};
+#undef S2
+  float* pp = part + (((size_t)b * ntiles + tile) * gmax + g) * 27 * 64 + lane;
+  __syncthreads();  // every wave is done with the embedding image before the reduction re-uses its LDS
+#pragma unroll
+  for (int w_ = 0; w_ < GN_WAVES; ++w_) {  // (same one-image reduction in wave order as se3_gn_build_kernel<false>)
+    if (wave == w_) {
+#pragma unroll
+      for (int k = 0; k < 27; ++k) red[k][lane] = w_ == 0 ? Hs[k] : red[k][lane] + Hs[k];
+    }
+    __syncthreads();
+  }
+  for (int k = wave; k < 27; k += GN_WAVES) pp[k * 64] = red[k][lane];
+}
+
+
 #ifndef GN_CH2
 #define GN_CH2 8
 #endif
@@ -1461,6 +1601,13 @@ static inline bool gn_two_pass() {
   static const bool f = getenv("CODD_GN_TWO_PASS") && atoi(getenv("CODD_GN_TWO_PASS")) == 1;
   return f;
 }
+static inline bool gn_ailds() {
+  // ON since round 5 (same bits as se3_gn_build3_kernel; stand-alone the same 120 us per step, in the frame +0.6 %: at 125
+  // registers three builder waves leave a SIMD room for a wave of the co-scheduled z|r convolution, at 157 they do not --
+  // profiles/r05_gn_ailds_ab.log); CODD_GN_AILDS=0 = the register form
+  static const bool f = !(getenv("CODD_GN_AILDS") && atoi(getenv("CODD_GN_AILDS")) == 0);
+  return f;
+}
 static inline bool gn_pair() {
   // 1 (default) = se3_gn_build3_kernel: two neighbours per step in packed fp32, factored normal equations; 0 = the
   // J-entry builder se3_gn_build_kernel<false> (A/B: DESIGN finding 45)
@@ -1488,6 +1635,9 @@ static int gn_build_solve(float* T, int B, int h, int w, float fx, float fy, flo
   }
   if (gn_pair() && !gn_mfma() && gn_two_pass())
     se3_gn_build4_kernel<<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, s>>>(T, jd, Hb + gn_geo2_offset(B, h, w, radius), h, w, fx, fy,
+                                                                        cx, cy, radius, tiles_x, ntiles, q4, gmax, part);
+  else if (gn_pair() && !gn_mfma() && gn_ailds())
+    se3_gn_build5_kernel<<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, s>>>(T, jd, Hb + gn_geo2_offset(B, h, w, radius), h, w, fx, fy,
                                                                         cx, cy, radius, tiles_x, ntiles, q4, gmax, part);
   else if (gn_pair() && !gn_mfma())
     se3_gn_build3_kernel<<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, s>>>(T, jd, Hb + gn_geo2_offset(B, h, w, radius), h, w, fx, fy,

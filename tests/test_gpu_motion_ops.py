@@ -1104,6 +1104,41 @@ torch.save(Tg.cpu(), sys.argv[1])
     assert err < 1e-4 * max(1.0, step)
 
 
+def test_se3_gn_pair_builder_with_embedding_in_lds_is_bit_identical():
+    """se3_gn_build5_kernel (CODD_GN_AILDS=1: the pixel's own embedding read from LDS instead of 32 registers, four waves per
+    SIMD) issues the pair builder's instructions on the same values in the same order: torch.equal on the updated field."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+from codd_amd import ops
+g = torch.Generator().manual_seed(5)
+B, h, w = 2, 37, 61
+T = torch.zeros(B, h, w, 7); T[..., 6] = 1; T[..., :3] = torch.randn(B, h, w, 3, generator=g) * 0.02
+d1 = torch.rand(B, h, w, generator=g) * 30 + 3
+ae = torch.randn(B, 32, h, w, generator=g) * 3
+xyz = torch.rand(B, h, w, 3, generator=g) * 40
+delta = torch.randn(B, 3, h, w, generator=g) * 0.2
+wgt = torch.sigmoid(torch.randn(B, 3, h, w, generator=g))
+Tg = T.cuda()
+for _ in range(2):
+    ops.se3_gn_step(Tg, ae.cuda(), xyz.cuda(), delta.cuda(), wgt.cuda(), d1.cuda(), [40.0, 42.0, w / 2.0, h / 2.0], radius=32)
+torch.save(Tg.cpu(), sys.argv[1])
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("0", "1"):
+        path = os.path.join(root, "gpurun_out", f"_gn_ailds_{flag}.pt")
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        subprocess.run([sys.executable, "-c", code, path], cwd=root, env=dict(os.environ, CODD_GN_PAIR="1", CODD_GN_AILDS=flag), check=True, timeout=300)
+        outs.append(torch.load(path))
+        os.remove(path)
+    assert torch.isfinite(outs[0]).all() and (outs[0][..., :3].abs().max().item() > 1e-3)
+    assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max().item()
+
+
 def test_resize_bilinear_add_equals_two_launches():
     """codd_resize_bilinear_add (the '+ x_i' term of an HRModule fuse layer folded into the neighbouring up-sampling
     term) against the two launches it replaces (add_relu, then resize_bilinear with accumulate): the same bits."""
