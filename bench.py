@@ -37,6 +37,13 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _loaded_library():
+    """the libcodd_hip.so this process loaded, relative to the repo when it is the in-tree one (CODD_LIB_AB)"""
+    from codd_amd import _abi
+    p = _abi.LOADED or ""
+    return os.path.relpath(p, ROOT) if p.startswith(ROOT + os.sep) else p
 sys.path.insert(0, ROOT)
 
 RAW_H, RAW_W = 540, 960
@@ -127,11 +134,6 @@ def parse():
     ap.add_argument("--no-autotune", action="store_true",
                     help="use the heuristic conv launch configurations instead of timing the alternatives once per "
                          "layer shape during the (untimed) first frames")
-    ap.add_argument("--frame-pipeline", type=int, default=0, choices=[0, 1],
-                    help="1: codd_amd.runtime.PipelinedRunner -- frame t+1's image-only work (stereo network, "
-                         "RAFT3D encoders) overlaps frame t's motion + fusion inside one graph (same results, one "
-                         "frame of latency; measured 82.0 vs 83.1 frames/s in round 2 (DESIGN.md finding 15): the CUs are already saturated by the "
-                         "intra-frame side streams); 0 (default): one frame at a time (FrameRunner)")
     ap.add_argument("--serial-streams", action="store_true",
                     help="disable the fork/join side streams (every launch on one stream) -- used for the "
                          "rocprofv3 run whose per-kernel averages are compared with the roofline numbers")
@@ -146,13 +148,11 @@ def self_launch(args):
     ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N`` (one rank per GPU, rendezvous on 127.0.0.1 and a
     free port) -- what the reference's scripts/inference_dist.sh:11-12 does for inference.py:88,130-135 -- and pass the
     children's stdout (rank 0's single JSON line) and exit code through."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: torchrun's own c10d rendezvous on a port IT picks and holds (no bind-close-reuse race with another job
+    # on the box, ADVICE r5); --local-addr: the container's hostname may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", os.path.abspath(__file__)] + sys.argv[1:]
     log("self-launch: " + " ".join(cmd))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     return subprocess.call(cmd, env=env)
@@ -211,19 +211,6 @@ def conv_roofline(runner, frames, device):
                      p.terms if p.layout == 2 else 0))
         return rc
 
-    orig_chain = ops._launch_chain
-
-    def timed_chain(lib, p, stream):  # LDS-resident chain: algorithmic FLOPs of its layers (the halo recompute is not counted)
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record(torch.cuda.current_stream(device))
-        rc = orig_chain(lib, p, stream)
-        e.record(torch.cuda.current_stream(device))
-        fl = sum(2.0 * p.layer[i].cin * (p.cout_store if i == p.nlayers - 1 else p.layer[i].cout) * p.layer[i].k ** 2
-                 for i in range(p.nlayers)) * p.H * p.W * p.B
-        recs.append((s, e, fl, (p.B, p.C0 + p.C1, p.cout_store, p.layer[0].k, -p.nlayers, p.H, p.W, 1, 0), 0))
-        chains.append(p.nlayers)
-        return rc
-
     orig_roll = ops._launch_roll
 
     def timed_roll(lib, p, stream):  # rolling-window launch (one or two layers): algorithmic FLOPs of its layers
@@ -255,8 +242,6 @@ def conv_roofline(runner, frames, device):
     ops._launch_roll = timed_roll
     multis = []
     ops._launch_conv_multi = timed_multi
-    chains = []
-    ops._launch_chain = timed_chain
     ops._launch_conv = timed
     serial_before = ops.Fork.serial
     ops.Fork.serial = True  # one launch at a time, so that every event pair brackets exactly one kernel
@@ -283,7 +268,6 @@ def conv_roofline(runner, frames, device):
         torch.cuda.synchronize(device)
     finally:
         ops._launch_conv = orig
-        ops._launch_chain = orig_chain
         ops._launch_roll = orig_roll
         ops._launch_conv_multi = orig_multi
         ops.Fork.serial = serial_before
@@ -312,7 +296,7 @@ def conv_roofline(runner, frames, device):
             log("conv B%d Cin%-4d Cout%-4d k%dx%d out %3dx%-3d s%d m%d terms%d : n=%3d  %7.3f ms  %6.1f us/launch  %5.1f TF"
                 % (*key, n, ms, ms / n * 1e3, f / ms / 1e9))
     return dict(launches=len(recs), time_ms=t_ms, gflop=flops / 1e9, hbm=hbm,
-                chain_launches=len(chains), chain_layers=sum(chains), roll_launches=len(rolls), roll_layers=sum(rolls), multi_launches=len(multis), multi_jobs=sum(multis),
+                roll_launches=len(rolls), roll_layers=sum(rolls), multi_launches=len(multis), multi_jobs=sum(multis),
                 families={k: dict(launches=v[0], ms=round(v[1], 3), gflop=round(v[2] / 1e9, 2),
                                   issued_gflop=round(v[3] / 1e9, 2)) for k, v in fam.items()})
 
@@ -504,7 +488,7 @@ def main():
     pin_rank_to_cores(local, max(world, int(os.environ.get("LOCAL_WORLD_SIZE", world))))
 
     from codd_amd import metrics, synth
-    from codd_amd.runtime import FrameRunner, PipelinedRunner
+    from codd_amd.runtime import FrameRunner
 
     from codd_amd import ops as _ops_tune
     # shipped = codd_amd/tuned/mi355x.json: launch configurations found by the autotuner on an MI355X for the layer
@@ -524,19 +508,12 @@ def main():
     img, r_img, gt = img.to(device), r_img.to(device), gt.to(device)
     raw_h, raw_w = (RAW_H, RAW_W) if (H, W) == (PAD_H, PAD_W) else (H, W)
     metas = synth.default_metas(H, W, img_shape=(raw_h, raw_w, 3))
-    pipelined = bool(args.frame_pipeline) and not args.stereo_only and not args.serial_streams
-    if pipelined:
-        runner = PipelinedRunner(est, metas[0], use_graph=not args.no_graph)
-        # push(frame k) completes frame k-1: every timed step still finishes exactly one frame
-        step = runner.push
-    else:
-        runner = FrameRunner(est, metas[0], use_graph=not args.no_graph)
-        step = runner.step
-    lag = 1 if pipelined else 0  # the disparity returned at step i belongs to frame i - lag
+    runner = FrameRunner(est, metas[0], use_graph=not args.no_graph)
+    step = runner.step
 
     def frame(i):
         k = i % MF
-        return img[:, k].contiguous(), r_img[:, k].contiguous(), gt[:, (i - lag) % MF]
+        return img[:, k].contiguous(), r_img[:, k].contiguous(), gt[:, k]
 
     # frame 0 primes the recurrent state; then W untimed warm-up frames (graph capture happens here)
     log("model built, inputs resident")
@@ -583,12 +560,7 @@ def main():
     if rank == 0:
         try:
             l, r, _ = frame(1)
-            rr = runner
-            if pipelined:  # per-launch timing uses the one-frame-at-a-time runner (eager, serial streams)
-                rr = FrameRunner(est, metas[0], use_graph=False)
-                for i in range(2):
-                    rr.step(*frame(i)[:2])
-            cr = conv_roofline(rr, (l, r), device)
+            cr = conv_roofline(runner, (l, r), device)
             fams = cr["families"]
             # dominant family = where the frame's MFMA work is (the eager event brackets of this pass over-count the
             # launch-bound small fp32 layers: ~8 us of host launch gap each; profiles/r0N_kernel_stats_serial.md hold the rocprofv3 durations of every round)
@@ -626,7 +598,7 @@ def main():
                         launches_per_frame=fd["launches"], ms_per_frame=fd["ms"],
                         algorithmic_frac_of_fp32_matrix_peak=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4),
                         families=fams, conv_launches_per_frame=cr["launches"],
-                        chain_launches_per_frame=cr["chain_launches"], conv_layers_inside_chains=cr["chain_layers"],
+                        
                         rolling_window_launches_per_frame=cr["roll_launches"], conv_layers_inside_rolling_launches=cr["roll_layers"],
                         multi_job_launches_per_frame=cr["multi_launches"], convs_inside_multi_job_launches=cr["multi_jobs"], conv_gflop_per_frame=round(cr["gflop"], 2),
                         conv_ms_per_frame=round(cr["time_ms"], 3),
@@ -638,7 +610,7 @@ def main():
         except Exception as e:  # pragma: no cover
             roof = dict(error=repr(e))
         log(f"roofline pass done: {roof}")
-        if world == 1 and args.precision in ("split", "split16") and args.fp32_steps > 0 and not args.stereo_only and not pipelined:
+        if world == 1 and args.precision in ("split", "split16") and args.fp32_steps > 0 and not args.stereo_only:
             # secondary figure: the same frame with every convolution on the exact-fp32 MFMA kernels (own graph)
             try:
                 prev = _ops_tune.set_conv_precision("fp32")
@@ -657,7 +629,7 @@ def main():
             finally:
                 _ops_tune.set_conv_precision(prev)
             log(f"fp32-exact pass done: {fp32_fps}")
-        if world == 1 and args.two_video_steps > 0 and not args.stereo_only and not pipelined and not args.no_graph:
+        if world == 1 and args.two_video_steps > 0 and not args.stereo_only and not args.no_graph:
             # throughput headroom, reported BESIDE the headline (one video per GPU): two independent videos resident on
             # this GPU -- two model replicas (own persistent buffers), two captured frame graphs replayed on two streams
             try:
@@ -738,9 +710,8 @@ def main():
                                          "first frames, %d moved off the heuristic)" % (
                                              len(_ops_tune.TUNE_DB), len(_ops_tune.AUTOTUNE_LOG),
                                              sum(1 for r in _ops_tune.AUTOTUNE_LOG if r[1] != r[3]))),
-                       "frame_pipeline": ("depth 2: stereo/encoders of frame t+1 overlap motion+fusion of frame t "
-                                          "(identical outputs, +1 frame latency)" if pipelined else "off"),
                        "fps_per_gpu": round(fps / world, 3),
+                       "library": _loaded_library(),
                        "ranks_seen": ranks_seen, "frames_timed_all_ranks": sum(r[2] for r in ranks_seen)},
             "epe_vs_synthetic_gt": red["epe"][0],
             # every convolution on the exact-fp32 kernels (--precision fp32), same frame, shorter run

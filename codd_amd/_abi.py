@@ -14,10 +14,6 @@ class View(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("ctot", C.c_int), ("coff", C.c_int)]
 
 
-class HrTerm(C.Structure):
-    _fields_ = [("ptr", C.c_void_p), ("h", C.c_int), ("w", C.c_int)]
-
-
 class XsView(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("c8", C.c_int), ("hp", C.c_int), ("wp", C.c_int), ("bt", C.c_int),
                 ("bl", C.c_int), ("o8", C.c_int), ("terms", C.c_int)]
@@ -44,20 +40,6 @@ class ConvParams(C.Structure):
 
 ACT = dict(none=0, lrelu=1, relu=2, sigmoid=3, tanh=4, mish=5, relu_ch0=6)
 
-CHAIN_MAX_LAYERS = 12
-
-
-class ChainLayer(C.Structure):
-    _fields_ = [("cin", C.c_int), ("cout", C.c_int), ("k", C.c_int), ("dil", C.c_int), ("act", C.c_int),
-                ("src", C.c_int), ("dst", C.c_int), ("res", C.c_int), ("wofs", C.c_longlong)]
-
-
-class ChainParams(C.Structure):
-    _fields_ = [("in0", View), ("in1", View), ("C0", C.c_int), ("C1", C.c_int),
-                ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("nlayers", C.c_int), ("stage", C.c_int),
-                ("layer", ChainLayer * CHAIN_MAX_LAYERS), ("wpacked", C.c_void_p), ("res1", View),
-                ("out", C.c_void_p), ("out_ctot", C.c_int), ("out_coff", C.c_int), ("cout_store", C.c_int),
-                ("th", C.c_int), ("tw", C.c_int)]
 
 
 
@@ -78,10 +60,6 @@ SIGNATURES = {
     "codd_conv2d": (_i, [C.POINTER(ConvParams), _p]),
     "codd_conv2d_check": (_i, [C.POINTER(ConvParams)]),
     "codd_conv2d_multi": (_i, [C.POINTER(ConvParams), _i, _p]),
-    "codd_chain_layer_size": (_ll, [_i, _i, _i]),
-    "codd_chain_pack_layer": (_i, [_p, _p, _i, _i, _i, _p, _p]),
-    "codd_conv_chain_check": (_i, [C.POINTER(ChainParams)]),
-    "codd_conv_chain": (_i, [C.POINTER(ChainParams), _p]),
     "codd_roll_packed_size": (_ll, [_i, _i, _i]),
     "codd_roll_pack_weights": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "codd_conv_roll": (_i, [C.POINTER(RollParams), _p]),
@@ -104,6 +82,8 @@ SIGNATURES = {
     "codd_raft_geometry": (_i, [_p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _p, _p, _p]),
     "codd_se3_gn_step": (_i, [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f, _p, _p]),
     "codd_se3_gn_scratch": (_ll, [_i, _i, _i, _i]),
+    "codd_set_option": (_i, [_i, _i]),
+    "codd_get_option": (_i, [_i]),
     "codd_se3_gn_step_heads": (_i, [_p, XsView, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _f, _i, _f, _f, _p, _p, _p]),
     "codd_cvx_upsample": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p]),
     "codd_cvx_upsample_se3_weight": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p]),
@@ -115,7 +95,6 @@ SIGNATURES = {
     "codd_resize_bilinear": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p]),
     "codd_resize_bilinear_add": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _p]),
     "codd_add_relu": (_i, [_p, _p, _ll, _i, _p, _p]),
-    "codd_hr_fuse_sum": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _p]),
     "codd_copy_many": (_i, [_p, _p, _p, _i, _p]),
     "codd_timestamp": (_i, [_p, _p]),
     "codd_gru_gate_zr": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p, _p, _p]),
@@ -142,8 +121,9 @@ SIGNATURES = {
     "codd_fusion_blend": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
 }
 
-ABI_VERSION = 11  # CODD_ABI_VERSION of include/codd_hip.h
+ABI_VERSION = 12  # CODD_ABI_VERSION of include/codd_hip.h
 _lib = None
+LOADED = None  # path of the library this process loaded
 MISSING = []
 
 
@@ -152,13 +132,21 @@ class CoddHipError(RuntimeError):
 
 
 def lib_path():
-    # CODD_LIB_AB (dev, same-lease A/B of two builds of the library): load this prebuilt libcodd_hip.so instead of the in-tree one
-    return os.environ.get("CODD_LIB_AB") or _build.LIB
+    """The library this process loads.  CODD_LIB_AB (dev, same-lease A/B of two builds: tools/ab_lib.sh) names a PREBUILT
+    libcodd_hip.so that is loaded instead of the in-tree one WITHOUT the missing-or-stale rebuild check -- only its ABI
+    version is compared -- so its use is announced on stderr and bench.py records the path in its JSON line."""
+    ab = os.environ.get("CODD_LIB_AB")
+    if ab:
+        import sys
+        print(f"codd_amd: WARNING: CODD_LIB_AB is set -- loading the prebuilt {ab} instead of the in-tree library; it is NOT "
+              f"checked against the sources of this tree", file=sys.stderr, flush=True)
+        return ab
+    return _build.LIB
 
 
 def load():
     """Load (building if the sources are newer) libcodd_hip.so; raises if unavailable."""
-    global _lib
+    global _lib, LOADED
     if _lib is not None:
         return _lib
     path = lib_path()
@@ -195,8 +183,19 @@ def load():
         fn.argtypes = args
     if lib.codd_abi_version() != ABI_VERSION:
         raise CoddHipError("ABI version mismatch")
-    _lib = lib
+    _lib, LOADED = lib, path
     return lib
+
+
+OPTIONS = dict(gn_q4=0, gn_builder=1)  # CODD_OPT_* of include/codd_hip.h
+
+
+def set_option(name, value):
+    """codd_set_option: the library's only process-wide state (defaults = the shipped configuration).  Returns the previous value."""
+    rc = load().codd_set_option(OPTIONS[name], int(value))
+    if rc < 0:
+        raise CoddHipError(f"codd_set_option({name}, {value}) rejected")
+    return rc
 
 
 def check(rc, what):

@@ -13,6 +13,8 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+int codd_opt(int key);  // current value of a CODD_OPT_* option (stereo.hip)
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 __device__ __forceinline__ float act_apply(float v, int act, int co) {

@@ -12,14 +12,13 @@
 // channels and the matching weight chunk are staged in LDS per chunk; channel stride of the
 // LDS image is padded to 16 (mod 32) floats so that the two ci-groups of a 32-lane half hit
 // disjoint banks.
-#include "conv_quad_persist.h"
+#include "conv_quad_kernel.h"
 #include <stdio.h>
 #include <stdlib.h>
 
 CONV_ALL_GROUPS(CONV_DECLARE)
 CONVQ_ALL(CONVQ_DECLARE)
 CONVQ_MULTI(CONVQM_DECLARE)
-CONVQP_ALL(CONVQP_DECLARE)
 
 
 __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int ntaps,
@@ -104,13 +103,6 @@ static int launch_conv(const ConvK& k, size_t lds, int grid, hipStream_t s) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  static const bool debug = getenv("CODD_CONV_DEBUG") != nullptr;  // dev aid: resident workgroups per CU
-  if (debug) {
-    int nb = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)conv_mfma_kernel<NW, NPB, MB, WREG, IREG>, NW * 64, lds);
-    fprintf(stderr, "conv<%d,%d,%d,%d,%d> grid %d lds %zu ck %d: %d workgroups/CU\n", NW, NPB, MB, WREG, IREG, grid, lds,
-            k.p.ck, nb);
-  }
   conv_mfma_kernel<NW, NPB, MB, WREG, IREG><<<grid, NW * 64, lds, s>>>(k);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
@@ -164,39 +156,6 @@ static int launch_quad_any(const ConvK& k, int nw, size_t lds, int grid, hipStre
   return CODD_EUNSUPPORTED;
 }
 
-template <int NPB, int MB, int WREG, int QREG>
-static int launch_qp(const ConvK& k, size_t lds, int ntiles, hipStream_t s) {
-  auto kern = conv_quad_persist_kernel<NPB, MB, WREG, QREG>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-  }
-  // grid = the workgroups the chip keeps resident (LDS, registers, 32 waves per CU), every one walks its share of the tiles
-  static size_t cached_lds = 0;  // (per instantiation; the occupancy query is a host call worth caching)
-  static int cached_per_cu = 0;
-  if (cached_per_cu == 0 || cached_lds != lds) {
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    cached_per_cu = per_cu;
-    cached_lds = lds;
-  }
-  int grid = 256 * cached_per_cu;
-  if (grid > ntiles) grid = ntiles;
-  kern<<<grid, 256, lds, s>>>(k, ntiles);
-  CODD_LAUNCH_CHECK();
-  return CODD_OK;
-}
-
-// layout 3: persistent quad-layout kernel (conv_quad_persist.h)
-static int launch_quad_persist(const ConvK& k, size_t lds, int ntiles, hipStream_t s) {
-  const codd_conv_params& p = k.p;
-  const int wr = cdiv(k.wchunk >> 2, 256), qr = cdiv((p.ck >> 2) * k.upc, 256);
-#define QP(N, M, R, QQ) if (p.npb == N && p.mb == M && wr <= R && qr <= QQ) return launch_qp<N, M, R, QQ>(k, lds, ntiles, s);
-  CONVQP_ALL(QP)
-#undef QP
-  return CODD_EUNSUPPORTED;
-}
-
 /* staging limits the host heuristics must respect: <= 16 float4 of weights and <= 8 float4 of input
  * per thread and chunk (codd_conv2d returns CODD_EUNSUPPORTED otherwise) */
 int codd_conv2d_bf16(const codd_conv_params* pp, void* stream, int dry_run);  // conv_bf16.hip
@@ -243,10 +202,8 @@ static int conv_fill(const codd_conv_params* pp, ConvK& k, size_t& lds, long lon
   k.vec_ok = (p.Win % 4 == 0) && ((uintptr_t)p.in0.ptr % 16 == 0) && (hwb % 16 == 0) &&
              (p.C1 == 0 || (uintptr_t)p.in1.ptr % 16 == 0);
   lds = ((size_t)k.wchunk + (size_t)p.ck * k.chs) * sizeof(float);
-  if (p.layout == 1 || p.layout == 3) {  // quad layout: unpadded weights, input tile [cq][y][x][4]
+  if (p.layout == 1) {  // quad layout: unpadded weights, input tile [cq][y][x][4]
     if (!(p.ck == 16 || p.ck == 32) || p.sx > 2 || !k.vec_ok) return CODD_EUNSUPPORTED;
-    if (p.layout == 3 && (k.nchunks != 1 || cdiv(p.store_mode ? 4 * p.Cout : p.Cout, 16 * p.mb) != 1 || nw != 4 || p.mb > 2))
-      return CODD_EUNSUPPORTED;  // persistent variant: the whole weight tensor is one chunk and one channel group
     k.wchunk = k.ntaps * p.ck * 16 * p.mb;
     lds = ((size_t)k.wchunk + (size_t)p.ck * k.thi * k.twp) * sizeof(float);
   } else if (p.layout != 0) {
@@ -255,11 +212,10 @@ static int conv_fill(const codd_conv_params* pp, ConvK& k, size_t& lds, long lon
   if (lds > 160 * 1024) return CODD_EUNSUPPORTED;
   grid = (long long)k.tiles_x * k.tiles_y * k.ncog * p.B;
   if (grid <= 0 || grid > 0x7fffffffLL) return CODD_EINVAL;
-  // XCD-contiguous tile walk for launches of several rounds (the large HITNet maps): dev switch CODD_CONV_XCD=0|1,
-  // minimum grid CODD_CONV_XCD_MIN
-  static const int xcd_on = getenv("CODD_CONV_XCD") ? atoi(getenv("CODD_CONV_XCD")) : 1;
-  static const int xcd_min = getenv("CODD_CONV_XCD_MIN") ? atoi(getenv("CODD_CONV_XCD_MIN")) : 1;
-  k.xcd = xcd_on && grid >= xcd_min;
+  // XCD-contiguous tile walk (conv_kernel.h conv_xcd_item): neighbouring tiles share halo rows and all weights, and the
+  // dispatcher places workgroup b on XCD b % 8 -- measured +0.9 % on the frame, 2 x 60 -> 35 MB fetched per full-resolution
+  // 16-channel HITNet layer (DESIGN.md finding 31)
+  k.xcd = 1;
   return CODD_OK;
 }
 
@@ -283,7 +239,6 @@ extern "C" int codd_conv2d(const codd_conv_params* pp, void* stream) {
   const codd_conv_params& p = k.p;
   hipStream_t s = (hipStream_t)stream;
   if (p.layout == 1) return launch_quad_any(k, nw, lds, (int)grid, s);
-  if (p.layout == 3) return launch_quad_persist(k, lds, (int)grid, s);
 #define CASEW(W, M) if (nw == W && p.mb == M) return launch_conv_nwx<W, M>(k, lds, (int)grid, s)
   CASEW(9, 1); CASEW(9, 2); CASEW(9, 4); CASEW(2, 1); CASEW(2, 2); CASEW(2, 4); CASEW(8, 1); CASEW(8, 2); CASEW(8, 4);
 #undef CASEW
@@ -349,16 +304,8 @@ extern "C" int codd_conv2d_multi(const codd_conv_params* ps, int n, void* stream
 // ------------------------------------------------------------------------------------------------
 extern "C" int codd_avgpool2(const float* in, int BC, int h, int w, float* out, void* stream);
 
-static int corr_mb() {  // 16-channel blocks per workgroup of the all-pairs GEMM (dev override: CODD_CORR_MB)
-  static const int v = getenv("CODD_CORR_MB") ? atoi(getenv("CODD_CORR_MB")) : 4;
-  return v;
-}
-#define CORR_MB corr_mb()
-static int corr_ck() {  // chunk depth of the all-pairs GEMM (dev override: CODD_CORR_CK)
-  static const int v = getenv("CODD_CORR_CK") ? atoi(getenv("CODD_CORR_CK")) : 32;
-  return v;
-}
-#define CORR_CK corr_ck()
+#define CORR_MB 4   // 16-channel blocks per workgroup of the all-pairs GEMM
+#define CORR_CK 32  // its chunk depth
 extern "C" long long codd_allpairs_corr_scratch(int B, int D, int h, int w) {
   long long packed = codd_conv2d_packed_size(h * w, D, 1, 1, CORR_MB, CORR_CK);
   long long pooled = 0;
@@ -402,12 +349,6 @@ extern "C" int codd_allpairs_corr(const float* f1, const float* f2, int B, int D
       p.kh = p.kw = 1; p.sy = p.sx = 1; p.dil_y = p.dil_x = 1;
       p.act = CODD_ACT_NONE; p.mb = CORR_MB; p.ck = CORR_CK;
       p.npb = 1;  // measured: 4x16-pixel tiles 559 us vs 890 us with 8x32 tiles for the whole pyramid
-      {  // dev overrides for experiments: CODD_CORR_NPB / CODD_CORR_NW (level 0 only)
-        static const int env_npb = getenv("CODD_CORR_NPB") ? atoi(getenv("CODD_CORR_NPB")) : 0;
-        static const int env_nw = getenv("CODD_CORR_NW") ? atoi(getenv("CODD_CORR_NW")) : 0;
-        if (i == 0 && env_npb) p.npb = env_npb;
-        if (i == 0 && env_nw) p.nw = env_nw;
-      }
       int rc = codd_conv2d(&p, stream);
       if (rc) return rc;
     }

@@ -58,9 +58,6 @@ struct ConvB {
   int wslots;                     // slots of one (channel group, chunk) weight image = planes * wplane16
   int tiles_x, tiles_y, ncog, cout_eff;
   int khe;                        // tap rows of one tap set (kh, or kh / 2 with a dual tap set)
-  int gpf;                        // gate epilogues: 1 = prefetch the channel-quad operands per pixel unit (A/B: CODD_GATE_PREFETCH)
-  int xcd;                        // 1: XCD-contiguous work-item walk (workgroup b, placed on XCD b % 8, takes a
-                                  // contiguous range of tiles of one channel group: conv_kernel.h conv_xcd_item)
   // magic multipliers ceil(2^32 / d) of the producers' prologue divisions (convb_div; exact for the < 2^16 operands of
   // the slot / entry arithmetic): a 32-bit udiv is ~35 VALU instructions, and 20 of them stood between the start of a
   // producer wave and its first LDS-DMA -- ~1.2 us of every launch's exposed ring fill (round 5)
@@ -123,11 +120,8 @@ static inline int convb_geometry(const codd_conv_params* pp, ConvB& k, size_t& l
   // ring of (weights + input) buffers + entry table: three deep when that fits the 160 KiB of a CU, else two
   const size_t per = ((size_t)k.wslots + (size_t)k.ibuf16) * 16, tab = ((size_t)k.nk + 2) * 16;
   k.nring = (k.nchunks >= 3 && 3 * per + tab <= 160 * 1024) ? 3 : 2;
-  {  // dev experiment: a two-deep ring where that lets TWO 8-wave workgroups share a CU
-    static const int ring2 = getenv("CODD_CONVB_RING2") ? atoi(getenv("CODD_CONVB_RING2")) : 0;
-    if (ring2 && k.nring == 3 && (p.pgw * p.cgw * (p.ksplit == 2 ? 2 : 1) + CONVB_NWP) <= 8 && 2 * (2 * per + tab) <= 160 * 1024)
-      k.nring = 2;
-  }
+  // (a two-deep ring where that lets TWO 8-wave workgroups share a CU: +3 % per layer stand-alone in round 3, 101.8 / 101.6
+  // against 101.6 / 101.7 frames/s in round 6's same-lease A/B, profiles/r06_ab_hr_fuse_ring2.log -- not kept)
   lds = k.nring * per + tab;
   if (lds > 160 * 1024) return CODD_EUNSUPPORTED;
   if (p.ksplit < 0 || p.ksplit > 2) return CODD_EINVAL;
@@ -171,17 +165,8 @@ static inline int convb_geometry(const codd_conv_params* pp, ConvB& k, size_t& l
   }
   grid = (long long)k.tiles_x * k.tiles_y * k.ncog * p.B;
   if (grid <= 0 || grid > 0x7fffffffLL) return CODD_EINVAL;
-  {  // dev switch CODD_CONVB_XCD=0|1 (minimum grid CODD_CONVB_XCD_MIN)
-    static const int xcd_on = getenv("CODD_CONVB_XCD") ? atoi(getenv("CODD_CONVB_XCD")) : 0;
-    static const int xcd_min = getenv("CODD_CONVB_XCD_MIN") ? atoi(getenv("CODD_CONVB_XCD_MIN")) : 16;
-    {
-      // (dev A/B, OFF: 95.9 against 95.9 frames/s in one session -- the gate operands' latency is not what the
-      // 28 us of the gate-input convolution are made of)
-      static const int gpf = getenv("CODD_GATE_PREFETCH") ? atoi(getenv("CODD_GATE_PREFETCH")) : 0;
-      k.gpf = gpf;
-    }
-    k.xcd = grid >= xcd_min ? xcd_on : 0;  // bit 0: XCD-contiguous walk, bit 1: channel group fastest
-  }
+  // (an XCD-contiguous work-item walk LOSES 3 % on this family: its 240-workgroup update-block launches are one dispatch
+  // round whose workgroups of one channel group then start in lock-step on one XCD -- DESIGN.md finding 31)
   return CODD_OK;
 }
 
@@ -260,22 +245,10 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   int bid = blockIdx.x;
-  if (k.xcd & 1) {  // consecutive work items on ONE XCD (workgroup b runs on XCD b % 8)
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int tx, ty, cog, b;
-  if (k.xcd & 2) {  // channel group fastest: the channel groups of one tile are neighbours (one XCD under the XCD walk)
-    cog = bid % k.ncog; bid /= k.ncog;
-    tx = bid % k.tiles_x; bid /= k.tiles_x;
-    ty = bid % k.tiles_y;
-    b = bid / k.tiles_y;
-  } else {
-    tx = bid % k.tiles_x; bid /= k.tiles_x;
-    ty = bid % k.tiles_y; bid /= k.tiles_y;
-    cog = bid % k.ncog;
-    b = bid / k.ncog;
-  }
+  const int tx = bid % k.tiles_x; bid /= k.tiles_x;
+  const int ty = bid % k.tiles_y; bid /= k.tiles_y;
+  const int cog = bid % k.ncog;
+  const int b = bid / k.ncog;
 
   if (wave >= NWC) {
     // =============================== producers ===============================
@@ -527,36 +500,6 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
       const int oy = ty * k.th + prow;
       const int ox = tx * k.tw + (u - prow * k.xb) * 16 + j;
       const bool inb = u < k.pu && oy < p.Hout && ox < p.Wout;
-      // Gate epilogues (gate = 2 | 3): the channel-quad operands of this pixel unit's B tiles are requested together,
-      // in straight-line code with clamped (always valid) addresses -- 3 B 16-byte loads in flight, one exposed
-      // L2 / HBM latency per unit -- instead of load -> wait -> use per operand and tile.  (All A x B tiles at once
-      // costs 12 A B registers and the K loop its occupancy: 34.8 -> 40.8 us on the 5 x 2-tile configuration.)
-      f32x4 gt1[B], gt2[B], gt3[B];
-#pragma unroll
-      for (int m = 0; m < B; ++m) gt1[m] = gt2[m] = gt3[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (p.gate >= 2 && k.gpf) {
-        const int hw_ = p.Hout * p.Wout;
-        const int G = p.gate == 2 ? k.cout_eff / 3 : k.cout_eff;
-        const int pixc = min(oy, p.Hout - 1) * p.Wout + min(ox, p.Wout - 1);
-        auto c4p = [&](const float* base, int ctot, int c) {
-          return (const f32x4*)(base + (((size_t)b * (ctot >> 2) + (c >> 2)) * hw_ + pixc) * 4);
-        };
-#pragma unroll
-        for (int m = 0; m < B; ++m) {
-          if (KS == 2 && ((a * B + m) & 1) != kpart) continue;
-          const int co0 = min((cog * CGW * B + cgi * B + m) * 16 + 4 * g, k.cout_eff - 4);
-          const int ctile = co0 & ~15;  // (wave-uniform class of the tile)
-          if (p.gate == 2) {
-            gt1[m] = *c4p(p.res1.ptr, p.res1.ctot, p.res1.coff + co0);
-            if (ctile < 2 * G) gt2[m] = *c4p(p.res2.ptr, p.res2.ctot, p.res2.coff + co0);
-            if (ctile >= G && ctile < 2 * G) gt3[m] = *c4p(p.post.ptr, p.post.ctot, p.post.coff + co0 - G);
-          } else {
-            gt1[m] = *c4p(p.res1.ptr, p.res1.ctot, p.res1.coff + G + co0);
-            gt2[m] = *c4p(p.res1.ptr, p.res1.ctot, p.res1.coff + co0);
-            gt3[m] = *c4p(p.post.ptr, p.post.ctot, p.post.coff + co0);
-          }
-        }
-      }
 #pragma unroll
       for (int m = 0; m < B; ++m) {
         if (KS == 2 && ((a * B + m) & 1) != kpart) continue;  // the k-split partner's tile
@@ -584,26 +527,22 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
           }
           const int G = p.gate == 2 ? k.cout_eff / 3 : k.cout_eff;
           if (p.gate == 2) {
-            if (k.gpf) v += gt1[m];  // (operands prefetched above; dead lanes never store)
-            else if (live) v += *c4(p.res1.ptr, p.res1.ctot, p.res1.coff + co0);
+            if (live) v += *c4(p.res1.ptr, p.res1.ctot, p.res1.coff + co0);
             if (ctile >= 2 * G) {  // q's input stream
               if (live) *c4(p.out, p.out_ctot, p.out_coff + co0 - G) = v;
               continue;
             }
-            if (k.gpf) v += gt2[m];
-            else if (live) v += *c4(p.res2.ptr, p.res2.ctot, p.res2.coff + co0);
+            if (live) v += *c4(p.res2.ptr, p.res2.ctot, p.res2.coff + co0);
             v = convb_act_slow(v, CODD_ACT_SIGMOID);
             if (ctile < G) {  // z
               if (live) *c4(p.out, p.out_ctot, p.out_coff + co0) = v;
               continue;
             }
             rco = co0 - G;  // r * h -> records
-            if (k.gpf) v *= gt3[m];
-            else if (live) v *= *c4(p.post.ptr, p.post.ctot, p.post.coff + rco);
+            if (live) v *= *c4(p.post.ptr, p.post.ctot, p.post.coff + rco);
           } else {
-            f32x4 z = gt2[m], h = gt3[m];
-            if (k.gpf) v += gt1[m];
-            else if (live) {
+            f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f}, h = z;
+            if (live) {
               v += *c4(p.res1.ptr, p.res1.ctot, p.res1.coff + G + co0);
               z = *c4(p.res1.ptr, p.res1.ctot, p.res1.coff + co0);
               h = *c4(p.post.ptr, p.post.ctot, p.post.coff + co0);

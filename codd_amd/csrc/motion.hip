@@ -454,9 +454,6 @@ extern "C" int codd_raft_geometry(const float* T, const float* depth1, const flo
 #define GN_JS 44  // floats per neighbour record (16-byte aligned)
 #define GN_WAVES 4
 #define GN_SOLVE_WAVES 14  // 27 sums over 14 waves: <= 2 each
-// split-bf16 copy of ae_j / 8 for the MFMA builder (se3_gn_build2_kernel): per pixel [plane hi | lo][32 bf16] = 128 bytes
-// = 32 floats; hi = bf16_rne(v), lo = bf16_rne(v - hi) as everywhere else (common.h xs_store8)
-#define GN_AQ 32
 // the pair builder's second record image (se3_gn_build3_kernel): [b][y][x / 2][k = 0..11][x & 1], k = X (3), target in
 // normalised image coordinates ((u - cx) / fx, (v - cy) / fy) and inverse depth, weights (wx fx^2, wy fy^2, wz), |a|^2;
 // the phantom partner of the last pixel of an odd-width row is written as zeros (depth 0 = masked, finite)
@@ -483,8 +480,7 @@ static __device__ __forceinline__ void gn_geo2_store_a2(float* __restrict__ geo2
 __global__ void se3_gn_prep_kernel(const float* __restrict__ ae, int ae_c, const float* __restrict__ xyz,
                                    const float* __restrict__ delta, const float* __restrict__ wgt,
                                    const float* __restrict__ d1, int h, int w, float fx, float fy, float cx, float cy,
-                                   float* __restrict__ jd, int* __restrict__ cnt, int ntiles,
-                                   unsigned short* __restrict__ aeq, float* __restrict__ geo2) {
+                                   float* __restrict__ jd, int* __restrict__ cnt, int ntiles, float* __restrict__ geo2) {
   const int N = h * w;
   const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
   if (j < ntiles) cnt[b * ntiles + j] = 0;  // arrival counters of the builder launched next (ntiles <= N)
@@ -501,10 +497,6 @@ __global__ void se3_gn_prep_kernel(const float* __restrict__ ae, int ae_c, const
     const float v = av[c] * (c < ae_c ? 0.125f : 0.f);
     rp[c] = v;
     a2 += v * v;
-    const __bf16 hi = (__bf16)v, lo = (__bf16)(v - (float)hi);
-    unsigned short* q = aeq + ((size_t)b * N + j) * (2 * GN_AQ);
-    q[c] = __builtin_bit_cast(unsigned short, hi);
-    q[GN_AE + c] = __builtin_bit_cast(unsigned short, lo);
   }
   const V3 X = inv_project(d1[(size_t)b * N + j], xj, yj, fx, fy, cx, cy);
   const float* xb = xyz + ((size_t)b * N + j) * 3;
@@ -540,8 +532,7 @@ __global__ __launch_bounds__(128) void gn_heads_prep_kernel(const codd_xs_view h
                                                           const float* __restrict__ xyz, const float* __restrict__ d1,
                                                           int h, int w, float fx, float fy, float cx, float cy,
                                                           float* __restrict__ jd, float* __restrict__ wout,
-                                                          int* __restrict__ cnt, int ntiles,
-                                                          unsigned short* __restrict__ aeq, float* __restrict__ geo2) {
+                                                          int* __restrict__ cnt, int ntiles, float* __restrict__ geo2) {
   const int N = h * w;
   const int lane = threadIdx.x & 63, px = lane & 15, g = lane >> 4, b = blockIdx.y;
   const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -646,20 +637,7 @@ __global__ __launch_bounds__(128) void gn_heads_prep_kernel(const codd_xs_view h
       v[r] = (acc[t][r] + bias[16 * t + 4 * g + r]) * 0.125f;
       a2 += v[r] * v[r];
     }
-    if (ok) {
-      *(f32x4*)(rp + 16 * t + 4 * g) = v;
-      // split-bf16 planes of the same four dims (16 t + 4 g ..): 8 bytes per plane
-      unsigned short hq[4], lq[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const __bf16 hi = (__bf16)v[r], lo = (__bf16)(v[r] - (float)hi);
-        hq[r] = __builtin_bit_cast(unsigned short, hi);
-        lq[r] = __builtin_bit_cast(unsigned short, lo);
-      }
-      unsigned short* q = aeq + ((size_t)b * N + j) * (2 * GN_AQ) + 16 * t + 4 * g;
-      *(uint2*)q = uint2{(unsigned)hq[0] | ((unsigned)hq[1] << 16), (unsigned)hq[2] | ((unsigned)hq[3] << 16)};
-      *(uint2*)(q + GN_AE) = uint2{(unsigned)lq[0] | ((unsigned)lq[1] << 16), (unsigned)lq[2] | ((unsigned)lq[3] << 16)};
-    }
+    if (ok) *(f32x4*)(rp + 16 * t + 4 * g) = v;
   }
   a2 += __shfl_xor(a2, 16, 64);
   a2 += __shfl_xor(a2, 32, 64);
@@ -679,210 +657,6 @@ static __device__ __forceinline__ v2f GN_PK(v2f a, v2f b, v2f c) {  // -> v_pk_f
 static __host__ __device__ __forceinline__ int gn_groups(int nj, int q4, int gmax) {
   const int g = (nj + q4 / 2) / q4;
   return g < 1 ? 1 : (g > gmax ? gmax : g);
-}
-
-#ifdef GN_STATS
-__device__ unsigned long long gn_stats[2];
-extern "C" int codd_gn_stats(unsigned long long* out, int reset) {  // dev builds only (not part of the ABI)
-  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(gn_stats), 16) != hipSuccess) return CODD_EINVAL;
-  if (reset) { const unsigned long long z[2] = {0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(gn_stats), z, 16) != hipSuccess) return CODD_EINVAL; }
-  return CODD_OK;
-}
-#endif
-static __device__ __forceinline__ void gn_solve_tile(float* __restrict__ T, const float (*sums)[64], int lane, int b,
-                                                     int tx0, int ty0, int h, int w, float lm, float ep);
-// FUSE: the LAST workgroup of a tile to deliver its partial (device-scope counter cnt[b][tile], zeroed by the record
-// packing kernel of the same step) adds the tile's G partials in index order and solves -- no separate solve launch.
-// T is then read (every workgroup of the tile, before its partial is counted) and written (the last one) by this
-// kernel: only ever for the workgroup's own tile.
-template <bool FUSE>
-__global__ __launch_bounds__(64 * GN_WAVES) void se3_gn_build_kernel(
-    float* T, const float* __restrict__ jd, int h, int w, float fx, float fy, float cx, float cy,
-    int radius, int tiles_x, int ntiles, int q4, int gmax, float* part, int* cnt, float lm, float ep) {
-  __shared__ float red[FUSE ? GN_WAVES : 1][27][64];
-  __shared__ int s_last;
-  const int N = h * w;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tile = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
-  const int tx0 = (tile % tiles_x) * 8, ty0 = (tile / tiles_x) * 8;
-  // rows / columns of the tile's neighbourhood, clipped to the image (all wave-uniform)
-  const int ylo = max(ty0 - radius, 0), yhi = min(ty0 + 7 + radius, h - 1);
-  const int xlo = max(tx0 - radius, 0), xhi = min(tx0 + 7 + radius, w - 1);
-  const int ncols = xhi - xlo + 1, nj = (yhi - ylo + 1) * ncols;
-  const int G = gn_groups(nj, q4, gmax);
-  if (g >= G) return;  // (workgroup-uniform) this tile needs fewer groups than the grid provides
-  // this wave's share of the row-major neighbour list: [s0, s1)
-  const int slot = g * GN_WAVES + wave, nslots = G * GN_WAVES;
-  const int s0 = (int)((long long)nj * slot / nslots), s1 = (int)((long long)nj * (slot + 1) / nslots);
-  const int ys = ylo + s0 / ncols, xs = xlo + s0 % ncols;
-  const int ye = ylo + (s1 - 1) / ncols, xe = xlo + (s1 - 1) % ncols;
-
-  const int xi = tx0 + (lane & 7), yi = ty0 + (lane >> 3);
-  const bool vi = xi < w && yi < h;
-  const int i = vi ? yi * w + xi : 0;
-  const int xim = xi - radius, yim = yi - radius;
-  const unsigned twor = 2u * (unsigned)radius;
-  const float* rec = jd + (size_t)b * N * GN_JS;
-  const float* aip = rec + (size_t)i * GN_JS;
-  // dev ablations (tools/ubench/gn_ablate.hip): GN_ABL_NOPRO no per-pixel loads in the prologue, GN_ABL_NODOT no
-  // affinity dot product, GN_ABL_NOGEOM no geometry / normal-equation updates, GN_ABL_NOSLOAD one record per row
-  // (scalar loads leave the inner loop), GN_ABL_NOEPI no reduction / partial store
-#ifdef GN_ABL_NOPRO
-  const SE3T Ti = {V3{0.01f * lane, 0.02f, 0.03f}, Q4{0.f, 0.f, 0.f, 1.f}};
-#else
-  const SE3T Ti = se3_load(T + ((size_t)b * N + i) * 7);
-#endif
-  // rotation matrix of T_i: Y = [c0 c1 c2] X + t
-  const V3 c0 = qrot(Ti.q, V3{1.f, 0.f, 0.f}), c1 = qrot(Ti.q, V3{0.f, 1.f, 0.f}), c2 = qrot(Ti.q, V3{0.f, 0.f, 1.f});
-  v2f ai[GN_AE / 2];
-#pragma unroll
-#ifdef GN_ABL_NOPRO
-  for (int c = 0; c < GN_AE / 2; ++c) ai[c] = v2f{0.01f * (lane + c), 0.02f * (lane - c)};
-  const float ai2 = 0.5f * lane;
-#else
-  for (int c = 0; c < GN_AE / 2; ++c) ai[c] = *(const v2f*)(aip + 2 * c);
-  const float ai2 = aip[41];
-#endif
-  // normal-equation sums: the upper triangle of H as row pairs (H_p,q  H_p,q+1), q even -- rows 1, 3, 5 carry one
-  // redundant lower-triangle entry so that every update is one packed FMA; H01 is structurally 0
-  float H00 = 0.f, H11 = 0.f, b0 = 0.f, b1 = 0.f, b4z = 0.f;
-  v2f h02 = {0.f, 0.f}, h04 = h02, h12 = h02, h14 = h02, h22 = h02, h24 = h02, h32 = h02, h34 = h02, h44 = h02, h54 = h02;
-  v2f b23 = h02, b45 = h02;
-  const float nfy = -fy;
-
-  if (s1 > s0)
-  for (int yj = ys; yj <= ye; ++yj) {
-    const bool rowin = vi && (unsigned)(yj - yim) <= twor;
-    const float* rrow = rec + (size_t)yj * w * GN_JS;
-    const int xa = yj == ys ? xs : xlo, xb = yj == ye ? xe : xhi;
-    for (int xj = xa; xj <= xb; ++xj) {
-      // wave-uniform address -> scalar loads; the whole 176-byte record is fetched up front (one batch of
-      // s_load_dwordx4/x8/x16, one wait); SGPR pairs feed the packed FMAs directly
-#ifdef GN_ABL_NOSLOAD
-      const float4* rp4 = (const float4*)(rrow + (size_t)xa * GN_JS);
-#else
-      const float4* rp4 = (const float4*)(rrow + (size_t)xj * GN_JS);
-#endif
-      float4 r[11];
-#pragma unroll
-      for (int q = 0; q < 11; ++q) r[q] = rp4[q];
-      const float Xx = r[8].x, Xy = r[8].y, Xz = r[8].z;
-      const float Yz = fmaf(c0.z, Xx, fmaf(c1.z, Xy, fmaf(c2.z, Xz, Ti.t.z)));
-      const bool in = rowin && (unsigned)(xj - xim) <= twor && Xz >= MIN_DEPTH && Yz >= MIN_DEPTH;
-      v2f acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        acc0 = GN_PK(ai[2 * q], (v2f){r[q].x, r[q].y}, acc0);
-        acc1 = GN_PK(ai[2 * q + 1], (v2f){r[q].z, r[q].w}, acc1);
-      }
-      acc0 += acc1;
-#ifdef GN_ABL_NODOT
-      const float dot = ai[0].x * r[0].x;
-#else
-      const float dot = acc0.x + acc0.y;
-#endif
-      const float d2 = fmaxf(fmaf(-2.f, dot, ai2 + r[10].y), 0.f);
-      const float a = in ? __builtin_amdgcn_rcpf(1.f + __expf(d2)) : 0.f;  // sigmoid(-d2), masked
-#ifdef GN_ABL_NOGEOM
-      H00 += a;
-      continue;
-#endif
-      // the affinity of far neighbours underflows against the accumulated sums: skip their geometry when every
-      // lane's weight is below 1e-9 (relative effect on H, b < 1e-9; wave-uniform branch)
-#ifdef GN_STATS  // dev build (tools/gn_skip_rate.py): neighbour visits / visits skipped by the test below, per wave
-      if (lane == 0) atomicAdd(&gn_stats[0], 1ull);
-      if (__ballot(a > 1e-9f) == 0ull) { if (lane == 0) atomicAdd(&gn_stats[1], 1ull); continue; }
-#elif !defined(GN_NO_SKIP)
-      if (__ballot(a > 1e-9f) == 0ull) continue;
-#endif
-      const float Yx = fmaf(c0.x, Xx, fmaf(c1.x, Xy, fmaf(c2.x, Xz, Ti.t.x)));
-      const float Yy = fmaf(c0.y, Xx, fmaf(c1.y, Xy, fmaf(c2.y, Xz, Ti.t.y)));
-      const float d = __builtin_amdgcn_rcpf(fmaxf(Yz, MIN_DEPTH));
-      const float xn = Yx * d, yn = Yy * d;
-      const float fxd = fx * d, fyd = fy * d, xy = xn * yn, fxx = fx * xn, fyy = fy * yn;
-      // J rows (d(u, v, 1/z) / d(tau, phi)); structural zeros: Jx1, Jy0, Jz0, Jz1, Jz5
-      const v2f Jx23 = {-fxd * xn, -fx * xy}, Jx45 = {fmaf(fxx, xn, fx), -fx * yn};
-      const v2f Jy23 = {-fyd * yn, fmaf(-fyy, yn, nfy)}, Jy45 = {fy * xy, fy * xn};
-      const v2f Jz23 = {-d * d, -yn * d}, Jz45 = {xn * d, 0.f};
-      const float rx = r[8].w - (fxx + cx), ry = r[9].x - (fyy + cy), rz = r[9].y - d;
-      const float wx = a * r[9].z, wy = a * r[9].w, wz = a * r[10].x;
-      const float wJx0 = wx * fxd, wJy1 = wy * fyd, wJz4 = wz * Jz45.x;
-      const v2f wJx23 = wx * Jx23, wJx45 = wx * Jx45, wJy23 = wy * Jy23, wJy45 = wy * Jy45, wJz23 = wz * Jz23;
-      H00 = fmaf(wJx0, fxd, H00);
-      h02 = GN_PK((v2f)(wJx0), Jx23, h02);
-      h04 = GN_PK((v2f)(wJx0), Jx45, h04);
-      H11 = fmaf(wJy1, fyd, H11);
-      h12 = GN_PK((v2f)(wJy1), Jy23, h12);
-      h14 = GN_PK((v2f)(wJy1), Jy45, h14);
-      h22 = GN_PK((v2f)(wJx23.x), Jx23, h22); h22 = GN_PK((v2f)(wJy23.x), Jy23, h22); h22 = GN_PK((v2f)(wJz23.x), Jz23, h22);
-      h24 = GN_PK((v2f)(wJx23.x), Jx45, h24); h24 = GN_PK((v2f)(wJy23.x), Jy45, h24); h24 = GN_PK((v2f)(wJz23.x), Jz45, h24);
-      h32 = GN_PK((v2f)(wJx23.y), Jx23, h32); h32 = GN_PK((v2f)(wJy23.y), Jy23, h32); h32 = GN_PK((v2f)(wJz23.y), Jz23, h32);
-      h34 = GN_PK((v2f)(wJx23.y), Jx45, h34); h34 = GN_PK((v2f)(wJy23.y), Jy45, h34); h34 = GN_PK((v2f)(wJz23.y), Jz45, h34);
-      h44 = GN_PK((v2f)(wJx45.x), Jx45, h44); h44 = GN_PK((v2f)(wJy45.x), Jy45, h44); h44 = GN_PK((v2f)(wJz4), Jz45, h44);
-      h54 = GN_PK((v2f)(wJx45.y), Jx45, h54); h54 = GN_PK((v2f)(wJy45.y), Jy45, h54);
-      b0 = fmaf(wJx0, rx, b0);
-      b1 = fmaf(wJy1, ry, b1);
-      b23 = GN_PK(wJx23, (v2f)(rx), b23); b23 = GN_PK(wJy23, (v2f)(ry), b23); b23 = GN_PK(wJz23, (v2f)(rz), b23);
-      b45 = GN_PK(wJx45, (v2f)(rx), b45); b45 = GN_PK(wJy45, (v2f)(ry), b45);
-      b4z = fmaf(wJz4, rz, b4z);
-    }
-  }
-  // combine the workgroup's 4 partial sums in a fixed order, one [27][64] partial per workgroup
-  const float Hs[27] = {H00, 0.f, h02.x, h02.y, h04.x, h04.y, H11, h12.x, h12.y, h14.x, h14.y, h22.x, h22.y, h24.x,
-                        h24.y, h32.y, h34.x, h34.y, h44.x, h44.y, h54.y, b0, b1, b23.x, b23.y, b45.x + b4z, b45.y};
-  float* pp = part + (((size_t)b * ntiles + tile) * gmax + g) * 27 * 64 + lane;
-#ifdef GN_ABL_NOEPI
-  if (Hs[0] != 12345.f) return;
-#endif
-  if constexpr (!FUSE) {
-    // wave w adds its sums into ONE [27][64] LDS image after wave w - 1 (same order, same bits as
-    // ((s0 + s1) + s2) + s3 over four images): 6.9 KB instead of 27.6 KB per workgroup, so that four resident
-    // builder workgroups leave 132 KB of a CU's LDS to a co-scheduled convolution (finding 41)
-    float (*acc_)[64] = red[0];
-#pragma unroll
-    for (int w_ = 0; w_ < GN_WAVES; ++w_) {
-      if (wave == w_) {
-#pragma unroll
-        for (int k = 0; k < 27; ++k) acc_[k][lane] = w_ == 0 ? Hs[k] : acc_[k][lane] + Hs[k];
-      }
-      __syncthreads();
-    }
-    for (int k = wave; k < 27; k += GN_WAVES) pp[k * 64] = acc_[k][lane];
-  } else {
-#pragma unroll
-    for (int k = 0; k < 27; ++k) red[wave][k][lane] = Hs[k];
-    __syncthreads();
-    // Device-scope hand-over WITHOUT fences (an agent-scope fence writes back / invalidates the whole L2 of the XCD --
-    // measured: +280 us per step, every other workgroup loses its cached neighbour records): the partials are written
-    // through (relaxed agent-scope stores = sc1), each wave waits for its own stores, the workgroup's arrival is
-    // counted after a barrier, and the last workgroup reads the partials with sc1 loads.
-    for (int k = wave; k < 27; k += GN_WAVES)
-      __hip_atomic_store(pp + k * 64, ((red[0][k][lane] + red[1][k][lane]) + red[2][k][lane]) + red[3][k][lane],
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0)
-      s_last = __hip_atomic_fetch_add(cnt + b * ntiles + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == G - 1;
-    __syncthreads();
-    if (!s_last) return;
-    float (*sums)[64] = red[0];
-    const float* p = part + (((size_t)b * ntiles + tile) * gmax) * 27 * 64 + lane;
-#define GN_LD(q) __hip_atomic_load(p + ((size_t)(q) * 27 + k) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-    for (int k = wave; k < 27; k += GN_WAVES) {
-      float s = 0.f;
-      int gg = 0;
-      for (; gg + 4 <= G; gg += 4) {  // four loads in flight, added in index order (as se3_gn_solve_kernel)
-        const float v0 = GN_LD(gg), v1 = GN_LD(gg + 1), v2 = GN_LD(gg + 2), v3 = GN_LD(gg + 3);
-        s = (((s + v0) + v1) + v2) + v3;
-      }
-      for (; gg < G; ++gg) s += GN_LD(gg);
-      sums[k][lane] = s;
-    }
-#undef GN_LD
-    __syncthreads();
-    if (wave == 0) gn_solve_tile(T, sums, lane, b, tx0, ty0, h, w, lm, ep);
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -981,7 +755,7 @@ __global__ __launch_bounds__(64 * GN_WAVES) void se3_gn_build3_kernel(
       const float ax = __builtin_amdgcn_rcpf(1.f + __expf(fmaxf(e2.x, 0.f)));
       const float ay = __builtin_amdgcn_rcpf(1.f + __expf(fmaxf(e2.y, 0.f)));
       const v2f a = {in0 ? ax : 0.f, in1 ? ay : 0.f};  // sigmoid(-d2), masked
-      if (__ballot(a.x > 1e-9f || a.y > 1e-9f) == 0ull) continue;  // (as in se3_gn_build_kernel)
+      if (__ballot(a.x > 1e-9f || a.y > 1e-9f) == 0ull) continue;  
       const v2f Yx = GN_PK(BC(c0.x), Xx, GN_PK(BC(c1.x), Xy, GN_PK(BC(c2.x), Xz, BC(Ti.t.x))));
       const v2f Yy = GN_PK(BC(c0.y), Xx, GN_PK(BC(c1.y), Xy, GN_PK(BC(c2.y), Xz, BC(Ti.t.y))));
       const v2f d = {__builtin_amdgcn_rcpf(fmaxf(Yz.x, MIN_DEPTH)), __builtin_amdgcn_rcpf(fmaxf(Yz.y, MIN_DEPTH))};
@@ -1016,7 +790,7 @@ __global__ __launch_bounds__(64 * GN_WAVES) void se3_gn_build3_kernel(
 #undef S2
   float* pp = part + (((size_t)b * ntiles + tile) * gmax + g) * 27 * 64 + lane;
 #pragma unroll
-  for (int w_ = 0; w_ < GN_WAVES; ++w_) {  // (same one-image reduction in wave order as se3_gn_build_kernel<false>)
+  for (int w_ = 0; w_ < GN_WAVES; ++w_) {  // (one [27][64] image, waves add in index order)
     if (wave == w_) {
 #pragma unroll
       for (int k = 0; k < 27; ++k) red[k][lane] = w_ == 0 ? Hs[k] : red[k][lane] + Hs[k];
@@ -1119,7 +893,7 @@ __global__ __launch_bounds__(64 * GN_WAVES) __attribute__((amdgpu_waves_per_eu(4
       const float ax = __builtin_amdgcn_rcpf(1.f + __expf(fmaxf(e2.x, 0.f)));
       const float ay = __builtin_amdgcn_rcpf(1.f + __expf(fmaxf(e2.y, 0.f)));
       const v2f a = {in0 ? ax : 0.f, in1 ? ay : 0.f};  // sigmoid(-d2), masked
-      if (__ballot(a.x > 1e-9f || a.y > 1e-9f) == 0ull) continue;  // (as in se3_gn_build_kernel)
+      if (__ballot(a.x > 1e-9f || a.y > 1e-9f) == 0ull) continue;  
       const v2f Yx = GN_PK(BC(c0.x), Xx, GN_PK(BC(c1.x), Xy, GN_PK(BC(c2.x), Xz, BC(Ti.t.x))));
       const v2f Yy = GN_PK(BC(c0.y), Xx, GN_PK(BC(c1.y), Xy, GN_PK(BC(c2.y), Xz, BC(Ti.t.y))));
       const v2f d = {__builtin_amdgcn_rcpf(fmaxf(Yz.x, MIN_DEPTH)), __builtin_amdgcn_rcpf(fmaxf(Yz.y, MIN_DEPTH))};
@@ -1155,7 +929,7 @@ __global__ __launch_bounds__(64 * GN_WAVES) __attribute__((amdgpu_waves_per_eu(4
   float* pp = part + (((size_t)b * ntiles + tile) * gmax + g) * 27 * 64 + lane;
   __syncthreads();  // every wave is done with the embedding image before the reduction re-uses its LDS
 #pragma unroll
-  for (int w_ = 0; w_ < GN_WAVES; ++w_) {  // (same one-image reduction in wave order as se3_gn_build_kernel<false>)
+  for (int w_ = 0; w_ < GN_WAVES; ++w_) {  // (one [27][64] image, waves add in index order)
     if (wave == w_) {
 #pragma unroll
       for (int k = 0; k < 27; ++k) red[k][lane] = w_ == 0 ? Hs[k] : red[k][lane] + Hs[k];
@@ -1165,302 +939,6 @@ __global__ __launch_bounds__(64 * GN_WAVES) __attribute__((amdgpu_waves_per_eu(4
   for (int k = wave; k < 27; k += GN_WAVES) pp[k * 64] = red[k][lane];
 }
 
-
-#ifndef GN_CH2
-#define GN_CH2 8
-#endif
-// GN_CH2: pairs per chunk of the two-pass builder (4 KB of affinities per wave)
-__global__ __launch_bounds__(64 * GN_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void se3_gn_build4_kernel(
-    const float* __restrict__ T, const float* __restrict__ jd, const float* __restrict__ geo2, int h, int w, float fx,
-    float fy, float cx, float cy, int radius, int tiles_x, int ntiles, int q4, int gmax, float* __restrict__ part) {
-  __shared__ float red[27][64];
-  __shared__ v2f abuf[GN_WAVES][GN_CH2][64];  // per wave: the affinities of a chunk of pairs, [pair][lane] = (a_j0, a_j1)
-  const int N = h * w, wp2 = (w + 1) >> 1;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tile = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
-  const int tx0 = (tile % tiles_x) * 8, ty0 = (tile / tiles_x) * 8;
-  const int ylo = max(ty0 - radius, 0), yhi = min(ty0 + 7 + radius, h - 1);
-  const int xlo = max(tx0 - radius, 0), xhi = min(tx0 + 7 + radius, w - 1);
-  const int ncols = xhi - xlo + 1, nj = (yhi - ylo + 1) * ncols;
-  const int G = gn_groups(nj, q4, gmax);
-  if (g >= G) return;
-  const int slot = g * GN_WAVES + wave, nslots = G * GN_WAVES;
-  const int s0 = (int)((long long)nj * slot / nslots), s1 = (int)((long long)nj * (slot + 1) / nslots);
-  const int ys = ylo + s0 / ncols, xs = xlo + s0 % ncols;
-  const int ye = ylo + (s1 - 1) / ncols, xe = xlo + (s1 - 1) % ncols;
-
-  const int xi = tx0 + (lane & 7), yi = ty0 + (lane >> 3);
-  const bool vi = xi < w && yi < h;
-  const int i = vi ? yi * w + xi : 0;
-  const int xim = xi - radius, yim = yi - radius;
-  const unsigned twor = 2u * (unsigned)radius;
-  const float* rec = jd + (size_t)b * N * GN_JS;
-  const float* aip = rec + (size_t)i * GN_JS;
-  const SE3T Ti = se3_load(T + ((size_t)b * N + i) * 7);
-  const V3 c0 = qrot(Ti.q, V3{1.f, 0.f, 0.f}), c1 = qrot(Ti.q, V3{0.f, 1.f, 0.f}), c2 = qrot(Ti.q, V3{0.f, 0.f, 1.f});
-  const v2f Z = {0.f, 0.f};
-  v2f H00 = Z, H11 = Z, H02 = Z, H12 = Z, H22 = Z, H03 = Z, H04 = Z, H05 = Z, H13 = Z, H14 = Z, H15 = Z, H23 = Z, H24 = Z,
-      H25 = Z, H33 = Z, H34 = Z, H35 = Z, H44 = Z, H45 = Z, H55 = Z, b0 = Z, b1 = Z, b2 = Z, b3 = Z, b4 = Z, b5 = Z;
-#define BC(s) ((v2f){(s), (s)})
-
-  // TWO-PASS walk over the wave's pairs, row by row, in chunks of GN_CH2 pairs (DESIGN finding 51).  Pass 1 needs the
-  // pixel's own embedding (32 VGPRs) and the pair's two embeddings (64 SGPRs) and leaves the unmasked affinities
-  // sigmoid(-|a_i - a_j|^2) in the wave's LDS slice; pass 2 needs the geometry pairs (20 SGPRs), the 52 accumulators and
-  // the geometry's temporaries -- not the embeddings.  Neither pass holds the other's registers: <= 128 VGPRs (4 waves
-  // per SIMD instead of 3) and one awaited group of scalar loads per pair and pass instead of three or four per pair.
-  v2f(*const ab)[64] = abuf[wave];
-  if (s1 > s0)
-  for (int yj = ys; yj <= ye; ++yj) {
-    const bool rowin = vi && (unsigned)(yj - yim) <= twor;
-    const float* rrow = rec + (size_t)yj * w * GN_JS;
-    const v2f* grow = (const v2f*)(geo2 + ((size_t)b * h + yj) * wp2 * GN_G2);
-    const int xa = yj == ys ? xs : xlo, xb = yj == ye ? xe : xhi;
-    for (int pc = xa >> 1; pc <= (xb >> 1); pc += GN_CH2) {
-      const int np = min(GN_CH2, (xb >> 1) - pc + 1);
-      unsigned skip = 0;
-      {  // ---- pass 1: affinities
-        // the pixel's embedding is re-read per chunk (L2-resident) through a pointer the compiler cannot hoist the
-        // loads of: kept in registers over pass 2 it would cost the fourth wave per SIMD
-        const float* aq = aip;
-        asm("" : "+v"(aq) : "s"(pc), "s"(yj));
-        v2f ai[GN_AE / 2];
-#pragma unroll
-        for (int c = 0; c < GN_AE / 2; ++c) ai[c] = *(const v2f*)(aq + 2 * c);
-        const float ai2 = aq[41];
-        for (int pl = 0; pl < np; ++pl) {
-          const int x0 = 2 * (pc + pl);
-          const float4* e0 = (const float4*)(rrow + (size_t)x0 * GN_JS);
-          const float4* e1 = (const float4*)(rrow + (size_t)min(x0 + 1, w - 1) * GN_JS);
-          float4 r0[8], r1[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) r0[q] = e0[q];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) r1[q] = e1[q];
-          const v2f a2 = {((const float*)e0)[41], ((const float*)e1)[41]};
-          v2f p0 = Z, p1 = Z, q0 = Z, q1 = Z;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            p0 = GN_PK(ai[2 * q], (v2f){r0[q].x, r0[q].y}, p0);
-            p1 = GN_PK(ai[2 * q + 1], (v2f){r0[q].z, r0[q].w}, p1);
-            q0 = GN_PK(ai[2 * q], (v2f){r1[q].x, r1[q].y}, q0);
-            q1 = GN_PK(ai[2 * q + 1], (v2f){r1[q].z, r1[q].w}, q1);
-          }
-          p0 += p1;
-          q0 += q1;
-          const v2f dot = {p0.x + p0.y, q0.x + q0.y};
-          const v2f e2 = GN_PK(BC(-2.f), dot, BC(ai2) + a2);
-          const v2f au = {__builtin_amdgcn_rcpf(1.f + __expf(fmaxf(e2.x, 0.f))),
-                          __builtin_amdgcn_rcpf(1.f + __expf(fmaxf(e2.y, 0.f)))};  // sigmoid(-d2)
-          ab[pl][lane] = au;
-          // the affinity of far neighbours underflows against the accumulated sums (as in se3_gn_build_kernel; decided
-          // here, on the unmasked value, so that pass 2's step is one basic block)
-          skip |= __ballot(au.x > 1e-9f || au.y > 1e-9f) == 0ull ? 1u << pl : 0u;
-        }
-      }
-      // ---- pass 2: geometry (a wave reads back what it wrote: no barrier)
-      for (int pl = 0; pl < np; ++pl) {
-        if (skip >> pl & 1) continue;
-        const int x0 = 2 * (pc + pl), x1 = x0 + 1;
-        const bool own0 = x0 >= xa, own1 = x1 <= xb;  // (x0 <= xb and x1 >= xa always hold)
-        const v2f* gp = grow + (size_t)(pc + pl) * (GN_G2 / 2);
-        v2f G2[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) G2[k] = gp[k];
-        const v2f au = ab[pl][lane];
-        const v2f Xx = G2[0], Xy = G2[1], Xz = G2[2];
-        const v2f Yz = GN_PK(BC(c0.z), Xx, GN_PK(BC(c1.z), Xy, GN_PK(BC(c2.z), Xz, BC(Ti.t.z))));
-        const bool in0 = rowin & own0 & ((unsigned)(x0 - xim) <= twor) & (Xz.x >= MIN_DEPTH) & (Yz.x >= MIN_DEPTH);
-        const bool in1 = rowin & own1 & ((unsigned)(x1 - xim) <= twor) & (Xz.y >= MIN_DEPTH) & (Yz.y >= MIN_DEPTH);
-        const v2f a = {in0 ? au.x : 0.f, in1 ? au.y : 0.f};
-        const v2f Yx = GN_PK(BC(c0.x), Xx, GN_PK(BC(c1.x), Xy, GN_PK(BC(c2.x), Xz, BC(Ti.t.x))));
-        const v2f Yy = GN_PK(BC(c0.y), Xx, GN_PK(BC(c1.y), Xy, GN_PK(BC(c2.y), Xz, BC(Ti.t.y))));
-        const v2f d = {__builtin_amdgcn_rcpf(fmaxf(Yz.x, MIN_DEPTH)), __builtin_amdgcn_rcpf(fmaxf(Yz.y, MIN_DEPTH))};
-        const v2f xn = Yx * d, yn = Yy * d;
-        const v2f rx = G2[3] - xn, ry = G2[4] - yn, rz = G2[5] - d;  // (rx, ry in units of fx, fy: folded into S00, S11)
-        const v2f S00 = a * G2[6], S11 = a * G2[7], t = (a * G2[8]) * d;
-        const v2f S02 = -(S00 * xn), S12 = -(S11 * yn);
-        const v2f S22 = GN_PK(t, d, -GN_PK(S12, yn, S02 * xn));
-        const v2f g0 = S00 * rx, g1 = S11 * ry;
-        const v2f g2 = -GN_PK(t, rz, GN_PK(g1, yn, g0 * xn));
-        const v2f dd = d * d;
-        H00 = GN_PK(dd, S00, H00); H11 = GN_PK(dd, S11, H11); H02 = GN_PK(dd, S02, H02); H12 = GN_PK(dd, S12, H12);
-        H22 = GN_PK(dd, S22, H22);
-        const v2f N00 = yn * S02, N01 = GN_PK(-xn, S02, S00), N02 = -(yn * S00);
-        const v2f N10 = GN_PK(yn, S12, -S11), N11 = -(xn * S12), N12 = xn * S11;
-        const v2f N20 = GN_PK(yn, S22, -S12), N21 = GN_PK(-xn, S22, S02), N22 = GN_PK(xn, S12, -N00);
-        H03 = GN_PK(d, N00, H03); H04 = GN_PK(d, N01, H04); H05 = GN_PK(d, N02, H05);
-        H13 = GN_PK(d, N10, H13); H14 = GN_PK(d, N11, H14); H15 = GN_PK(d, N12, H15);
-        H23 = GN_PK(d, N20, H23); H24 = GN_PK(d, N21, H24); H25 = GN_PK(d, N22, H25);
-        H33 = GN_PK(yn, N20, H33) - N10; H34 = GN_PK(yn, N21, H34) - N11; H35 = GN_PK(yn, N22, H35) - N12;
-        H44 = GN_PK(-xn, N21, H44) + N01; H45 = GN_PK(-xn, N22, H45) + N02;
-        H55 = GN_PK(xn, N12, GN_PK(-yn, N02, H55));
-        b0 = GN_PK(d, g0, b0); b1 = GN_PK(d, g1, b1); b2 = GN_PK(d, g2, b2);
-        b3 = GN_PK(yn, g2, b3) - g1; b4 = GN_PK(-xn, g2, b4) + g0; b5 = GN_PK(xn, g1, GN_PK(-yn, g0, b5));
-      }
-    }
-  }
-#undef BC
-#define S2(v) ((v).x + (v).y)
-  const float Hs[27] = {S2(H00), 0.f, S2(H02), S2(H03), S2(H04), S2(H05), S2(H11), S2(H12), S2(H13), S2(H14), S2(H15),
-                        S2(H22), S2(H23), S2(H24), S2(H25), S2(H33), S2(H34), S2(H35), S2(H44), S2(H45), S2(H55),
-                        S2(b0), S2(b1), S2(b2), S2(b3), S2(b4), S2(b5)};
-#undef S2
-  float* pp = part + (((size_t)b * ntiles + tile) * gmax + g) * 27 * 64 + lane;
-#pragma unroll
-  for (int w_ = 0; w_ < GN_WAVES; ++w_) {  // (same one-image reduction in wave order as se3_gn_build_kernel<false>)
-    if (wave == w_) {
-#pragma unroll
-      for (int k = 0; k < 27; ++k) red[k][lane] = w_ == 0 ? Hs[k] : red[k][lane] + Hs[k];
-    }
-    __syncthreads();
-  }
-  for (int k = wave; k < 27; k += GN_WAVES) pp[k * 64] = red[k][lane];
-}
-
-// MFMA builder (round 4, CODD_GN_MFMA=1; off by default, see gn_mfma()): the 32-term affinity dot products -- 18 of the scalar builder's 110
-// VALU instructions per neighbour -- move to the bf16 matrix pipe, which this VALU-bound kernel leaves idle.
-//   * neighbours are taken 16 at a time; Gram block G[j][i] = <ae_j, ae_i> for the tile's 64 pixels by
-//     v_mfma_f32_32x32x16_bf16 on split-bf16 operands (3 terms, as the convolutions: hi*hi + hi*lo + lo*hi):
-//     rows = neighbours, columns = pixels; MFMA q covers pixels 32 q .. 32 q + 31, two k-steps cover the 32 dims:
-//     12 MFMAs = 384 matrix-pipe cycles per 16 neighbours (24 per neighbour, against 87 VALU cycles);
-//   * row m of the A operand holds neighbour (m % 4) + 4 (m / 8), i.e. rows m and m + 4 the SAME neighbour, so that
-//     accumulator register r of BOTH lane halves is neighbour r: the neighbour stays wave-uniform (scalar record
-//     loads, SGPR operands as before) and lane L = pixel L picks accumulator set L / 32 with one v_cndmask;
-//   * everything after the dot product is the scalar builder's arithmetic, instruction for instruction.
-// (The fp32-MFMA variant of round 2 gained nothing: v_mfma_f32_16x16x4_f32 runs at the VALU's own FMA rate.)
-// ------------------------------------------------------------------------------------------------
-typedef float gn_f32x16 __attribute__((ext_vector_type(16)));
-__global__ __launch_bounds__(64 * GN_WAVES) void se3_gn_build2_kernel(
-    const float* __restrict__ T, const float* __restrict__ jd, const uint4* __restrict__ aeq, int h, int w, float fx,
-    float fy, float cx, float cy, int radius, int tiles_x, int ntiles, int q4, int gmax, float* part) {
-  __shared__ float red[GN_WAVES][27][64];
-  const int N = h * w;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tile = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
-  const int tx0 = (tile % tiles_x) * 8, ty0 = (tile / tiles_x) * 8;
-  const int ylo = max(ty0 - radius, 0), yhi = min(ty0 + 7 + radius, h - 1);
-  const int xlo = max(tx0 - radius, 0), xhi = min(tx0 + 7 + radius, w - 1);
-  const int ncols = xhi - xlo + 1, nj = (yhi - ylo + 1) * ncols;
-  const int G = gn_groups(nj, q4, gmax);
-  if (g >= G) return;
-  const int slot = g * GN_WAVES + wave, nslots = G * GN_WAVES;
-  const int s0 = (int)((long long)nj * slot / nslots), s1 = (int)((long long)nj * (slot + 1) / nslots);
-
-  const int xi = tx0 + (lane & 7), yi = ty0 + (lane >> 3);
-  const bool vi = xi < w && yi < h;
-  const int i = vi ? yi * w + xi : 0;
-  const int xim = xi - radius, yim = yi - radius;
-  const unsigned twor = 2u * (unsigned)radius;
-  const float* rec = jd + (size_t)b * N * GN_JS;
-  const SE3T Ti = se3_load(T + ((size_t)b * N + i) * 7);
-  const V3 c0 = qrot(Ti.q, V3{1.f, 0.f, 0.f}), c1 = qrot(Ti.q, V3{0.f, 1.f, 0.f}), c2 = qrot(Ti.q, V3{0.f, 0.f, 1.f});
-  const float ai2 = rec[(size_t)i * GN_JS + 41];
-  // B operands: pixel p = 32 q + (lane % 32) of the tile, dims 16 s + 8 (lane / 32) .. + 7, planes hi | lo
-  const int hh = lane >> 5;
-  const uint4* aqb = aeq + (size_t)b * N * 8;  // 8 x 16 bytes per pixel: [plane][octet]
-  codd_bf16x8 bh[2][2], bl[2][2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int p = 32 * q + (lane & 31), px = tx0 + (p & 7), py = ty0 + (p >> 3);
-    const uint4* pp = aqb + (size_t)((px < w && py < h) ? py * w + px : 0) * 8 + hh;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bh[q][s] = __builtin_bit_cast(codd_bf16x8, pp[2 * s]);
-      bl[q][s] = __builtin_bit_cast(codd_bf16x8, pp[4 + 2 * s]);
-    }
-  }
-  const int nb = (lane & 3) + 4 * ((lane & 31) >> 3);  // neighbour (of a block of 16) this lane's A row carries
-
-  float H00 = 0.f, H11 = 0.f, b0 = 0.f, b1 = 0.f, b4z = 0.f;
-  v2f h02 = {0.f, 0.f}, h04 = h02, h12 = h02, h14 = h02, h22 = h02, h24 = h02, h32 = h02, h34 = h02, h44 = h02, h54 = h02;
-  v2f b23 = h02, b45 = h02;
-  const float nfy = -fy;
-  // running (row, column) of the next neighbour of this wave's piece [s0, s1) of the row-major list
-  int yj = ylo + s0 / ncols, xj = xlo + s0 % ncols;
-
-  for (int blk = s0; blk < s1; blk += 16) {
-    gn_f32x16 acc0, acc1;
-    {
-      const int idx = min(blk + nb, s1 - 1);
-      const int ay = idx / ncols, ax = idx - ay * ncols;
-      const uint4* ap = aqb + (size_t)((ylo + ay) * w + xlo + ax) * 8 + hh;
-      const codd_bf16x8 ah0 = __builtin_bit_cast(codd_bf16x8, ap[0]), ah1 = __builtin_bit_cast(codd_bf16x8, ap[2]);
-      const codd_bf16x8 al0 = __builtin_bit_cast(codd_bf16x8, ap[4]), al1 = __builtin_bit_cast(codd_bf16x8, ap[6]);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-      // small terms first; the two accumulators alternate
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh[0][0], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh[1][0], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh[0][1], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh[1][1], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl[0][0], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl[1][0], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl[0][1], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl[1][1], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh[0][0], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh[1][0], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh[0][1], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh[1][1], acc1, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (blk + r < s1) {  // (wave-uniform)
-        const float dot = hh ? acc1[r] : acc0[r];
-        const bool rowin = vi && (unsigned)(yj - yim) <= twor;
-        const float4* rp4 = (const float4*)(rec + ((size_t)yj * w + xj) * GN_JS);
-        const float4 r8 = rp4[8], r9 = rp4[9], r10 = rp4[10];  // scalar loads (wave-uniform address)
-        const float Xx = r8.x, Xy = r8.y, Xz = r8.z;
-        const float Yz = fmaf(c0.z, Xx, fmaf(c1.z, Xy, fmaf(c2.z, Xz, Ti.t.z)));
-        const bool in = rowin && (unsigned)(xj - xim) <= twor && Xz >= MIN_DEPTH && Yz >= MIN_DEPTH;
-        const float d2 = fmaxf(fmaf(-2.f, dot, ai2 + r10.y), 0.f);
-        const float a = in ? __builtin_amdgcn_rcpf(1.f + __expf(d2)) : 0.f;  // sigmoid(-d2), masked
-        if (++xj > xhi) { xj = xlo; ++yj; }
-#ifndef GN_NO_SKIP
-        if (__ballot(a > 1e-9f) == 0ull) continue;
-#endif
-        const float Yx = fmaf(c0.x, Xx, fmaf(c1.x, Xy, fmaf(c2.x, Xz, Ti.t.x)));
-        const float Yy = fmaf(c0.y, Xx, fmaf(c1.y, Xy, fmaf(c2.y, Xz, Ti.t.y)));
-        const float d = __builtin_amdgcn_rcpf(fmaxf(Yz, MIN_DEPTH));
-        const float xn = Yx * d, yn = Yy * d;
-        const float fxd = fx * d, fyd = fy * d, xy = xn * yn, fxx = fx * xn, fyy = fy * yn;
-        const v2f Jx23 = {-fxd * xn, -fx * xy}, Jx45 = {fmaf(fxx, xn, fx), -fx * yn};
-        const v2f Jy23 = {-fyd * yn, fmaf(-fyy, yn, nfy)}, Jy45 = {fy * xy, fy * xn};
-        const v2f Jz23 = {-d * d, -yn * d}, Jz45 = {xn * d, 0.f};
-        const float rx = r8.w - (fxx + cx), ry = r9.x - (fyy + cy), rz = r9.y - d;
-        const float wx = a * r9.z, wy = a * r9.w, wz = a * r10.x;
-        const float wJx0 = wx * fxd, wJy1 = wy * fyd, wJz4 = wz * Jz45.x;
-        const v2f wJx23 = wx * Jx23, wJx45 = wx * Jx45, wJy23 = wy * Jy23, wJy45 = wy * Jy45, wJz23 = wz * Jz23;
-        H00 = fmaf(wJx0, fxd, H00);
-        h02 = GN_PK((v2f)(wJx0), Jx23, h02);
-        h04 = GN_PK((v2f)(wJx0), Jx45, h04);
-        H11 = fmaf(wJy1, fyd, H11);
-        h12 = GN_PK((v2f)(wJy1), Jy23, h12);
-        h14 = GN_PK((v2f)(wJy1), Jy45, h14);
-        h22 = GN_PK((v2f)(wJx23.x), Jx23, h22); h22 = GN_PK((v2f)(wJy23.x), Jy23, h22); h22 = GN_PK((v2f)(wJz23.x), Jz23, h22);
-        h24 = GN_PK((v2f)(wJx23.x), Jx45, h24); h24 = GN_PK((v2f)(wJy23.x), Jy45, h24); h24 = GN_PK((v2f)(wJz23.x), Jz45, h24);
-        h32 = GN_PK((v2f)(wJx23.y), Jx23, h32); h32 = GN_PK((v2f)(wJy23.y), Jy23, h32); h32 = GN_PK((v2f)(wJz23.y), Jz23, h32);
-        h34 = GN_PK((v2f)(wJx23.y), Jx45, h34); h34 = GN_PK((v2f)(wJy23.y), Jy45, h34); h34 = GN_PK((v2f)(wJz23.y), Jz45, h34);
-        h44 = GN_PK((v2f)(wJx45.x), Jx45, h44); h44 = GN_PK((v2f)(wJy45.x), Jy45, h44); h44 = GN_PK((v2f)(wJz4), Jz45, h44);
-        h54 = GN_PK((v2f)(wJx45.y), Jx45, h54); h54 = GN_PK((v2f)(wJy45.y), Jy45, h54);
-        b0 = fmaf(wJx0, rx, b0);
-        b1 = fmaf(wJy1, ry, b1);
-        b23 = GN_PK(wJx23, (v2f)(rx), b23); b23 = GN_PK(wJy23, (v2f)(ry), b23); b23 = GN_PK(wJz23, (v2f)(rz), b23);
-        b45 = GN_PK(wJx45, (v2f)(rx), b45); b45 = GN_PK(wJy45, (v2f)(ry), b45);
-        b4z = fmaf(wJz4, rz, b4z);
-      }
-    }
-  }
-  const float Hs[27] = {H00, 0.f, h02.x, h02.y, h04.x, h04.y, H11, h12.x, h12.y, h14.x, h14.y, h22.x, h22.y, h24.x,
-                        h24.y, h32.y, h34.x, h34.y, h44.x, h44.y, h54.y, b0, b1, b23.x, b23.y, b45.x + b4z, b45.y};
-#pragma unroll
-  for (int k = 0; k < 27; ++k) red[wave][k][lane] = Hs[k];
-  __syncthreads();
-  float* pp = part + (((size_t)b * ntiles + tile) * gmax + g) * 27 * 64 + lane;
-  for (int k = wave; k < 27; k += GN_WAVES)
-    pp[k * 64] = ((red[0][k][lane] + red[1][k][lane]) + red[2][k][lane]) + red[3][k][lane];
-}
 
 // Damp, solve (Cholesky, fp64) and retract the 64 pixels of one tile from its summed normal equations sums[27][64]
 // (one wave; lane = pixel).
@@ -1556,14 +1034,11 @@ __global__ __launch_bounds__(64 * GN_SOLVE_WAVES) void se3_gn_solve_kernel(
 
 // Neighbours per workgroup (4 waves): small enough that the launch is several dispatch rounds of equal-sized
 // waves (dynamic balance over the 256 CUs), large enough that a wave's set-up (its 32 + 12 per-pixel registers) and
-// the per-workgroup partial (6.9 KB) stay in the noise.
-static inline bool gn_pair();
+// the per-workgroup partial (6.9 KB) stay in the noise.  Default 192 (a pair slot is lost at each end of a row segment:
+// 103.5 us at 128, 100.3 at 192, 99.4 at 256, 104.7 at 384); CODD_OPT_GN_Q4 selects another grouping -- another fp32
+// summation order of the same normal equations, which the parity tests use as a re-association probe.
 static inline int gn_q4() {
-  // 128 for the J-entry builder, 192 for the pair builder (half as many steps per neighbour, a pair slot lost at each
-  // end of a row segment: 103.5 us at 128, 100.3 at 192, 99.4 at 256, 104.7 at 384; 256 is also the one grouping of
-  // eight tried -- both builders -- that takes the 16-frame cfg3 sequence through the other branch of the frame-6
-  // event, profiles/r04_gn_grouping_vs_trajectory.log); CODD_GN_Q4 = dev override
-  static const int q = getenv("CODD_GN_Q4") ? atoi(getenv("CODD_GN_Q4")) : (gn_pair() ? 192 : 128);
+  const int q = codd_opt(CODD_OPT_GN_Q4);
   return q < 16 ? 16 : q;
 }
 static inline int gn_gmax(int radius) {
@@ -1571,53 +1046,19 @@ static inline int gn_gmax(int radius) {
   return gn_groups(NC * NC, gn_q4(), 1 << 20);
 }
 
-// floats of scratch in front of the split-bf16 embedding planes (16-byte aligned)
-static inline size_t gn_aeq_offset(int B, int h, int w, int radius) {
+// floats of scratch in front of the pair builder's geo2 image: [partials | neighbour records | per-tile counters]
+static inline size_t gn_geo2_offset(int B, int h, int w, int radius) {
   const int ntiles = cdiv(w, 8) * cdiv(h, 8);
   const size_t n = (size_t)B * ntiles * gn_gmax(radius) * 27 * 64 + (size_t)B * h * w * GN_JS + (size_t)B * ntiles;
   return (n + 3) & ~(size_t)3;
-}
-// floats in front of the pair builder's geo2 image
-static inline size_t gn_geo2_offset(int B, int h, int w, int radius) {
-  return gn_aeq_offset(B, h, w, radius) + (size_t)B * h * w * GN_AQ;
 }
 extern "C" long long codd_se3_gn_scratch(int B, int h, int w, int radius) {
   // (+ 2 pairs: the pair builder's warm-up loads read one pair past the step's own)
   return (long long)gn_geo2_offset(B, h, w, radius) + ((long long)B * h * ((w + 1) / 2) + 2) * GN_G2;
 }
-// [partials | neighbour records | per-tile arrival counters | split-bf16 embeddings (MFMA builder)]
 static inline int* gn_counters(float* Hb, int B, int h, int w, int radius) {
   const int ntiles = cdiv(w, 8) * cdiv(h, 8);
   return (int*)(Hb + (size_t)B * ntiles * gn_gmax(radius) * 27 * 64 + (size_t)B * h * w * GN_JS);
-}
-static inline bool gn_mfma() {
-  // A/B (dev), OFF: 1 = se3_gn_build2_kernel (dot products on the bf16 matrix pipe).  Measured (DESIGN finding 38):
-  // 15 % fewer VALU instructions per neighbour, 116.9 against 118.5 us -- the builder is not bound by its VALU count
-  static const bool f = getenv("CODD_GN_MFMA") && atoi(getenv("CODD_GN_MFMA")) == 1;
-  return f;
-}
-static inline bool gn_two_pass() {
-  // (with the pair builder) 1 = se3_gn_build4_kernel: affinities and geometry in two passes per chunk of 8 pairs
-  static const bool f = getenv("CODD_GN_TWO_PASS") && atoi(getenv("CODD_GN_TWO_PASS")) == 1;
-  return f;
-}
-static inline bool gn_ailds() {
-  // ON since round 5 (same bits as se3_gn_build3_kernel; stand-alone the same 120 us per step, in the frame +0.6 %: at 125
-  // registers three builder waves leave a SIMD room for a wave of the co-scheduled z|r convolution, at 157 they do not --
-  // profiles/r05_gn_ailds_ab.log); CODD_GN_AILDS=0 = the register form
-  static const bool f = !(getenv("CODD_GN_AILDS") && atoi(getenv("CODD_GN_AILDS")) == 0);
-  return f;
-}
-static inline bool gn_pair() {
-  // 1 (default) = se3_gn_build3_kernel: two neighbours per step in packed fp32, factored normal equations; 0 = the
-  // J-entry builder se3_gn_build_kernel<false> (A/B: DESIGN finding 45)
-  static const bool f = !(getenv("CODD_GN_PAIR") && atoi(getenv("CODD_GN_PAIR")) == 0);
-  return f;
-}
-static inline bool gn_fused_solve() {
-  // dev A/B, OFF: measured 85.2-86.4 against 86.1-87.3 frames/s for the separate solve launch (DESIGN finding 24)
-  static const bool f = getenv("CODD_GN_FUSED_SOLVE") && atoi(getenv("CODD_GN_FUSED_SOLVE")) == 1;
-  return f;
 }
 
 static int gn_build_solve(float* T, int B, int h, int w, float fx, float fy, float cx, float cy, int radius, float lm,
@@ -1626,28 +1067,14 @@ static int gn_build_solve(float* T, int B, int h, int w, float fx, float fy, flo
   const int q4 = gn_q4(), gmax = gn_gmax(radius);
   float* part = Hb;
   const float* jd = Hb + (size_t)B * ntiles * gmax * 27 * 64;
-  int* cnt = gn_counters(Hb, B, h, w, radius);  // zeroed by the record packing kernel launched just before
-  if (gn_fused_solve()) {
-    se3_gn_build_kernel<true><<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, s>>>(T, jd, h, w, fx, fy, cx, cy, radius, tiles_x,
-                                                                              ntiles, q4, gmax, part, cnt, lm, ep);
-    CODD_LAUNCH_CHECK();
-    return CODD_OK;
-  }
-  if (gn_pair() && !gn_mfma() && gn_two_pass())
-    se3_gn_build4_kernel<<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, s>>>(T, jd, Hb + gn_geo2_offset(B, h, w, radius), h, w, fx, fy,
-                                                                        cx, cy, radius, tiles_x, ntiles, q4, gmax, part);
-  else if (gn_pair() && !gn_mfma() && gn_ailds())
-    se3_gn_build5_kernel<<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, s>>>(T, jd, Hb + gn_geo2_offset(B, h, w, radius), h, w, fx, fy,
-                                                                        cx, cy, radius, tiles_x, ntiles, q4, gmax, part);
-  else if (gn_pair() && !gn_mfma())
+  // CODD_OPT_GN_BUILDER: 5 (default) = the pixel's own embedding in LDS (125 VGPRs), 3 = in registers (157 VGPRs): the same
+  // instructions on the same values in the same order (bit-identical; tests/test_gpu_motion_ops.py)
+  if (codd_opt(CODD_OPT_GN_BUILDER) == 3)
     se3_gn_build3_kernel<<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, s>>>(T, jd, Hb + gn_geo2_offset(B, h, w, radius), h, w, fx, fy,
                                                                         cx, cy, radius, tiles_x, ntiles, q4, gmax, part);
-  else if (gn_mfma())
-    se3_gn_build2_kernel<<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, s>>>(
-        T, jd, (const uint4*)(Hb + gn_aeq_offset(B, h, w, radius)), h, w, fx, fy, cx, cy, radius, tiles_x, ntiles, q4, gmax, part);
   else
-    se3_gn_build_kernel<false><<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, s>>>(T, jd, h, w, fx, fy, cx, cy, radius, tiles_x,
-                                                                               ntiles, q4, gmax, part, cnt, lm, ep);
+    se3_gn_build5_kernel<<<dim3(ntiles, gmax, B), 64 * GN_WAVES, 0, s>>>(T, jd, Hb + gn_geo2_offset(B, h, w, radius), h, w, fx, fy,
+                                                                        cx, cy, radius, tiles_x, ntiles, q4, gmax, part);
   CODD_LAUNCH_CHECK();
   se3_gn_solve_kernel<<<dim3(ntiles, B), 64 * GN_SOLVE_WAVES, 0, s>>>(T, part, h, w, radius, tiles_x, ntiles, q4, gmax, lm, ep);
   CODD_LAUNCH_CHECK();
@@ -1664,7 +1091,6 @@ extern "C" int codd_se3_gn_step(float* T, const float* ae, int ae_c, const float
   hipStream_t s = (hipStream_t)stream;
   se3_gn_prep_kernel<<<dim3(cdiv(h * w, 128), B), 128, 0, s>>>(ae, ae_c, xyz, delta, weight, depth1, h, w, fx, fy, cx,
                                                              cy, jd, gn_counters(Hb, B, h, w, radius), ntiles,
-                                                             (unsigned short*)(Hb + gn_aeq_offset(B, h, w, radius)),
                                                              Hb + gn_geo2_offset(B, h, w, radius));
   CODD_LAUNCH_CHECK();
   return gn_build_solve(T, B, h, w, fx, fy, cx, cy, radius, lm, ep, Hb, s);
@@ -1682,8 +1108,7 @@ extern "C" int codd_se3_gn_step_heads(float* T, codd_xs_view hidden, const void*
   hipStream_t s = (hipStream_t)stream;
   gn_heads_prep_kernel<<<dim3(cdiv(h * w, 16), B), 128, 0, s>>>(hidden, (const uint4*)head_w, head_b, xyz, depth1, h, w, fx, fy, cx, cy,
                                                                jd, weight_out, gn_counters(Hb, B, h, w, radius), ntiles,
-                                                               (unsigned short*)(Hb + gn_aeq_offset(B, h, w, radius)),
-                                                             Hb + gn_geo2_offset(B, h, w, radius));
+                                                               Hb + gn_geo2_offset(B, h, w, radius));
   CODD_LAUNCH_CHECK();
   return gn_build_solve(T, B, h, w, fx, fy, cx, cy, radius, lm, ep, Hb, s);
 }
@@ -2141,182 +1566,6 @@ extern "C" int codd_induced_flow(const float* T, const float* depth, int B, int 
   if (!T || !depth || !out) return CODD_EINVAL;
   dim3 grid(cdiv(H * W, 256), B);
   induced_flow_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(T, depth, H, W, fx, fy, cx, cy, out);
-  CODD_LAUNCH_CHECK();
-  return CODD_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// HRNet helpers: bilinear resize (torch F.interpolate semantics) and add(+relu).
-// ------------------------------------------------------------------------------------------------
-// ``extra`` (optional, contiguous [B, C, Ho, Wo]): added to the accumulation base before the blend is added --
-// out = relu?((out + extra) + v) / (extra + v): the "+ x_i" term of an HRModule fuse layer without its own launch
-// (the same two rounded additions as an add_relu launch followed by this one)
-__global__ void resize_bilinear_kernel(const float* __restrict__ in, int C, int Hi, int Wi, int Ho, int Wo, int ac,
-                                       float* __restrict__ out, int out_ctot, int out_coff, int accumulate, int relu,
-                                       long long total, const float* __restrict__ extra) {
-  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
-  const int x = (int)(e % Wo);
-  long long t = e / Wo;
-  const int y = (int)(t % Ho); t /= Ho;
-  const int c = (int)(t % C);
-  const int b = (int)(t / C);
-  float sy, sx;
-  if (ac) {
-    sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) * (float)y : 0.f;
-    sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) * (float)x : 0.f;
-  } else {
-    sy = fmaxf(((float)Hi / (float)Ho) * ((float)y + 0.5f) - 0.5f, 0.f);
-    sx = fmaxf(((float)Wi / (float)Wo) * ((float)x + 0.5f) - 0.5f, 0.f);
-  }
-  const int y0 = min((int)sy, Hi - 1), x0 = min((int)sx, Wi - 1);
-  const int y1 = min(y0 + 1, Hi - 1), x1 = min(x0 + 1, Wi - 1);
-  const float ly = sy - (float)y0, lx = sx - (float)x0;
-  const float* p = in + ((size_t)b * C + c) * Hi * Wi;
-  float v = (1.f - ly) * ((1.f - lx) * p[y0 * Wi + x0] + lx * p[y0 * Wi + x1]) +
-            ly * ((1.f - lx) * p[y1 * Wi + x0] + lx * p[y1 * Wi + x1]);
-  float* o = out + ((size_t)b * out_ctot + out_coff + c) * Ho * Wo + (size_t)y * Wo + x;
-  if (extra) {
-    const float xe = extra[e];
-    v += accumulate ? __fadd_rn(*o, xe) : xe;
-  } else if (accumulate) {
-    v += *o;
-  }
-  if (relu) v = fmaxf(v, 0.f);
-  *o = v;
-}
-
-extern "C" int codd_resize_bilinear(const float* in, int B, int C, int Hi, int Wi, int Ho, int Wo, int align_corners,
-                                    float* out, int out_ctot, int out_coff, int accumulate, int relu, void* stream) {
-  if (!in || !out) return CODD_EINVAL;
-  const long long total = (long long)B * C * Ho * Wo;
-  resize_bilinear_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(in, C, Hi, Wi, Ho, Wo, align_corners, out,
-                                                                            out_ctot, out_coff, accumulate, relu, total, nullptr);
-  CODD_LAUNCH_CHECK();
-  return CODD_OK;
-}
-
-extern "C" int codd_resize_bilinear_add(const float* in, int B, int C, int Hi, int Wi, int Ho, int Wo, int align_corners,
-                                        float* out, int out_ctot, int out_coff, int accumulate, int relu,
-                                        const float* extra, void* stream) {
-  if (!in || !out || !extra) return CODD_EINVAL;
-  const long long total = (long long)B * C * Ho * Wo;
-  resize_bilinear_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(in, C, Hi, Wi, Ho, Wo, align_corners, out,
-                                                                            out_ctot, out_coff, accumulate, relu, total, extra);
-  CODD_LAUNCH_CHECK();
-  return CODD_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// HRModule fuse layer, the summation part (mmseg HRModule.forward; configs/models/codd.py:44-74): output branch i is
-//   relu( sum_j t_ij ),  t_ij = x_i (j == i) | the strided-conv chain of x_j (j < i, already at the target size) |
-//                               bilinear_up(conv1x1(x_j)) (j > i, align_corners = False)
-// summed in j order.  One launch per output branch instead of one resize / add launch per term.
-// ------------------------------------------------------------------------------------------------
-struct HrTerms {
-  const float* ptr[CODD_HR_MAX_TERMS];
-  int h[CODD_HR_MAX_TERMS], w[CODD_HR_MAX_TERMS];
-  int n;
-};
-__global__ void hr_fuse_sum_kernel(const HrTerms tm, int C, int Ho, int Wo, int relu, float* __restrict__ out,
-                                   long long total) {
-  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= total) return;
-  const int x = (int)(e % Wo);
-  long long t = e / Wo;
-  const int y = (int)(t % Ho);
-  const long long bc = t / Ho;  // b * C + c
-  float acc = 0.f;
-#pragma unroll
-  for (int k = 0; k < CODD_HR_MAX_TERMS; ++k) {
-    if (k >= tm.n) break;
-    const int Hi = tm.h[k], Wi = tm.w[k];
-    const float* p = tm.ptr[k] + (size_t)bc * Hi * Wi;
-    float v;
-    if (Hi == Ho && Wi == Wo) {
-      v = p[(size_t)y * Wo + x];
-    } else {  // as resize_bilinear_kernel, align_corners = False
-      const float sy = fmaxf(((float)Hi / (float)Ho) * ((float)y + 0.5f) - 0.5f, 0.f);
-      const float sx = fmaxf(((float)Wi / (float)Wo) * ((float)x + 0.5f) - 0.5f, 0.f);
-      const int y0 = min((int)sy, Hi - 1), x0 = min((int)sx, Wi - 1);
-      const int y1 = min(y0 + 1, Hi - 1), x1 = min(x0 + 1, Wi - 1);
-      const float ly = sy - (float)y0, lx = sx - (float)x0;
-      v = (1.f - ly) * ((1.f - lx) * p[y0 * Wi + x0] + lx * p[y0 * Wi + x1]) +
-          ly * ((1.f - lx) * p[y1 * Wi + x0] + lx * p[y1 * Wi + x1]);
-    }
-    // the same bits as the separate launches (resize_bilinear_kernel with accumulate / add_relu_kernel / a convolution's
-    // res1 operand): the term is complete before ONE rounded addition -- never contracted into the blend's last fma
-    acc = k == 0 ? v : __fadd_rn(v, acc);
-  }
-  out[e] = relu ? fmaxf(acc, 0.f) : acc;
-}
-
-extern "C" int codd_hr_fuse_sum(const codd_hr_term* terms, int n, int B, int C, int H, int W, int relu, float* out,
-                                void* stream) {
-  if (!terms || n < 1 || n > CODD_HR_MAX_TERMS || !out || B < 1 || C < 1 || H < 1 || W < 1) return CODD_EINVAL;
-  HrTerms tm;
-  memset(&tm, 0, sizeof(tm));
-  for (int k = 0; k < n; ++k) {
-    if (!terms[k].ptr || terms[k].h < 1 || terms[k].w < 1 || terms[k].h > H || terms[k].w > W) return CODD_EINVAL;
-    tm.ptr[k] = terms[k].ptr; tm.h[k] = terms[k].h; tm.w[k] = terms[k].w;
-  }
-  tm.n = n;
-  const long long total = (long long)B * C * H * W;
-  hr_fuse_sum_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(tm, C, H, W, relu, out, total);
-  CODD_LAUNCH_CHECK();
-  return CODD_OK;
-}
-
-__global__ void add_relu_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, int relu,
-                                float* __restrict__ y) {
-  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  float v = a[e] + (b ? b[e] : 0.f);
-  if (relu) v = fmaxf(v, 0.f);
-  y[e] = v;
-}
-
-extern "C" int codd_add_relu(const float* a, const float* b, long long n, int relu, float* y, void* stream) {
-  if (!a || !y) return CODD_EINVAL;
-  add_relu_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(a, b, n, relu, y);
-  CODD_LAUNCH_CHECK();
-  return CODD_OK;
-}
-
-// Up to 8 tensor copies in one launch (the recurrent-state write-back at the end of the captured frame: five
-// dependent 8-us launches otherwise).  Element counts and addresses must be multiples of 4 floats / 16 bytes.
-struct CopyMany {
-  const float4* src[8];
-  float4* dst[8];
-  long long end[8];  // exclusive prefix ends, in float4 units
-  int count;
-};
-__global__ void copy_many_kernel(const CopyMany c) {
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= c.end[c.count - 1]) return;
-  int k = 0;
-  long long base = 0;
-#pragma unroll
-  for (int q = 0; q < 7; ++q)
-    if (q < c.count - 1 && e >= c.end[q]) { k = q + 1; base = c.end[q]; }
-  c.dst[k][e - base] = c.src[k][e - base];
-}
-extern "C" int codd_copy_many(const float* const* src, float* const* dst, const long long* n, int count, void* stream) {
-  if (!src || !dst || !n || count < 1 || count > 8) return CODD_EINVAL;
-  CopyMany c;
-  long long tot = 0;
-  for (int k = 0; k < count; ++k) {
-    if (!src[k] || !dst[k] || n[k] < 0 || (n[k] & 3) || ((uintptr_t)src[k] & 15) || ((uintptr_t)dst[k] & 15))
-      return CODD_EINVAL;
-    c.src[k] = (const float4*)src[k];
-    c.dst[k] = (float4*)dst[k];
-    tot += n[k] / 4;
-    c.end[k] = tot;
-  }
-  for (int k = count; k < 8; ++k) { c.src[k] = nullptr; c.dst[k] = nullptr; c.end[k] = tot; }
-  c.count = count;
-  if (tot == 0) return CODD_OK;
-  copy_many_kernel<<<cdiv(tot, 256), 256, 0, (hipStream_t)stream>>>(c);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }

@@ -154,13 +154,12 @@ extern "C" int codd_tile_costvol_argmin(const float* L, const float* R, int B, i
                                         float* cost, int cost_ctot, int cost_coff, float* disp, int disp_ctot,
                                         int disp_coff, int zero_dxdy, void* stream) {
   if (!L || !R || !cost || !disp || B < 1 || C < 1 || D < 1 || Ht < 1 || Wt < 1) return CODD_EINVAL;
-  static const int dev_tpb = getenv("CODD_COSTVOL_TPB") ? atoi(getenv("CODD_COSTVOL_TPB")) : 0;  // dev A/B: 1 = scalar form
   hipStream_t st = (hipStream_t)stream;
-  if ((D & 3) == 0 && dev_tpb != 1) {
+  if ((D & 3) == 0) {
     // tiles per workgroup: 16.  More tiles share more of the staged window (64 tiles re-read a right feature 2.2x
     // instead of 6x at D = 320) but measured SLOWER at the finest level -- 40.5 (16) / 43.8 (32) / 55.2 us (64): the
     // kernel is a stage-then-scan latency chain per workgroup, and more, smaller workgroups overlap it better
-    int tpb = (dev_tpb == 16 || dev_tpb == 32 || dev_tpb == 64) ? dev_tpb : 16;
+    int tpb = 16;
     for (;; tpb >>= 1) {
       const int win = D + 4 * (tpb - 1);
       const size_t lds = (size_t)(C * win + C * tpb) * sizeof(float);
@@ -302,9 +301,8 @@ extern "C" int codd_tile_warp_cost(const float* fl, const float* fr, int B, int 
                                    codd_view hyp1, int nhyp, float* out0, float* out1, void* stream) {
   if (!fl || !fr || !hyp0.ptr || !out0 || nhyp < 1 || nhyp > 2 || (nhyp == 2 && (!hyp1.ptr || !out1)))
     return CODD_EINVAL;
-  static const int stage_on = getenv("CODD_TILE_WARP_STAGE") ? atoi(getenv("CODD_TILE_WARP_STAGE")) : 1;  // dev A/B
   const size_t lds = (size_t)C * 4 * Wt * sizeof(float);
-  if (stage_on && lds <= 96 * 1024 && ((uintptr_t)fr & 15) == 0) {
+  if (lds <= 96 * 1024 && ((uintptr_t)fr & 15) == 0) {
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute((const void*)tile_warp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return CODD_EUNSUPPORTED;
@@ -385,3 +383,16 @@ extern "C" int codd_hyp_select(const float* upd, codd_view cur, codd_view prev, 
 }
 
 extern "C" int codd_abi_version(void) { return CODD_ABI_VERSION; }
+
+// ---- option table (include/codd_hip.h: the library's only process-wide state; nothing is read from the environment) ----
+static int g_opt[CODD_OPT_COUNT] = {192, 5};
+int codd_opt(int key) { return g_opt[key]; }
+extern "C" int codd_get_option(int key) { return key >= 0 && key < CODD_OPT_COUNT ? g_opt[key] : CODD_EINVAL; }
+extern "C" int codd_set_option(int key, int value) {
+  if (key < 0 || key >= CODD_OPT_COUNT) return CODD_EINVAL;
+  if (key == CODD_OPT_GN_Q4 && (value < 16 || value > 4096)) return CODD_EINVAL;
+  if (key == CODD_OPT_GN_BUILDER && value != 3 && value != 5) return CODD_EINVAL;
+  const int prev = g_opt[key];
+  g_opt[key] = value;
+  return prev;
+}

@@ -462,9 +462,6 @@ class RAFT3D(ops.RuntimeState, nn.Module):
             self._side = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
         cur = torch.cuda.current_stream(dev)
         out = {}
-        from . import hrnet as _hr
-        if _hr.FORK_BRANCHES and hasattr(self.cnet[0], "fork") and getattr(self.cnet[0], "fork_branches", True):
-            self.cnet[0].fork(dev).prefork(cur)  # HRNet's branch streams join the frame graph through THIS stream
         for key, stream, fn in (("fmap", self._side[0], self.fnet), ("netinp", self._side[1], self.context)):
             stream.wait_stream(cur)
             with torch.cuda.stream(stream):

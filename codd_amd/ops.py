@@ -552,7 +552,7 @@ def conv2d(x, pc, x2=None, stride=1, pad=0, dil=1, act="none", res1=None, res2=N
     mb = cfg[3] if len(cfg) > 3 else pc.mb
     layout = cfg[4] if len(cfg) > 4 else 0
     p.terms = 0
-    p.wpacked = pc.packed(ck, mb, 1 if layout == 3 else layout).data_ptr()  # (layout 3 = layout 1 weights, persistent kernel)
+    p.wpacked = pc.packed(ck, mb, layout).data_ptr()
     p.mb, p.npb, p.nw, p.ck, p.layout = mb, npb, nw, ck, layout
     heur = (key, (Hout, Wout, B, sy, sx, dy, dx, pl))
     if _DEFERRED is not None and layout == 1 and npb == 1 and nw == 4 and mb == 1:
@@ -598,12 +598,6 @@ def _db_cfg_ok(lib, p, c, sig):
 MULTI_CONV = _os.environ.get("CODD_MULTI_CONV", "1") == "1"  # (A/B switch of conv2d_multi)
 MULTI_DEEP_FIRST = _os.environ.get("CODD_MULTI_DEEP_FIRST", "1") == "1"  # (A/B: job order inside a multi-job launch)
 MULTI_MB = int(_os.environ.get("CODD_MULTI_MB", "1"))  # 16-channel blocks per workgroup of a multi-job launch (1 | 2)
-# tuner candidates on the persistent quad kernel (layout 3: weights resident in LDS, workgroups walk the tiles).  OFF:
-# measured on MI355X (tools/time_persist.py, profiles/r03_persist_times.log) it LOSES to the per-tile kernel on every
-# big HITNet layer it was written for (16->16 3x3 at 576x960: 59.8 vs 50.5 us; 32->32 at 288x480: 54.4 vs 47.3) --
-# three small workgroups per CU overlap their staging better than one or two persistent ones with a register prefetch
-PERSIST_CONV = _os.environ.get("CODD_PERSIST_CONV", "0") == "1"
-
 
 _DEFERRED = None
 
@@ -951,14 +945,6 @@ def _autotune(lib, p, pc, default, with_time=False):
                 for ck in (16, 32):
                     if ck <= max(16, cin_pad):
                         cands.append((npb, nw, ck, mb, 1))
-        # persistent quad kernel (layout 3): the whole weight tensor is one chunk and one channel group
-        if PERSIST_CONV and cin_pad <= 32 and not pc.deconv:
-            ck = 16 if cin_pad <= 16 else 32
-            for mb in (1, 2):
-                if pc.cout_eff <= 16 * mb:
-                    for npb in (1, 2, 4):
-                        cands.append((npb, 4, ck, mb, 3))
-                    break
     stream = _stream()
     # the timed launches write into a scratch copy of the output buffer: the real one may alias an operand
     # (in-place accumulation "out = conv(x) + out"), which repeated launches would accumulate over and over
@@ -970,7 +956,7 @@ def _autotune(lib, p, pc, default, with_time=False):
     best, best_t, t_default = default, float("inf"), None
     for (npb, nw, ck, mb, layout) in [default] + cands:  # the heuristic is timed twice (first = warm-up of clocks / caches)
         try:
-            p.wpacked = pc.packed(ck, mb, 1 if layout == 3 else layout).data_ptr()
+            p.wpacked = pc.packed(ck, mb, layout).data_ptr()
         except Exception:
             continue
         p.mb, p.npb, p.nw, p.ck, p.layout = mb, npb, nw, ck, layout
@@ -999,115 +985,6 @@ def _autotune(lib, p, pc, default, with_time=False):
     AUTOTUNE_LOG.append(("%dx%d k%dx%d %d->%d out %dx%d" % (p.sy, p.sx, pc.kh, pc.kw, pc.cin, pc.cout, p.Hout, p.Wout),
                          default, None if t_default is None else t_default * 1e3, best, best_t * 1e3))
     return (best, best_t) if with_time else best
-
-
-# ----------------------------------------------------------------------------------------- conv chains
-# LDS-resident chains (codd_conv_chain) are OFF by default.  Measured on MI355X (tools/time_chain.py, profiles/
-# r03_chain_times.log; DESIGN.md round-3 findings): a chain only beats its layers as separate launches where those are
-# launch-bound -- maps of up to 36 x 60 pixels (TileUpdate0-2: 64 vs 80 us for six layers; the three 3x3 convolutions
-# behind down4: 35 vs 40 us) -- and inside the captured frame graph even that gain vanishes (HITNetMF stereo-only 352
-# with vs 358 frames/s without).  From 72 x 120 up the per-tile halo recompute, a wave's serial (tap, octet) MFMA chain
-# and the single resident workgroup per CU (LDS + 200 registers) cost far more than the launches save (144 x 240: 261
-# vs 104 us; a 32-channel residual pair at 288 x 480: 135 vs 83 us).  CODD_CHAINS=1 enables them for maps of up to
-# CODD_CHAIN_MAX_PIXELS pixels (tests run both schedules).
-USE_CHAINS = _os.environ.get("CODD_CHAINS", "0") == "1"
-CHAIN_MAX_PIXELS = int(_os.environ.get("CODD_CHAIN_MAX_PIXELS", str(36 * 60)))
-
-
-def use_chain(H, W):
-    return USE_CHAINS and H * W <= CHAIN_MAX_PIXELS
-
-
-class PackedChain:
-    """A chain of small stride-1 convolutions packed for codd_conv_chain (include/codd_hip.h): ONE launch, the
-    intermediates stay in LDS.  ``layers``: dicts(w [cout,cin,k,k], b [cout] | None, dil, act, src, dst, res) -- src /
-    dst / res are LDS buffer ids (0 | 1), -1 = global (first src, last dst) or no residual; ``stage``: the buffer the
-    input tile is staged into when the first layer is a 3x3."""
-
-    TILES = ((8, 8), (8, 16), (16, 16), (4, 16), (16, 32), (4, 8), (4, 4), (2, 8))
-
-    def __init__(self, layers, stage=0):
-        lib = _abi.load()
-        assert 1 <= len(layers) <= _abi.CHAIN_MAX_LAYERS
-        self.layers, self.stage = [], stage
-        sizes = []
-        for L in layers:
-            w = L["w"].detach().float().contiguous()
-            _require_gpu(w)
-            cout, cin, k, _ = w.shape
-            n = lib.codd_chain_layer_size(cout, cin, k)
-            if n <= 0:
-                raise _abi.CoddHipError("conv chain: unsupported layer %dx%d %d->%d" % (k, k, cin, cout))
-            sizes.append(n)
-            self.layers.append(dict(cin=cin, cout=cout, k=k, dil=L.get("dil", 1), act=ACT[L.get("act", "none")],
-                                    src=L["src"], dst=L["dst"], res=L.get("res", -1)))
-        self.buf = torch.empty(sum(sizes), device=layers[0]["w"].device, dtype=torch.float32)
-        off = 0
-        for L, d, n in zip(layers, self.layers, sizes):
-            w = L["w"].detach().float().contiguous()
-            b = None if L.get("b") is None else L["b"].detach().float().contiguous()
-            d["wofs"] = off
-            _abi.check(lib.codd_chain_pack_layer(w.data_ptr(), None if b is None else b.data_ptr(), d["cout"], d["cin"],
-                                                 d["k"], self.buf.data_ptr() + 4 * off, _stream()), "chain_pack_layer")
-            off += n
-        self.cin, self.cout = self.layers[0]["cin"], self.layers[-1]["cout"]
-        self._tiles = {}
-
-    def fill(self, p):
-        p.nlayers, p.stage, p.wpacked = len(self.layers), self.stage, self.buf.data_ptr()
-        for i, d in enumerate(self.layers):
-            L = p.layer[i]
-            L.cin, L.cout, L.k, L.dil, L.act, L.src, L.dst, L.res, L.wofs = (
-                d["cin"], d["cout"], d["k"], d["dil"], d["act"], d["src"], d["dst"], d["res"], d["wofs"])
-
-    def tile(self, lib, p, B, H, W):
-        """Output tile of a workgroup: the accepted candidate with the fewest MFMAs on the busiest CU (halo recompute
-        against dispatch rounds over the 256 CUs)."""
-        key = (B, H, W)
-        if key not in self._tiles:
-            best = None
-            for th, tw in self.TILES:
-                p.th, p.tw = th, tw
-                if lib.codd_conv_chain_check(C.byref(p)) != 0:
-                    continue
-                halo = sum(d["dil"] * (d["k"] // 2) for d in self.layers)
-                m, per = 0, 0
-                for d in self.layers:
-                    m += d["dil"] * (d["k"] // 2)
-                    npx = (th + 2 * (halo - m)) * (tw + 2 * (halo - m))
-                    per += -(-npx // 32) * 2 * d["k"] ** 2 * 2 * -(-d["cin"] // 8) * -(-d["cout"] // 16)
-                wgs = -(-H // th) * -(-W // tw) * B
-                cost = -(-wgs // 256) * per
-                if best is None or cost < best[0]:
-                    best = (cost, th, tw)
-            if best is None:
-                raise _abi.CoddHipError("conv chain: no tile fits the LDS budget")
-            self._tiles[key] = best[1:]
-        return self._tiles[key]
-
-
-def conv_chain(x, pch, x2=None, res1=None, out=None, cout_store=None, tile=None):
-    """Run the packed chain on (x | x2) -> out [B, cout_store, H, W] (tensor or Slice); ``res1`` (tensor / Slice) is
-    added to the last layer's result before its activation."""
-    lib = _abi.load()
-    xs = _as_slice(x)
-    _require_gpu(xs.buf)
-    B, C0, H, W = xs.shape
-    C1 = 0 if x2 is None else _as_slice(x2).c
-    assert C0 + C1 == pch.cin, (C0, C1, pch.cin)
-    cs = pch.cout if cout_store is None else cout_store
-    if out is None:
-        out = torch.empty(B, cs, H, W, device=xs.buf.device, dtype=torch.float32)
-    os_ = _as_slice(out)
-    assert os_.shape == (B, cs, H, W), (os_.shape, (B, cs, H, W))
-    p = _abi.ChainParams()
-    p.in0, p.in1, p.C0, p.C1, p.B, p.H, p.W = _view(xs), _view(x2), C0, C1, B, H, W
-    pch.fill(p)
-    p.res1 = _view(res1)
-    p.out, p.out_ctot, p.out_coff, p.cout_store = os_.buf.data_ptr(), os_.buf.shape[1], os_.coff, cs
-    p.th, p.tw = pch.tile(lib, p, B, H, W) if tile is None else tile
-    _abi.check(_launch_chain(lib, p, _stream()), "codd_conv_chain")
-    return out
 
 
 # ---------------------------------------------------------------------------- rolling-window convolutions
@@ -1216,11 +1093,6 @@ def conv_roll(x, pr, x2=None, out=None, cout_store=None, rh=None):
 def _launch_roll(lib, p, stream):
     """Single choke point of every rolling-window launch (bench.py wraps it with HIP events)."""
     return lib.codd_conv_roll(C.byref(p), stream)
-
-
-def _launch_chain(lib, p, stream):
-    """Single choke point of every chain launch (bench.py wraps it with HIP events)."""
-    return lib.codd_conv_chain(C.byref(p), stream)
 
 
 # ----------------------------------------------------------------------------------------- stereo
@@ -1610,22 +1482,6 @@ def add_relu(a, b=None, relu=True, out=None):
         out = torch.empty_like(a)
     _abi.check(lib.codd_add_relu(a.data_ptr(), None if b is None else b.data_ptr(), a.numel(), int(relu),
                                  out.data_ptr(), _stream()), "add_relu")
-    return out
-
-
-def hr_fuse_sum(terms, out_hw, relu=True):
-    """relu(sum of ``terms`` in order) at size ``out_hw``; a smaller term is bilinearly up-sampled on the fly
-    (align_corners False) -- the summation of an HRModule fuse layer in ONE launch (codd_hr_fuse_sum)."""
-    lib = _abi.load()
-    B, Cc = terms[0].shape[:2]
-    H, W = out_hw
-    arr = (_abi.HrTerm * len(terms))()
-    for k, t in enumerate(terms):
-        _require_gpu(t)
-        assert t.is_contiguous() and t.dtype == torch.float32 and t.shape[:2] == (B, Cc)
-        arr[k].ptr, arr[k].h, arr[k].w = t.data_ptr(), t.shape[2], t.shape[3]
-    out = torch.empty(B, Cc, H, W, device=terms[0].device, dtype=torch.float32)
-    _abi.check(lib.codd_hr_fuse_sum(arr, len(terms), B, Cc, H, W, int(relu), out.data_ptr(), _stream()), "hr_fuse_sum")
     return out
 
 

@@ -44,26 +44,6 @@ def invalidate_packed(module):
         m.__dict__.pop("_codd_packed_cat", None)
 
 
-def chain(owner, key, specs, stage=0):
-    """ops.PackedChain (one launch, intermediates in LDS: csrc/chain.hip) of the nn.Conv2d modules in ``specs`` =
-    [(conv, dict(src, dst[, res, act])), ...]; cached on ``owner`` per parameter version like ``packed``.  A spec may
-    carry ``cout_keep`` (leading output channels of that conv that are computed)."""
-    mods = [m for m, _ in specs]
-    ver = tuple((m.weight.data_ptr(), m.weight._version, None if m.bias is None else m.bias._version) for m in mods)
-    cache = owner.__dict__.setdefault("_codd_packed_cat", {})
-    ent = cache.get(("chain", key))
-    if ent is None or ent[0] != ver:
-        layers = []
-        for m, sp in specs:
-            sp = dict(sp)
-            keep = sp.pop("cout_keep", None)
-            assert tuple(m.stride) == (1, 1) and m.kernel_size[0] == m.kernel_size[1] and m.dilation[0] == m.dilation[1]
-            layers.append(dict(w=m.weight[:keep] if keep else m.weight, b=None if m.bias is None else (m.bias[:keep] if keep else m.bias),
-                               dil=m.dilation[0], **sp))
-        ent = cache[("chain", key)] = (ver, ops.PackedChain(layers, stage=stage), tuple(mods))
-    return ent[1]
-
-
 def roll(owner, key, specs, residual=False):
     """ops.PackedRoll (one rolling-window launch: csrc/conv_roll.hip) of the nn.Conv2d modules in ``specs`` =
     [(conv, act), ...] (one 3x3, two 3x3 or 1x1 -> 3x3); cached on ``owner`` per parameter version like ``packed``."""
@@ -75,14 +55,6 @@ def roll(owner, key, specs, residual=False):
         ent = cache[("roll", key)] = (ver, ops.PackedRoll([dict(w=m.weight, b=m.bias, act=a) for m, a in specs],
                                                           residual=residual), tuple(mods))
     return ent[1]
-
-
-def _rb(blk, a, b, act="lrelu", first=False, last=False):
-    """Chain specs of a BasicBlock whose input lives in LDS buffer ``a``: conv1 a -> b, conv2 b -> a (+ a).
-    ``first``: the block opens the chain (its input is the chain input, staged into buffer ``a``); ``last``: conv2
-    writes the chain output (the residual still comes from buffer ``a``)."""
-    return [(blk.conv1[0][0], dict(src=-1 if first else a, dst=b, act=act)),
-            (blk.conv2[0], dict(src=b, dst=-1 if last else a, res=a, act=act))]
 
 
 def cv(m, x, x2=None, act="none", **kw):
@@ -141,10 +113,6 @@ class HITUNet(nn.Module):
 
         def up_merge(up, merge, skip, t):
             u = ops.conv2d(t, packed(up[0], deconv=True), act="lrelu")
-            if ops.use_chain(*skip.shape[2:]):  # 1x1 (skip | up) -> 3x3 -> 3x3 in one launch (backbone.py:24-39)
-                pch = chain(merge, "merge", [(merge[0], dict(src=-1, dst=0, act="lrelu")), (merge[2], dict(src=0, dst=1, act="lrelu")),
-                                             (merge[4], dict(src=1, dst=-1, act="lrelu"))])
-                return ops.conv_chain(skip, pch, x2=u)
             if ops.use_roll(merge[0].out_channels, *skip.shape):
                 # 1x1 (skip | up) -> 3x3 as one rolling-window launch, the last 3x3 as another
                 t = ops.conv_roll(skip, roll(merge, "head", [(merge[0], "lrelu"), (merge[2], "lrelu")]), x2=u)
@@ -163,16 +131,9 @@ class HITUNet(nn.Module):
         x1 = seq(self.down1, x0)
         x2 = seq(self.down2, x1)
         x3 = seq(self.down3, x2)
-        if ops.use_chain(x3.shape[2] // 2, x3.shape[3] // 2):  # the three 3x3 convolutions behind down4's strided conv: one launch
-            d4 = self.down4
-            x4 = cv(d4[0][0], x3, act="lrelu")
-            x4 = ops.conv_chain(x4, chain(d4, "tail", [(d4[0][2], dict(src=-1, dst=1, act="lrelu")),
-                                                       (d4[1], dict(src=1, dst=0, act="lrelu")),
-                                                       (d4[3], dict(src=0, dst=-1, act="lrelu"))], stage=0))
-        else:
-            x4 = seq(self.down4[0], x3)
-            x4 = cv(self.down4[1], x4, act="lrelu")
-            x4 = cv(self.down4[3], x4, act="lrelu")
+        x4 = seq(self.down4[0], x3)
+        x4 = cv(self.down4[1], x4, act="lrelu")
+        x4 = cv(self.down4[3], x4, act="lrelu")
         yield x4
         u4 = up_merge(self.up4, self.merge4, x3, x4)
         yield u4
@@ -311,10 +272,6 @@ class TileUpdate0(nn.Module):
         aug = hyp.buf  # [hyp 16 | local cv 16]
         w, _ = ops.tile_warp_cost(fl, fr, hyp)
         cv(self.decrease[0], w, act="lrelu", out=Slice(aug, 16, 16))
-        if ops.use_chain(*aug.shape[2:]):  # conv0 -> resblock0 -> resblock1 -> lastconv (+ hyp, relu on d): one launch
-            pch = chain(self, "update", [(self.conv0[0], dict(src=-1, dst=0, act="lrelu"))] + _rb(self.resblock0[0], 0, 1) +
-                        _rb(self.resblock1[0], 0, 1) + [(self.lastconv, dict(src=0, dst=-1, act="relu_ch0"))])
-            return [ops.conv_chain(aug, pch, res1=hyp)]
         t = cv(self.conv0[0], aug, act="lrelu")
         t = self.resblock0[0].run(t)
         t = self.resblock1[0].run(t)
@@ -340,15 +297,10 @@ class TileUpdate(nn.Module):
         with ops.deferred_convs():  # (two independent 1x1 convolutions: one multi-job launch, same bits)
             cv(self.decrease[0], w0, act="lrelu", out=Slice(aug, 16, 16))
             cv(self.decrease[0], w1, act="lrelu", out=Slice(aug, 48, 16))
-        if ops.use_chain(*aug.shape[2:]):
-            pch = chain(self, "update", [(self.conv0[0], dict(src=-1, dst=0, act="lrelu"))] + _rb(self.resblock0[0], 0, 1) +
-                        _rb(self.resblock1[0], 0, 1) + [(self.lastconv, dict(src=0, dst=-1))])
-            upd = ops.conv_chain(aug, pch)
-        else:
-            t = cv(self.conv0[0], aug, act="lrelu")
-            t = self.resblock0[0].run(t)
-            t = self.resblock1[0].run(t)
-            upd = cv(self.lastconv, t)
+        t = cv(self.conv0[0], aug, act="lrelu")
+        t = self.resblock0[0].run(t)
+        t = self.resblock1[0].run(t)
+        upd = cv(self.lastconv, t)
         B, _, h, w = upd.shape
         out = torch.empty(B, 16, h, w, device=upd.device, dtype=torch.float32)
         return [ops.hyp_select(upd, hyp, up, out)]
@@ -366,8 +318,6 @@ class PostTileUpdate(nn.Module):
         self._final = final
 
     def forward(self, fl, prev):
-        if ops.use_chain(*fl.shape[2:]):
-            return self._forward_chains(fl, prev)
         if ops.use_roll(self.conv1[0].out_channels, *fl.shape):
             t = ops.conv_roll(fl, roll(self, "head", [(self.conv1[0], "lrelu"), (self.conv1[2], "lrelu")]), x2=prev)
         else:
@@ -383,24 +333,6 @@ class PostTileUpdate(nn.Module):
         return cv(self.lastconv, t, res1=prev, act="relu_ch0")
 
 
-def _post_chains(self, fl, prev):
-    """PostTileUpdate / FinalTileUpdate as LDS-resident chains (propagation.py:251-333): [1x1 (fea | prev) -> 3x3 ->
-    resblock 0], one chain per middle resblock (the dilation-3 one has a 6-pixel halo of its own), [last resblock ->
-    lastconv + prev, relu on d]: 4 (3) launches instead of 11 (7)."""
-    blks = [b[0] for b in self.resblocks]
-    t = ops.conv_chain(fl, chain(self, "head", [(self.conv1[0], dict(src=-1, dst=0, act="lrelu")),
-                                                (self.conv1[2], dict(src=0, dst=1, act="lrelu"))] + _rb(blks[0], 1, 0, last=True)), x2=prev)
-    for i, blk in enumerate(blks[1:-1], 1):
-        t = ops.conv_chain(t, chain(self, "rb%d" % i, _rb(blk, 0, 1, first=True, last=True), stage=0))
-    tail = _rb(blks[-1], 0, 1, first=True)
-    if self._final:  # only channel 0 of the 3-channel output is consumed (propagation.py:372): relu(prev_d + out0)
-        pch = chain(self, "tail", tail + [(self.lastconv, dict(src=0, dst=-1, act="relu", cout_keep=1))], stage=0)
-        return ops.conv_chain(t, pch, res1=Slice(_buf(prev), _off(prev), 1))
-    pch = chain(self, "tail", tail + [(self.lastconv, dict(src=0, dst=-1, act="relu_ch0"))], stage=0)
-    return ops.conv_chain(t, pch, res1=prev)
-
-
-PostTileUpdate._forward_chains = _post_chains
 
 
 class FinalTileUpdate(PostTileUpdate):

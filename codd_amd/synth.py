@@ -54,19 +54,124 @@ def fill_tensor(name, shape, gain=1.0):
     return torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
 
 
-def fill_state_dict(keys_and_shapes, gain=1.0):
-    """``keys_and_shapes``: iterable of (name, shape) or a module / state_dict."""
+# --------------------------------------------------------------------------- conditioned weights (round 6)
+# The random filler above gives a network that is NOT a stereo matcher: its strided random convolutions alias, its
+# hypothesis selection (reference propagation.py:225-240) is a coin toss between the levels and its residual heads add
+# ~1 px of noise per stage -- disparity error 23-36 px on the synthetic video, coarse-tile arg-mins on near-ties in
+# 7-10 % of the frames, Fusion's sigmoid heads saturated at 0 / 1.  Two correct fp32 evaluations of such a network
+# disagree by whole tiles.  ``mode="conditioned"`` is a closed-form weight set, still keyed by
+# state-dict name and made of nothing but integer patterns and the reproducible RandomState draws (no BLAS, no QR: the
+# same bits on every machine), under which HITNet IS a coarse-to-fine block matcher:
+#   * backbone: anti-aliased decimation ([1 3 3 1] x [1 3 3 1] / 64 per channel on the 4x4 stride-2 convolutions),
+#     nearest up-sampling on the 2x2 deconvolutions, merges that pass 0.7 x skip + 0.3 x up-path, identity 3x3
+#     layers -- each plus a 5 % random perturbation on every tap, so every tap of every kernel still matters;
+#   * hypothesis selection driven by the local matching cost: `decrease` channel 0 = mean warping cost of the
+#     hypothesis (k = 0), `conv0` channels 0 / 1 = +-(cost_cur - cost_prev), `lastconv` confidence rows read them
+#     through the (down-weighted) residual blocks: the cheaper hypothesis wins, as in a trained network;
+#   * residual heads (`lastconv`) at 0.005 instead of 0.02: sub-pixel perturbations of the block matcher's result;
+#   * Fusion's two sigmoid heads (`weight_head.1`, `forget_head.2`) scaled so that their logits stay inside |x| < 2.
+# Measured on the oracle (tools/cond_probe.py): tile initialisation within one disparity step of the ground truth on
+# 99.7 % of the matchable tiles at every level, final median error 0.33 px, no selection flips under 1e-5 input noise.
+_COND = dict(eps=0.05, skip=0.7, up=0.3, res=0.005, g_res=0.3, gamma=1.0, weight_head=0.01, weight_bias=1.5, forget_head=0.2)
+_LP4 = np.outer([1.0, 3.0, 3.0, 1.0], [1.0, 3.0, 3.0, 1.0]) / 64.0
+
+
+def _rnd(name, shape, gain):
+    return gain * _rs(name).standard_normal(shape) / math.sqrt(int(np.prod(shape[1:])))
+
+
+def _conditioned(name, shape, gain):
+    """float64 array for state-dict entry ``name`` under mode="conditioned", or None: use the random filler."""
+    C = _COND
+    leaf = name.rsplit(".", 1)[-1]
+    if name == "fusion.weight_head.1.weight":
+        return _rnd(name, shape, gain * C["weight_head"])
+    if name == "fusion.weight_head.1.bias":
+        return np.full(shape, C["weight_bias"])
+    if name == "fusion.forget_head.2.weight":
+        return _rnd(name, shape, gain * C["forget_head"])
+    if not name.startswith("stereo."):
+        return None
+    n = name[len("stereo."):]
+    if leaf == "bias":
+        if n.startswith("backbone.") or ".decrease." in n or ".conv0." in n:
+            return np.zeros(shape)
+        if ".lastconv." in n and shape == (34,):
+            v = 0.05 * _rs(name).standard_normal(shape)
+            v[:2] = 0.0
+            return v
+        return None
+    if leaf != "weight":
+        return None
+    if n.startswith("backbone."):
+        k = n[len("backbone."):-len(".weight")]
+        if k == "conv1.0":
+            return _rnd(name, shape, 1.0)
+        w = _rnd(name, shape, C["eps"])
+        if k.startswith("up"):  # ConvTranspose2d weight [Cin, Cout, 2, 2]: nearest up-sampling, channel i -> i
+            for j in range(shape[1]):
+                w[j % shape[0], j] += 1.0
+            return w
+        co, ci, kh, _ = shape
+        for j in range(co):
+            if kh == 4 and j < ci:  # anti-aliased decimation
+                w[j, j] += _LP4
+            elif kh == 4:  # channel growth: low-passed difference of two input channels
+                w[j, (j * 5 + 1) % ci] += 0.75 * _LP4
+                w[j, (j * 7 + 3) % ci] -= 0.75 * _LP4
+            elif kh == 1:  # merge.0 over cat(skip, up)
+                w[j, j, 0, 0] += C["skip"]
+                w[j, ci // 2 + j, 0, 0] += C["up"]
+            else:
+                w[j, j, 1, 1] += 1.0
+        return w
+    if ".tile_conv" in n and n.endswith(".2.weight"):
+        w = _rnd(name, shape, C["eps"])
+        for j in range(shape[0]):
+            w[j, j, 0, 0] += 1.0
+        return w
+    if n.endswith(".decrease.0.weight"):  # in = [|fea| 16, cost(k=-1) 16, cost(k=0) 16, cost(k=+1) 16]
+        w = _rnd(name, shape, 1.0)
+        for o, base in ((0, 32), (1, 16), (2, 48)):
+            w[o] = 0.0
+            w[o, base:base + 16, 0, 0] = 1.0 / 16
+        return w
+    if n.endswith(".conv0.0.weight") and shape[1] == 64:  # in = [hyp 16, cv_cur 16, up_prev 16, cv_prev 16]
+        w = _rnd(name, shape, 1.0)
+        w[0:2] = 0.0
+        w[0, 16, 0, 0], w[0, 48, 0, 0] = C["gamma"], -C["gamma"]
+        w[1, 16, 0, 0], w[1, 48, 0, 0] = -C["gamma"], C["gamma"]
+        return w
+    if ".resblock" in n and any(f".tile_update{i}." in n for i in range(1, 5)):
+        return _rnd(name, shape, C["g_res"])
+    if n.endswith(".lastconv.weight"):
+        w = _rnd(name, shape, gain * C["res"])
+        if shape[0] == 34:  # rows 0 / 1 = confidence of (up-sampled previous, current): read conv0's channels 0 / 1
+            w[0:2] = 0.0
+            w[0, 0, 1, 1] = w[1, 1, 1, 1] = 1.0
+        return w
+    return None
+
+
+def fill_state_dict(keys_and_shapes, gain=1.0, mode="random"):
+    """``keys_and_shapes``: iterable of (name, shape) or a module / state_dict.  ``mode``: "random" (every golden up to
+    round 5) or "conditioned" (the block-matcher weight set above; entries it does not design come from the random filler)."""
+    assert mode in ("random", "conditioned"), mode
     if hasattr(keys_and_shapes, "state_dict"):
         keys_and_shapes = keys_and_shapes.state_dict()
     if isinstance(keys_and_shapes, dict):
         keys_and_shapes = [(k, tuple(v.shape)) for k, v in keys_and_shapes.items()]
-    return {k: fill_tensor(k, s, gain) for k, s in keys_and_shapes}
+    out = {}
+    for k, s in keys_and_shapes:
+        v = _conditioned(k, tuple(int(x) for x in s), gain) if mode == "conditioned" else None
+        out[k] = fill_tensor(k, s, gain) if v is None else torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+    return out
 
 
-def load_synthetic_weights(module, gain=1.0):
+def load_synthetic_weights(module, gain=1.0, mode="random"):
     """Fill every parameter / buffer of ``module`` in place from the deterministic filler."""
     sd = module.state_dict()
-    new = fill_state_dict(sd, gain)
+    new = fill_state_dict(sd, gain, mode)
     module.load_state_dict({k: new[k].to(sd[k].dtype) for k in sd}, strict=True)
     return module
 
@@ -113,15 +218,18 @@ def _texture_waves(x, y, ch):
     return out
 
 
-def disparity_field(H, W, t=0.0, dmin=1.0, dmax=48.0):
-    """Smooth positive disparity field [H, W] (px) at time ``t``."""
+def disparity_field(H, W, t=0.0, dmin=1.0, dmax=48.0, left_taper=0.0):
+    """Smooth positive disparity field [H, W] (px) at time ``t``.  ``left_taper`` > 0: the field falls linearly to 0
+    over the first ``left_taper`` columns, so that every left pixel has its match INSIDE the right image (x - d >= 0)
+    and no unmatched band with arbitrary arg-mins exists at the left border."""
     y, x = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32),
                           indexing="ij")
     s = 0.5 + 0.25 * torch.sin(2 * math.pi * (x / W) + 0.1 * t) + 0.25 * torch.cos(2 * math.pi * (y / H) * 1.5)
-    return dmin + (dmax - dmin) * s.clamp(0, 1)
+    d = dmin + (dmax - dmin) * s.clamp(0, 1)
+    return d * (x / left_taper).clamp(0, 1) if left_taper > 0 else d
 
 
-def stereo_sequence(H, W, MF, dmax=48.0, flow=(0.75, 0.25), texture="sines", dphase=1.0):
+def stereo_sequence(H, W, MF, dmax=48.0, flow=(0.75, 0.25), texture="sines", dphase=1.0, left_taper=0.0):
     """Synthetic stereo video: returns (img, r_img) float32 [1, MF, 3, H, W] and gt disparity
     [1, MF, 1, H, W].  Left frame t samples the texture at (x - t*fx, y - t*fy); the right
     image samples the same texture at (x + d(x, y)) so that right(x - d) ~ left(x).
@@ -133,7 +241,7 @@ def stereo_sequence(H, W, MF, dmax=48.0, flow=(0.75, 0.25), texture="sines", dph
                           indexing="ij")
     ls, rs, ds = [], [], []
     for t in range(MF):
-        d = disparity_field(H, W, float(t) * dphase, dmax=dmax)  # (dphase: speed of the disparity field's drift, 0.1 rad/frame * dphase)
+        d = disparity_field(H, W, float(t) * dphase, dmax=dmax, left_taper=left_taper)  # (dphase: speed of the disparity field's drift, 0.1 rad/frame * dphase)
         xs, ys = x - t * flow[0], y - t * flow[1]
         left = torch.stack([_texture(xs, ys, c) for c in range(3)])
         right = torch.stack([_texture(xs + d, ys, c) for c in range(3)])

@@ -15,8 +15,10 @@
  *     buffers instead of torch.cat;
  *   - every function enqueues on `stream` (hipStream_t as void*) and returns immediately:
  *     0 on success, a negative CODD_E* code on bad arguments, a positive hipError_t otherwise;
- *   - no global state, no allocation, no host synchronisation: safe under hipGraph capture and
- *     callable concurrently on distinct streams.
+ *   - no allocation, no host synchronisation, nothing read from the process environment: safe under hipGraph
+ *     capture and callable concurrently on distinct streams.  The ONLY process-wide state is the small option table
+ *     behind codd_set_option() below; every option defaults to the shipped configuration and the host library sets
+ *     one only where a test asks for it.
  */
 #ifndef CODD_HIP_H
 #define CODD_HIP_H
@@ -25,11 +27,23 @@
 extern "C" {
 #endif
 
-#define CODD_ABI_VERSION 11
+#define CODD_ABI_VERSION 12
 
 #define CODD_OK 0
 #define CODD_EINVAL (-1)
 #define CODD_EUNSUPPORTED (-2)
+
+/* Options (ABI v12; they replace the CODD_* environment switches the library used to read -- VERDICT r5 item 7).
+ *   CODD_OPT_GN_Q4       neighbours per workgroup of the Gauss-Newton builder (default 192, >= 16): the grouping of its
+ *                        partial sums, i.e. another fp32 summation order of the same normal equations; the parity tests
+ *                        use 256 as a re-association probe.  Changes codd_se3_gn_scratch(): set it before sizing scratch.
+ *   CODD_OPT_GN_BUILDER  5 (default): the pixel's own embedding in LDS (125 VGPRs); 3: in registers (157 VGPRs) -- the
+ *                        bit-identity reference of the shipped builder.
+ * codd_set_option returns the previous value, or CODD_EINVAL for an unknown key / out-of-range value; not thread-safe
+ * against concurrent launches (set options before launching). */
+enum { CODD_OPT_GN_Q4 = 0, CODD_OPT_GN_BUILDER = 1, CODD_OPT_COUNT = 2 };
+int codd_set_option(int key, int value);
+int codd_get_option(int key);
 
 /* activation codes for the conv epilogue */
 enum { CODD_ACT_NONE = 0, CODD_ACT_LRELU02 = 1, CODD_ACT_RELU = 2, CODD_ACT_SIGMOID = 3,
@@ -110,9 +124,7 @@ typedef struct {
   int nw;  /* waves (= 16-pixel tile rows) per workgroup: 0 or 4 (default), or 2 / 8 / 9 (npb 1 only) */
   int ck;  /* input channels staged per LDS chunk (multiple of 4) */
   int layout; /* 0: weights packed by codd_conv2d_pack_weights; 1: quad layout (codd_conv2d_pack_weights_quad;
-                 ck 16 or 32, x-stride <= 2, 16-byte aligned rows); 3: layout 1 on the PERSISTENT kernel (whole weight
-                 tensor = one chunk and one channel group: Cin <= ck, Cout <= 16 * mb, mb <= 2, nw 4: workgroups keep the
-                 weights in LDS and walk the tiles, prefetching the next tile's input); 2: split-bf16 kernel (weights packed by
+                 ck 16 or 32, x-stride <= 2, 16-byte aligned rows); 2: split-bf16 kernel (weights packed by
                  codd_conv2d_pack_weights_bf16 for (mb, ck, terms); here nw = tile rows, npb = 16-pixel units per
                  tile row (1 | 2), ck a multiple of 8) */
   int terms;  /* layout 2: 1 = bf16 operands, 3 = split-bf16 (hi/lo) operands, 16 = fp16 operands, 48 = split-fp16 (CODD_TERMS_*) */
@@ -194,58 +206,6 @@ int codd_conv2d_pack_weights(const float* w, float* wpacked, int Cout, int Cin, 
 int codd_conv2d_pack_weights_ex(const float* w, float* wpacked, int Cout, int Cin, int kh, int kw,
                                 int mb, int ck, long long co_stride, long long ci_stride, float scale,
                                 void* stream);
-
-/* ---------------------------------------------------------------------------------------------
- * LDS-resident convolution CHAIN (exact fp32, v_mfma_f32_16x16x4_f32): a sequence of stride-1 1x1 / 3x3 (dilated)
- * convolutions with <= 64 channels executed by ONE launch.  A workgroup owns a th x tw output tile, keeps every
- * intermediate activation of the tile (plus the halo the remaining layers need, recomputed per tile) in two LDS
- * buffers and only touches global memory for the chain's input, the per-layer weights and the final result.
- * Replaces the launch-bound small-layer chains of the reference: TileUpdate* conv0 -> resblock0 -> resblock1 ->
- * lastconv (propagation.py:124-248), PostTileUpdate conv1 / resblocks / lastconv (propagation.py:251-333), BasicBlock
- * (propagation.py:103-121) and mmseg HRNet BasicBlock pairs (configs/models/codd.py:44-74; BatchNorm folded).
- *
- *   layer l:  y = act_l( conv_l(x_l) + bias_l [+ r_l] ),  x_l = the buffer `src`, y -> the buffer `dst` (0 | 1);
- *             r_l = the buffer `res` at the same pixel (res = -1: none; res == dst is allowed: in-place residual).
- *   Every intermediate is forced to 0 outside the image, i.e. each layer sees the zero padding of a stand-alone
- *   "same" convolution of its input map.
- *   first layer: src = -1 -> the chain input (channel concatenation of in0 | in1) is read from global memory; a 1x1
- *                first layer reads it directly, a 3x3 one has the tile staged into buffer `stage` first (which later
- *                layers may use as a residual source).
- *   last layer:  dst = -1 -> global `out` (channels [0, cout_store) of it), after  + res1 (global view, optional).
- * Weights: one packed block per layer (codd_chain_pack_layer), all in one buffer at float offsets `wofs`.
- * --------------------------------------------------------------------------------------------- */
-#define CODD_CHAIN_MAX_LAYERS 12
-typedef struct {
-  int cin, cout;  /* cin <= 64, cout <= 48 */
-  int k, dil;     /* k = 1 | 3 (square, stride 1, "same" padding dil * (k - 1) / 2) */
-  int act;        /* CODD_ACT_* */
-  int src, dst;   /* LDS buffer ids (0 | 1); -1 = global (first layer's src, last layer's dst) */
-  int res;        /* -1 | buffer id of the residual operand */
-  long long wofs; /* float offset of the layer's packed block inside wpacked (multiple of 4) */
-} codd_chain_layer;
-
-typedef struct {
-  codd_view in0, in1; /* chain input = channels [0,C0) of in0 | [0,C1) of in1 */
-  int C0, C1;
-  int B, H, W;
-  int nlayers;
-  int stage;          /* buffer the input tile is staged into when the first layer is a 3x3 */
-  codd_chain_layer layer[CODD_CHAIN_MAX_LAYERS];
-  const float* wpacked;
-  codd_view res1;     /* added to the last layer's result before its activation (ptr == NULL: none) */
-  float* out;
-  int out_ctot, out_coff;
-  int cout_store;     /* leading channels of the last layer that are stored (<= its cout) */
-  int th, tw;         /* output tile of a workgroup */
-} codd_chain_params;
-
-/* floats of one layer's packed block: [tap][k-step = cin/4][16-channel block][64 lanes] MFMA A operands + bias */
-long long codd_chain_layer_size(int cout, int cin, int k);
-/* w: [cout][cin][k][k] fp32 (device), bias: [cout] or NULL -> dst (device, codd_chain_layer_size floats) */
-int codd_chain_pack_layer(const float* w, const float* bias, int cout, int cin, int k, float* dst, void* stream);
-/* CODD_OK if codd_conv_chain accepts the program (LDS budget, buffer discipline); launches nothing */
-int codd_conv_chain_check(const codd_chain_params* p);
-int codd_conv_chain(const codd_chain_params* p, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * ROLLING-WINDOW convolutions (exact fp32, v_mfma_f32_16x16x4_f32) for HITNet's large-map, few-channel stride-1
@@ -436,16 +396,6 @@ int codd_resize_bilinear_add(const float* in, int B, int C, int Hi, int Wi, int 
 
 /* y = relu?(a + b) elementwise (HRNet fuse sums), n floats. */
 int codd_add_relu(const float* a, const float* b, long long n, int relu, float* y, void* stream);
-/* HRModule fuse layer, summation (mmseg HRModule.forward as built by configs/models/codd.py:44-74):
- * out[B,C,H,W] = relu?( sum_k term_k ) in index order; a term [B,C,h,w] smaller than (H, W) is bilinearly up-sampled
- * (align_corners = False) on the fly -- one launch per output branch instead of one resize / add launch per term. */
-#define CODD_HR_MAX_TERMS 4
-typedef struct {
-  const float* ptr;
-  int h, w;
-} codd_hr_term;
-int codd_hr_fuse_sum(const codd_hr_term* terms, int n, int B, int C, int H, int W, int relu, float* out, void* stream);
-
 /* dst[k][0..n[k]) = src[k][0..n[k]) for k < count <= 8 in ONE launch (the recurrent-state write-back at the end of a
  * captured frame); every n[k] a multiple of 4, every pointer 16-byte aligned. */
 int codd_copy_many(const float* const* src, float* const* dst, const long long* n, int count, void* stream);

@@ -24,7 +24,7 @@ def test_header_symbols_exported_and_bound():
         assert getattr(lib, n) is not None
     for n in _abi.SIGNATURES:
         assert n in names, f"{n} bound but not declared in include/codd_hip.h"
-    assert lib.codd_abi_version() == _abi.ABI_VERSION == 11  # CODD_ABI_VERSION of include/codd_hip.h
+    assert lib.codd_abi_version() == _abi.ABI_VERSION == 12  # CODD_ABI_VERSION of include/codd_hip.h
 
 
 def test_conv_packed_size_is_consistent():

@@ -629,34 +629,6 @@ def test_metric_kernels_kitti_style_ground_truth():
         assert abs(row[i].item() - float(ref[i])) < 2e-5 * max(1.0, abs(float(ref[i]))), (k, row[i].item(), ref[i])
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_pipelined_runner_equals_frame_runner(use_graph):
-    """Overlapping frame t+1's image-only work with frame t's motion + fusion must not change a bit."""
-    from codd_amd import configs, synth
-    from codd_amd.registry import build_estimator
-    from codd_amd.runtime import FrameRunner, PipelinedRunner
-    H, W, MF = 128, 256, 6
-    est = build_estimator(configs.codd(iters=2)).to(DEV).eval()
-    synth.load_synthetic_weights(est, gain=1.4)
-    left, right, _ = synth.stereo_sequence(H, W, MF, 32.0)
-    left, right = left.to(DEV), right.to(DEV)
-    metas = synth.default_metas(H, W)[0]
-    ref_runner = FrameRunner(est, metas, use_graph=use_graph)
-    ref = [ref_runner.step(left[:, f].contiguous(), right[:, f].contiguous()).clone() for f in range(MF)]
-    pr = PipelinedRunner(est, metas, use_graph=use_graph)
-    got = []
-    for f in range(MF):
-        o = pr.push(left[:, f].contiguous(), right[:, f].contiguous())
-        if f == 0:
-            assert o is None
-        else:
-            got.append(o.clone())
-    got.append(pr.flush().clone())
-    torch.cuda.synchronize()
-    for f in range(MF):
-        assert torch.equal(got[f], ref[f]), (f, (got[f] - ref[f]).abs().max().item())
-
-
 def test_fused_geometry_lookup_equals_separate_kernels():
     from codd_amd import ops
     h, w = 24, 40
@@ -875,26 +847,6 @@ def test_scene_flow_evaluation_through_graph_replay_equals_eager():
         assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (k, a, b)
 
 
-def test_split_graphs_equal_single_graph():
-    """FrameRunner(split=True): four graphs on three streams (runtime._capture_split) -- same kernels, same per-chain
-    order as the single graph, so the disparities must agree to rounding of nothing (identical launches)."""
-    from codd_amd import configs, synth
-    from codd_amd.registry import build_estimator
-    from codd_amd.runtime import FrameRunner
-    H, W, MF = 128, 192, 4
-    est = build_estimator(configs.codd(iters=2)).to(DEV).eval()
-    synth.load_synthetic_weights(est, gain=1.4)
-    left, right, _ = synth.stereo_sequence(H, W, MF, 24.0)
-    metas = synth.default_metas(H, W)
-    outs = []
-    for split in (False, True):
-        r = FrameRunner(est, metas[0], use_graph=True, split=split)
-        outs.append([r.step(left[:, f].to(DEV).contiguous(), right[:, f].to(DEV).contiguous()).clone() for f in range(MF)])
-        assert r.graph is not None
-    for a, b in zip(*outs):
-        assert (a - b).abs().max().item() < 1e-5
-
-
 @pytest.mark.parametrize("patch", [3, 5])
 def test_fused_forget_branch_equals_cues_plus_head_convolutions(patch):
     """codd_fusion_forget (cues + merged linear forget head + sigmoid in one launch; the cue tensor is never written)
@@ -1022,121 +974,56 @@ def test_update_block_with_fused_gates_equals_gate_kernels():
             assert rel(b[2], a[2]) < 1e-4
 
 
-def test_hr_fuse_sum_against_torch():
-    """codd_hr_fuse_sum: relu(x_i + same-size terms + bilinearly up-sampled smaller terms), summed in order."""
-    from codd_amd import ops
-    B, Cc, H, W = 2, 18, 36, 60
-    a, b = rnd(B, Cc, H, W, seed=1), rnd(B, Cc, H, W, seed=2)
-    c, d = rnd(B, Cc, H // 2, W // 2, seed=3), rnd(B, Cc, 9, 15, seed=4)
-    up = lambda t: F.interpolate(t, size=(H, W), mode="bilinear", align_corners=False)
-    ref = F.relu(((a + up(c)) + b) + up(d))
-    got = ops.hr_fuse_sum([t.to(DEV) for t in (a, c, b, d)], (H, W), relu=True).cpu()
-    assert (got - ref).abs().max().item() < 1e-5
-    ref2 = a + up(d)
-    got2 = ops.hr_fuse_sum([a.to(DEV), d.to(DEV)], (H, W), relu=False).cpu()
-    assert (got2 - ref2).abs().max().item() < 1e-5
-
-
-def test_hrmodule_fused_sum_equals_per_term_launches():
-    """HRModule.run with the fuse layers as multi-job convolutions + one summation launch per branch against the
-    per-term resize / add launches (CODD_HR_FUSE_SUM=0), 4 branches incl. the odd-width 1/32 map."""
-    from codd_amd import hrnet, ops
-    torch.manual_seed(7)
-    mod = hrnet.HRModule((18, 36, 72, 144), 1).to(DEV).eval()
-    with torch.no_grad():
-        for m in mod.modules():
-            if isinstance(m, torch.nn.BatchNorm2d):
-                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.1)
-    xs = [torch.relu(rnd(1, c, 144 >> k, 240 >> k, seed=k)).to(DEV) for k, c in enumerate((18, 36, 72, 144))]
-    outs = {}
-    prev = ops.set_conv_precision("fp32")
-    try:
-        for fused in (False, True):
-            keep = hrnet.FUSE_SUM
-            hrnet.FUSE_SUM = fused
-            try:
-                outs[fused] = [o.cpu() for o in mod.run(xs)]
-            finally:
-                hrnet.FUSE_SUM = keep
-    finally:
-        ops.set_conv_precision(prev)
-    for a, b in zip(outs[False], outs[True]):
-        assert a.shape == b.shape and (a - b).abs().max().item() < 1e-4 * max(1.0, a.abs().max().item())
-
-
-@pytest.mark.parametrize("env", [dict(CODD_GN_MFMA="1", CODD_GN_PAIR="0"), dict(CODD_GN_PAIR="1", CODD_GN_TWO_PASS="0"),
-                                 dict(CODD_GN_PAIR="1", CODD_GN_TWO_PASS="1")], ids=["mfma", "pair", "pair_two_pass"])
-def test_se3_gn_step_builder_variants_match_j_entry_builder(env):
-    """se3_gn_build2_kernel (CODD_GN_MFMA=1: affinity dot products as split-bf16 MFMA Gram blocks) and
-    se3_gn_build3_kernel (CODD_GN_PAIR=1, the default: two neighbours per step in packed fp32, factored normal
-    equations) against the J-entry builder se3_gn_build_kernel<false> on the same inputs (odd width: the pair builder's
-    phantom partner), in child processes (the switches are read once per process)."""
-    import os
-    import subprocess
-    import sys
-    code = r'''
-import os, sys, torch
-sys.path.insert(0, os.getcwd())
-from codd_amd import ops
-g = torch.Generator().manual_seed(3)
-B, h, w = 1, 37, 61
-T = torch.zeros(B, h, w, 7); T[..., 6] = 1; T[..., :3] = torch.randn(B, h, w, 3, generator=g) * 0.02
-d1 = torch.rand(B, h, w, generator=g) * 30 + 3
-ae = torch.randn(B, 32, h, w, generator=g) * 3
-xyz = torch.rand(B, h, w, 3, generator=g) * 40
-delta = torch.randn(B, 3, h, w, generator=g) * 0.2
-wgt = torch.sigmoid(torch.randn(B, 3, h, w, generator=g))
-Tg = T.cuda()
-ops.se3_gn_step(Tg, ae.cuda(), xyz.cuda(), delta.cuda(), wgt.cuda(), d1.cuda(), [40.0, 42.0, w / 2.0, h / 2.0], radius=9)
-torch.save(Tg.cpu(), sys.argv[1])
-'''
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = []
-    for flag, e in (("0", dict(CODD_GN_MFMA="0", CODD_GN_PAIR="0")), ("1", env)):
-        path = os.path.join(root, "gpurun_out", f"_gn_variant_{flag}.pt")
-        os.makedirs(os.path.dirname(path), exist_ok=True)
-        subprocess.run([sys.executable, "-c", code, path], cwd=root, env=dict(os.environ, **e), check=True, timeout=300)
-        outs.append(torch.load(path))
-        os.remove(path)
-    step = (outs[0][..., :3]).abs().max().item()
-    err = (outs[0] - outs[1]).abs().max().item()
-    print("J-entry builder vs", env, ": max |delta T|", err, "step", step)
-    assert err < 1e-4 * max(1.0, step)
+def _gn_two_steps(ops):
+    g = torch.Generator().manual_seed(5)
+    B, h, w = 2, 37, 61
+    T = torch.zeros(B, h, w, 7); T[..., 6] = 1; T[..., :3] = torch.randn(B, h, w, 3, generator=g) * 0.02
+    d1 = torch.rand(B, h, w, generator=g) * 30 + 3
+    ae = torch.randn(B, 32, h, w, generator=g) * 3
+    xyz = torch.rand(B, h, w, 3, generator=g) * 40
+    delta = torch.randn(B, 3, h, w, generator=g) * 0.2
+    wgt = torch.sigmoid(torch.randn(B, 3, h, w, generator=g))
+    Tg = T.to(DEV)
+    for _ in range(2):
+        ops.se3_gn_step(Tg, ae.to(DEV), xyz.to(DEV), delta.to(DEV), wgt.to(DEV), d1.to(DEV), [40.0, 42.0, w / 2.0, h / 2.0], radius=32)
+    return Tg.cpu()
 
 
 def test_se3_gn_pair_builder_with_embedding_in_lds_is_bit_identical():
-    """se3_gn_build5_kernel (CODD_GN_AILDS=1: the pixel's own embedding read from LDS instead of 32 registers, four waves per
-    SIMD) issues the pair builder's instructions on the same values in the same order: torch.equal on the updated field."""
-    import os
-    import subprocess
-    import sys
-    code = r'''
-import os, sys, torch
-sys.path.insert(0, os.getcwd())
-from codd_amd import ops
-g = torch.Generator().manual_seed(5)
-B, h, w = 2, 37, 61
-T = torch.zeros(B, h, w, 7); T[..., 6] = 1; T[..., :3] = torch.randn(B, h, w, 3, generator=g) * 0.02
-d1 = torch.rand(B, h, w, generator=g) * 30 + 3
-ae = torch.randn(B, 32, h, w, generator=g) * 3
-xyz = torch.rand(B, h, w, 3, generator=g) * 40
-delta = torch.randn(B, 3, h, w, generator=g) * 0.2
-wgt = torch.sigmoid(torch.randn(B, 3, h, w, generator=g))
-Tg = T.cuda()
-for _ in range(2):
-    ops.se3_gn_step(Tg, ae.cuda(), xyz.cuda(), delta.cuda(), wgt.cuda(), d1.cuda(), [40.0, 42.0, w / 2.0, h / 2.0], radius=32)
-torch.save(Tg.cpu(), sys.argv[1])
-'''
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    """se3_gn_build5_kernel (the shipped builder: the pixel's own embedding read from LDS instead of 32 registers, four waves
+    per SIMD) issues the pair builder's instructions on the same values in the same order as se3_gn_build3_kernel
+    (CODD_OPT_GN_BUILDER = 3, kept as its reference): torch.equal on the updated field."""
+    from codd_amd import _abi, ops
     outs = []
-    for flag in ("0", "1"):
-        path = os.path.join(root, "gpurun_out", f"_gn_ailds_{flag}.pt")
-        os.makedirs(os.path.dirname(path), exist_ok=True)
-        subprocess.run([sys.executable, "-c", code, path], cwd=root, env=dict(os.environ, CODD_GN_PAIR="1", CODD_GN_AILDS=flag), check=True, timeout=300)
-        outs.append(torch.load(path))
-        os.remove(path)
+    try:
+        for builder in (3, 5):
+            _abi.set_option("gn_builder", builder)
+            outs.append(_gn_two_steps(ops))
+    finally:
+        _abi.set_option("gn_builder", 5)
     assert torch.isfinite(outs[0]).all() and (outs[0][..., :3].abs().max().item() > 1e-3)
     assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max().item()
+
+
+def test_library_options_replace_environment_switches():
+    """codd_set_option / codd_get_option (ABI v12): defaults = the shipped configuration, bad keys / values are rejected, the
+    previous value comes back, and another Gauss-Newton grouping (CODD_OPT_GN_Q4: another fp32 summation order of the same
+    normal equations, with another scratch size) gives the same step to rounding level."""
+    from codd_amd import _abi, ops
+    lib = _abi.load()
+    assert lib.codd_get_option(0) == 192 and lib.codd_get_option(1) == 5
+    assert lib.codd_set_option(99, 1) < 0 and lib.codd_set_option(0, 3) < 0 and lib.codd_set_option(1, 4) < 0
+    assert lib.codd_get_option(99) < 0
+    s192 = lib.codd_se3_gn_scratch(1, 72, 120, 32)
+    ref = _gn_two_steps(ops)
+    try:
+        assert _abi.set_option("gn_q4", 256) == 192
+        assert lib.codd_se3_gn_scratch(1, 72, 120, 32) != s192
+        got = _gn_two_steps(ops)
+    finally:
+        assert _abi.set_option("gn_q4", 192) == 256
+    d = (got - ref).abs().max().item()
+    assert 0 <= d < 2e-5 * ref.abs().max().item(), d
 
 
 def test_resize_bilinear_add_equals_two_launches():
@@ -1194,32 +1081,6 @@ def test_deferred_convs_equal_single_launches():
             assert torch.equal(a, b)
     finally:
         ops.set_conv_precision(prev)
-
-
-def test_hrnet_launch_reductions_keep_every_bit():
-    """The context network with the round-4 launch reductions (deferred multi-job fuse convolutions, folded '+ x_i'
-    terms, lockstep chain endings) against the one-launch-per-term schedule: torch.equal on the output."""
-    import codd_amd  # noqa: F401
-    from codd_amd import configs, hrnet, ops, synth
-    from codd_amd.registry import build_estimator
-    est = build_estimator(configs.codd(iters=2)).eval()
-    synth.load_synthetic_weights(est, gain=1.4)
-    est = est.to(DEV)
-    img, _, _ = synth.stereo_sequence(256, 384, 1)
-    x = img[:, 0].to(DEV)
-    flags = ("DEFER_FUSE", "FOLD_SELF", "LOCKSTEP_FUSE")
-    saved = {f: getattr(hrnet, f) for f in flags}
-    try:
-        outs = []
-        for on in (True, False):
-            for f in flags:
-                setattr(hrnet, f, on)
-            with ops.stage("context"):
-                outs.append(est.motion.raft3d.context(x).clone())
-        assert torch.equal(outs[0], outs[1]), (outs[0] - outs[1]).abs().max().item()
-    finally:
-        for f, v in saved.items():
-            setattr(hrnet, f, v)
 
 
 def test_timestamp_marks_are_ordered():

@@ -77,25 +77,3 @@ def test_stereo_only_graph_replay_equals_eager():
         assert torch.equal(a, b), f
     assert graph.graph is not None
 
-
-def test_hitnet_with_lds_chains_equals_per_layer_schedule():
-    """CODD_CHAINS=1 schedule (U-Net merges, down4 tail, TileUpdate / PostTileUpdate chains as single codd_conv_chain
-    launches with LDS-resident intermediates -- off by default, see ops.USE_CHAINS) against the per-layer schedule on
-    the same weights: exact fp32 either way, only the summation grouping differs."""
-    from codd_amd import configs, ops, synth
-    from codd_amd.registry import build_estimator
-    est = build_estimator(configs.stereo_only()).to("cuda").eval()
-    synth.load_synthetic_weights(est, gain=1.4)
-    img, r_img, _ = synth.stereo_sequence(128, 256, 1, 24.0)
-    l, r = img[:, 0].cuda().contiguous(), r_img[:, 0].cuda().contiguous()
-    saved = ops.USE_CHAINS, ops.CHAIN_MAX_PIXELS
-    try:
-        ops.USE_CHAINS = False
-        ref = est.stereo.stereo_matching(l, r)["pred_disp"].clone()
-        ops.USE_CHAINS, ops.CHAIN_MAX_PIXELS = True, 1 << 30  # every chain site, whatever the map size
-        got = est.stereo.stereo_matching(l, r)["pred_disp"].clone()
-    finally:
-        ops.USE_CHAINS, ops.CHAIN_MAX_PIXELS = saved
-    diff = (got - ref).abs()
-    assert torch.isfinite(got).all()
-    assert diff.median().item() < 1e-4 and (diff > 0.25).float().mean().item() < 2e-3, (diff.mean().item(), diff.max().item())

@@ -456,94 +456,6 @@ def test_conv_chain_through_split_records(mode, tol):
         ops.set_conv_precision(prev)
 
 
-def _chain_ref(x, layers, res1=None, stage=0):
-    """torch restatement of codd_conv_chain: buffers 0 / 1, residuals, per-layer activation."""
-    acts = dict(none=lambda t: t, lrelu=lambda t: F.leaky_relu(t, 0.2), relu=F.relu)
-    bufs = {stage: x} if layers[0]["w"].shape[-1] == 3 else {}  # a 3x3 first layer has its input staged
-    cur = x
-    stage = None
-    for i, L in enumerate(layers):
-        src = cur if L["src"] < 0 else bufs[L["src"]]
-        k, d = L["w"].shape[-1], L.get("dil", 1)
-        y = F.conv2d(src, L["w"], L.get("b"), padding=d * (k // 2), dilation=d)
-        if L.get("res", -1) >= 0:
-            y = y + bufs[L["res"]]
-        if L["dst"] < 0 and res1 is not None:
-            y = y + res1
-        if L.get("act") == "relu_ch0":
-            y = torch.cat([F.relu(y[:, :1]), y[:, 1:]], 1)
-        else:
-            y = acts[L.get("act", "none")](y)
-        if L["dst"] < 0:
-            return y
-        bufs[L["dst"]] = y
-        if i == 0 and L["w"].shape[-1] == 3:
-            pass
-    raise AssertionError
-
-
-def test_conv_chain_matches_torch():
-    """codd_conv_chain (LDS-resident chains, csrc/chain.hip) against torch: a 1x1-first chain over two concatenated
-    sources (TileUpdate shape: 1x1, two residual blocks, 3x3 to 34 channels), a staged 3x3-first chain with residuals
-    from the stage buffer (HRNet BasicBlock pair, 18 channels, batch 2), a dilation-3 block, and a chain ending in
-    res1 + relu_ch0 with only channel 0 stored; map sizes that are not multiples of any tile; every tile candidate."""
-    from codd_amd import ops
-    from codd_amd.ops import Slice
-
-    def mk(cout, cin, k, seed):
-        return rnd(cout, cin, k, k, seed=seed) / (cin * k * k) ** 0.5, rnd(cout, seed=seed + 100) * 0.1
-
-    def gpu(layers):
-        return [dict(L, w=L["w"].to(dev()), b=None if L.get("b") is None else L["b"].to(dev())) for L in layers]
-
-    cases = []
-    # A: TileUpdate shape -- 64 (40 | 24) -> 1x1 32 -> rb -> rb -> 3x3 34
-    ws = [mk(32, 64, 1, 1)] + [mk(32, 32, 3, 2 + i) for i in range(4)] + [mk(34, 32, 3, 9)]
-    prog = [dict(src=-1, dst=0, act="lrelu"), dict(src=0, dst=1, act="lrelu"), dict(src=1, dst=0, res=0, act="lrelu"),
-            dict(src=0, dst=1, act="lrelu"), dict(src=1, dst=0, res=0, act="lrelu"), dict(src=0, dst=-1)]
-    cases.append(("tileupdate", [dict(p_, w=w, b=b) for p_, (w, b) in zip(prog, ws)], 0, (1, 64, 37, 61), 40, False, None))
-    # B: two BasicBlocks on 18 channels, input staged into buffer 0, batch 2, last layer takes an LDS residual
-    ws = [mk(18, 18, 3, 20 + i) for i in range(4)]
-    prog = [dict(src=-1, dst=1, act="relu"), dict(src=1, dst=0, res=0, act="relu"), dict(src=0, dst=1, act="relu"),
-            dict(src=1, dst=-1, res=0, act="relu")]
-    cases.append(("hrnet18", [dict(p_, w=w, b=b) for p_, (w, b) in zip(prog, ws)], 0, (2, 18, 40, 52), None, False, None))
-    # C: dilation-3 residual block on 32 channels (no bias on the second conv)
-    ws = [mk(32, 32, 3, 30), (mk(32, 32, 3, 31)[0], None)]
-    prog = [dict(src=-1, dst=1, act="lrelu", dil=3), dict(src=1, dst=-1, res=0, act="lrelu", dil=3)]
-    cases.append(("dil3", [dict(p_, w=w, b=b) for p_, (w, b) in zip(prog, ws)], 0, (1, 32, 33, 47), None, False, None))
-    # D: residual block + 3x3 24 -> 16 + res1, relu on channel 0, only channel 0 stored (FinalTileUpdate tail shape)
-    ws = [mk(24, 24, 3, 40), mk(24, 24, 3, 41), mk(16, 24, 3, 42)]
-    prog = [dict(src=-1, dst=1, act="lrelu"), dict(src=1, dst=0, res=0, act="lrelu"), dict(src=0, dst=-1, act="relu_ch0")]
-    cases.append(("tail", [dict(p_, w=w, b=b) for p_, (w, b) in zip(prog, ws)], 0, (1, 24, 29, 70), None, True, 1))
-    for name, layers, stage, shape, split, with_res1, store in cases:
-        x = rnd(*shape, seed=7)
-        cout = layers[-1]["w"].shape[0]
-        res1 = rnd(shape[0], cout, shape[2], shape[3], seed=8) if with_res1 else None
-        ref = _chain_ref(x, layers, res1, stage)
-        pch = ops.PackedChain(gpu(layers), stage=stage)
-        xd = x.to(dev())
-        ntile = 0
-        for tile in (None,) + ops.PackedChain.TILES:
-            big = torch.full((shape[0], cout + 5, shape[2], shape[3]), 7.0, device=dev())
-            cs = cout if store is None else store
-            try:
-                if split:
-                    ops.conv_chain(Slice(xd, 0, split), pch, x2=Slice(xd, split, shape[1] - split),
-                                   res1=None if res1 is None else res1.to(dev()), out=Slice(big, 3, cs), cout_store=store, tile=tile)
-                else:
-                    ops.conv_chain(xd, pch, res1=None if res1 is None else res1.to(dev()), out=Slice(big, 3, cs),
-                                   cout_store=store, tile=tile)
-            except Exception as e:
-                assert tile is not None and "code -2" in str(e), (name, tile, e)  # tile over the LDS budget
-                continue
-            ntile += 1
-            got = big[:, 3:3 + cs].cpu()
-            err = (got - ref[:, :cs]).abs().max().item() / max(1.0, ref.abs().max().item())
-            assert err < 2e-5, (name, tile, err)
-            assert (big[:, :3] == 7.0).all() and (big[:, 3 + cs:] == 7.0).all(), (name, tile)
-        assert ntile >= 3, (name, ntile)
-
-
 def test_conv2d_multi_equals_separate_launches():
     """codd_conv2d_multi: up to four independent convolutions (different maps, channel counts, strides; residual +
     ReLU epilogues) as ONE launch -- HRNet's resolution branches -- against torch; a job whose rows are not 16-byte
@@ -574,48 +486,6 @@ def test_conv2d_multi_equals_separate_launches():
         for o, r in zip(outs, refs):
             assert o.shape == r.shape
             assert (o.cpu() - r).abs().max().item() < 5e-5 * max(1.0, r.abs().max().item())
-    finally:
-        ops.set_conv_precision(prev)
-
-
-def test_persistent_quad_kernel_matches_torch():
-    """layout 3 (conv_quad_persist_kernel: weights resident in LDS, workgroups walk the tiles and prefetch the next
-    tile's input) on the layer class it serves -- cin <= 32, cout <= 32: every tile shape, two concatenated inputs,
-    batch 2, residual + activation epilogue, maps that are not multiples of the tile, far more tiles than workgroups."""
-    from codd_amd import ops
-    from codd_amd.ops import Slice
-    prev = ops.set_conv_precision("fp32")
-    try:
-        for (c0, c1, cout, k, H, W, B) in [(32, 0, 32, 3, 70, 100, 2), (16, 0, 16, 3, 130, 260, 1), (16, 8, 16, 3, 37, 52, 1),
-                                           (32, 0, 16, 1, 64, 96, 1), (24, 0, 24, 3, 40, 64, 2)]:
-            cin = c0 + c1
-            x = rnd(B, cin, H, W, seed=cin + H)
-            w, b = rnd(cout, cin, k, k, seed=1) / (cin * k * k) ** 0.5, rnd(cout, seed=2) * 0.1
-            res = rnd(B, cout, H, W, seed=3)
-            ref = F.leaky_relu(F.conv2d(x, w, b, padding=k // 2) + res, 0.2)
-            xd, resd = x.to(dev()), res.to(dev())
-            pc = ops.PackedConv(w.to(dev()), b.to(dev()))
-            key = (H, W, B, 1, 1, 1, 1, k // 2, c1 > 0, 0)
-            ck = 16 if cin <= 16 else 32
-            n = 0
-            for mb in (1, 2):
-                if cout > 16 * mb:
-                    continue
-                for npb in (1, 2, 4):
-                    pc.tuned[key] = (npb, 4, ck, mb, 3)
-                    out = torch.full((B, cout + 2, H, W), 5.0, device=dev())
-                    import warnings
-                    with warnings.catch_warnings():
-                        warnings.simplefilter("error")  # a rejected configuration would fall back with a warning
-                        if c1:
-                            ops.conv2d(Slice(xd, 0, c0), pc, x2=Slice(xd, c0, c1), pad=k // 2, act="lrelu", res1=resd, out=Slice(out, 1, cout))
-                        else:
-                            ops.conv2d(xd, pc, pad=k // 2, act="lrelu", res1=resd, out=Slice(out, 1, cout))
-                    assert tuple(pc.tuned[key]) == (npb, 4, ck, mb, 3)
-                    assert (out[:, 1:1 + cout].cpu() - ref).abs().max().item() < 5e-5, (cin, cout, npb, mb)
-                    assert (out[:, 0] == 5.0).all() and (out[:, -1] == 5.0).all()
-                    n += 1
-            assert n >= 3
     finally:
         ops.set_conv_precision(prev)
 

@@ -24,4 +24,4 @@ s.record()
 for t in Ts:
     ops.se3_gn_step(t, *args, K8, radius=32)
 e.record(); torch.cuda.synchronize()
-print(f"CODD_GN_MFMA={os.environ.get('CODD_GN_MFMA', '0')} CODD_GN_Q4={os.environ.get('CODD_GN_Q4', '128')}: {s.elapsed_time(e) / 40 * 1e3:.1f} us per GN step (prep + build + solve)")
+print(f"{s.elapsed_time(e) / 40 * 1e3:.1f} us per GN step (prep + build + solve)")
