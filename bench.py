@@ -172,14 +172,22 @@ def dry_run_cpu(args, rank, local, world):
         time.sleep(0.002)
         return gt + (1.0 + rank)
 
+    from codd_amd import ops
+    ops.TUNE_DB[f"stub|rank{rank}"] = (rank, 4, 16)  # what every rank timing for itself would leave behind: N different tables
+    note = sync_launch_configurations(rank, world, lambda: ops.TUNE_DB.update({"stub|settled": (1, 4, 32)}))
     dt, red = timed_region(step, lambda i: (None, None, gt), args.steps, lambda d, g: seqm.update(d, g), seqm.row, dev, True)
     mine = torch.tensor([rank, local, args.steps], dtype=torch.int64)
     allr = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(allr, mine)
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, dict(rank=rank, gpu=local, frames=args.steps, fps=round(args.steps / timed_region.own_seconds, 3),
+                                          tune_db=tune_db_digest()))
     if rank == 0:
         print(json.dumps({"metric": "dry run (CPU stub runner, gloo)", "value": round(world * args.steps / dt, 3), "unit": "frames/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
-                          "epe_vs_synthetic_gt": red["epe"][0], "config": {"ranks_seen": [t.tolist() for t in allr]}}), flush=True)
+                          "epe_vs_synthetic_gt": red["epe"][0],
+                          "config": {"ranks_seen": [t.tolist() for t in allr], "per_rank": per_rank, "launch_configuration_sync": note,
+                                     "launch_configurations_identical_on_all_ranks": len({r["tune_db"] for r in per_rank}) == 1}}), flush=True)
     dist.destroy_process_group()
 
 
@@ -440,11 +448,35 @@ def timed_region(step, frame_fn, steps, update_metric, metric_row, device, use_d
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
+    timed_region.own_seconds = dt  # this rank's own clock (the JSON line lists every rank's frames/s beside the MAX-based value)
     if use_dist:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     return dt, red
+
+
+def sync_launch_configurations(rank, world, settle):
+    """Every rank must run the SAME launch configurations (tile, chunk depth = fp32 summation order): layer shapes the shipped
+    db does not know are timed on the fly, and N ranks timing for themselves can settle on N different picks (VERDICT r5 item
+    9).  Rank 0 runs ``settle()`` (which meets and times every layer shape), then its table replaces every other rank's
+    BEFORE they launch anything.  Returns a note for the JSON line."""
+    import torch.distributed as dist
+    from codd_amd import ops
+    if rank == 0:
+        settle()
+    picks = [{k: list(v) for k, v in ops.TUNE_DB.items()} if rank == 0 else None]
+    dist.broadcast_object_list(picks, src=0)
+    if rank != 0:
+        ops.TUNE_DB.clear()
+        ops.TUNE_DB.update({k: tuple(v) for k, v in picks[0].items()})
+    return f"rank 0's {len(picks[0])} launch configurations broadcast to {world - 1} rank(s) before their first launch"
+
+
+def tune_db_digest():
+    import hashlib
+    from codd_amd import ops
+    return hashlib.sha256(json.dumps({k: list(v) for k, v in ops.TUNE_DB.items()}, sort_keys=True).encode()).hexdigest()[:12]
 
 
 def pin_rank_to_cores(local_rank, local_world):
@@ -515,6 +547,15 @@ def main():
         k = i % MF
         return img[:, k].contiguous(), r_img[:, k].contiguous(), gt[:, k]
 
+    tune_note = None
+    if use_dist and world > 1 and not args.no_autotune:
+        def settle():  # rank 0 meets every layer shape of the steady-state frame in two eager frames
+            r0 = FrameRunner(est, metas[0], use_graph=False)
+            for i in range(2):
+                r0.step(*frame(i)[:2])
+            torch.cuda.synchronize(device)
+        tune_note = sync_launch_configurations(rank, world, settle)
+        log(tune_note)
     # frame 0 primes the recurrent state; then W untimed warm-up frames (graph capture happens here)
     log("model built, inputs resident")
     l, r, _ = frame(0)
@@ -541,11 +582,15 @@ def main():
     log(f"timed region done: {dt:.3f} s")
     # every rank reports in: (rank, local GPU index, frames it timed) gathered over RCCL -> ranks_seen in the JSON line
     ranks_seen = [[rank, local, args.steps]]
+    per_rank = [dict(rank=rank, gpu=local, frames=args.steps, fps=round(args.steps / timed_region.own_seconds, 3), tune_db=tune_db_digest())]
     if use_dist:
         mine = torch.tensor([rank, local, args.steps], device=device, dtype=torch.int64)
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         ranks_seen = [t.tolist() for t in allr]
+        objs = [None] * world
+        dist.all_gather_object(objs, per_rank[0])
+        per_rank = objs
     if args.tune_db and rank == 0:  # (re)write: shapes met for the first time in this run were tuned on the fly
         _ops_tune.save_tune_db(args.tune_db)
     if os.environ.get("CODD_BENCH_VERBOSE"):
@@ -712,6 +757,9 @@ def main():
                                              sum(1 for r in _ops_tune.AUTOTUNE_LOG if r[1] != r[3]))),
                        "fps_per_gpu": round(fps / world, 3),
                        "library": _loaded_library(),
+                       "per_rank": per_rank,  # every rank's own frames/s (its own clock) and the digest of its launch-configuration table
+                       "launch_configurations_identical_on_all_ranks": len({r["tune_db"] for r in per_rank}) == 1,
+                       "launch_configuration_sync": tune_note or "single rank",
                        "ranks_seen": ranks_seen, "frames_timed_all_ranks": sum(r[2] for r in ranks_seen)},
             "epe_vs_synthetic_gt": red["epe"][0],
             # every convolution on the exact-fp32 kernels (--precision fp32), same frame, shorter run

@@ -71,6 +71,10 @@ def test_bench_gpus_n_launches_itself():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
     assert sorted(out["config"]["ranks_seen"]) == [[0, 0, 4], [1, 1, 4]]
+    # every rank runs rank 0's launch-configuration table (broadcast before the first launch) and reports its own frame rate
+    assert out["config"]["launch_configurations_identical_on_all_ranks"] is True
+    assert [r["rank"] for r in out["config"]["per_rank"]] == [0, 1] and all(r["fps"] > 0 for r in out["config"]["per_rank"])
+    assert "broadcast to 1 rank" in out["config"]["launch_configuration_sync"]
     # launched WITH a world size that contradicts --gpus: refused, not silently run
     env2 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-cpu"], env=env2,
