@@ -217,6 +217,15 @@ def conv_roofline(runner, frames, device):
         recs.append((s, e, 2.0 * (p.C0 + p.C1) * cout * p.kh * p.kw * p.Hout * p.Wout * p.B,
                      (p.B, p.C0 + p.C1, cout, p.kh, p.kw, p.Hout, p.Wout, p.sy, p.store_mode),
                      p.terms if p.layout == 2 else 0))
+        if p.layout == 2:  # which instantiation conv_bf16_kernel<PGW, CGW, A, B, TERMS, OUTF, KS> serves which layer
+            a_ = -(-(p.nw * p.npb) // p.pgw)
+            inst = "<%d, %d, %d, %d, %d, %d, %d>" % (p.pgw, p.cgw, a_, p.mb // p.cgw, p.terms, 1 if (p.xso or p.gate) else 0, 2 if p.ksplit == 2 else 1)
+            layer = "%dx%d%s %d->%d @%dx%d%s" % (p.kh // 2 if p.dil2 else p.kh, p.kw, " dual-tap (dil %d + %d)" % (p.dil2, p.dil_y) if p.dil2 else
+                                                  (" dil %d" % p.dil_y if p.dil_y > 1 else ""), p.C0 + p.C1, cout, p.Hout, p.Wout,
+                                                  {0: "", 1: ", gate 1 (z|r pre-activation)", 2: ", gate 2 (z, r*h, q input)", 3: ", gate 3 (state update)"}[p.gate])
+            th_, tw_ = p.nw, 16 * p.npb
+            grid = -(-p.Hout // th_) * -(-p.Wout // tw_) * -(-cout // (16 * p.mb)) * p.B
+            insts.append((inst, layer, grid, s, e))
         return rc
 
     orig_roll = ops._launch_roll
@@ -246,6 +255,7 @@ def conv_roofline(runner, frames, device):
         multis.append(n)
         return rc
 
+    insts = []
     rolls = []
     ops._launch_roll = timed_roll
     multis = []
@@ -303,7 +313,13 @@ def conv_roofline(runner, frames, device):
         for key, (n, ms, f) in sorted(by.items(), key=lambda kv: -kv[1][1]):
             log("conv B%d Cin%-4d Cout%-4d k%dx%d out %3dx%-3d s%d m%d terms%d : n=%3d  %7.3f ms  %6.1f us/launch  %5.1f TF"
                 % (*key, n, ms, ms / n * 1e3, f / ms / 1e9))
-    return dict(launches=len(recs), time_ms=t_ms, gflop=flops / 1e9, hbm=hbm,
+    by_inst = {}
+    for inst, layer, grid, s_, e_ in insts:
+        c = by_inst.setdefault(inst, {}).setdefault(layer, [0, 0.0, grid])
+        c[0] += 1; c[1] += s_.elapsed_time(e_)
+    by_inst = {k: [dict(layer=l, launches_per_frame=v[0], us_per_launch=round(v[1] / v[0] * 1e3, 1), workgroups=v[2]) for l, v in ls.items()]
+               for k, ls in sorted(by_inst.items())}
+    return dict(launches=len(recs), time_ms=t_ms, gflop=flops / 1e9, hbm=hbm, instantiations=by_inst,
                 roll_launches=len(rolls), roll_layers=sum(rolls), multi_launches=len(multis), multi_jobs=sum(multis),
                 families={k: dict(launches=v[0], ms=round(v[1], 3), gflop=round(v[2] / 1e9, 2),
                                   issued_gflop=round(v[3] / 1e9, 2)) for k, v in fam.items()})
@@ -643,7 +659,9 @@ def main():
                         launches_per_frame=fd["launches"], ms_per_frame=fd["ms"],
                         algorithmic_frac_of_fp32_matrix_peak=round(ach / FP32_MATRIX_PEAK_TFLOPS, 4),
                         families=fams, conv_launches_per_frame=cr["launches"],
-                        
+                        # which layer each conv_bf16_kernel<PGW, CGW, A, B, TERMS, OUTF, KS> instantiation serves in this frame
+                        # (launches, HIP-event microseconds per launch, workgroups per launch): the key to the rocprofv3 / PMC tables
+                        instantiations=cr["instantiations"],
                         rolling_window_launches_per_frame=cr["roll_launches"], conv_layers_inside_rolling_launches=cr["roll_layers"],
                         multi_job_launches_per_frame=cr["multi_launches"], convs_inside_multi_job_launches=cr["multi_jobs"], conv_gflop_per_frame=round(cr["gflop"], 2),
                         conv_ms_per_frame=round(cr["time_ms"], 3),

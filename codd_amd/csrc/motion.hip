@@ -1182,48 +1182,74 @@ __global__ __launch_bounds__(256) void cvx_upsample_kernel(const float* __restri
 
 // upsample_se3 (mode 1) and the convex up-sampling of the 3-channel confidence (mode 2) of the SAME mask in one pass
 // (reference raft3d.py:267-273 applies both after the last update): the 19.9 MB mask and its soft-max are read / formed once.
+// Stores (round 6): a thread owns one COARSE pixel, so its results for sub-pixel (i, j) lie 8 output pixels = 224 bytes
+// (SE3 records) / 32 bytes (confidence planes) from its neighbour lane's -- as direct stores every lane wrote its own
+// partial 32-byte sector: 60 MB of HBM writes for 22 MB of results (profiles/r05_pmc_counters.md).  The workgroup's results
+// (2 output rows x 512 output pixels) are staged in LDS and leave as whole rows: 14 336 contiguous bytes per SE3 row,
+// 2 048 per confidence row, 16-byte stores.  Same arithmetic, same bits.
+#define CVX_TS 57  // floats per coarse pixel of a staged SE3 row: 8 sub-pixels x 7 + 1 pad (odd stride: <= 2 lanes per bank)
+#define CVX_WS 9   // floats per coarse pixel of a staged confidence row: 8 + 1 pad
 __global__ __launch_bounds__(256) void cvx_upsample_se3w_kernel(const float* __restrict__ T, const float* __restrict__ wgt,
                                                                 const float* __restrict__ mask, int h, int w,
                                                                 float* __restrict__ Tout, float* __restrict__ wout) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int wave = (threadIdx.x >> 6) + 4 * (blockIdx.z & 3);
+  __shared__ float sT[2][64 * CVX_TS];
+  __shared__ float sW[3][2][64 * CVX_WS];
+  const int xl = threadIdx.x & 63, x0 = blockIdx.x * 64, x = x0 + xl;
+  const int q = blockIdx.z & 3;  // quarter of the 64 sub-pixels: output rows 8 y + 2 q, + 1
+  const int wave = (threadIdx.x >> 6) + 4 * q;
   const int y = blockIdx.y, b = blockIdx.z >> 2;
-  if (x >= w) return;
   const int N = h * w;
-  float nb[9][9];  // 6 twist components | 3 confidence channels of the 9 neighbours
-#pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
-    const bool in = (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w;
-    V3 tau = V3{0, 0, 0}, phi = V3{0, 0, 0};
-    if (in) { const SE3T Tn = se3_load(T + ((size_t)b * N + yy * w + xx) * 7); se3_log(Tn, &tau, &phi); }
-    nb[k][0] = tau.x; nb[k][1] = tau.y; nb[k][2] = tau.z; nb[k][3] = phi.x; nb[k][4] = phi.y; nb[k][5] = phi.z;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) nb[k][6 + c] = in ? wgt[((size_t)b * 3 + c) * N + yy * w + xx] : 0.f;
-  }
-  const float* mb = mask + (size_t)b * 576 * N + (size_t)y * w + x;
   const int H8 = 8 * h, W8 = 8 * w;
-  for (int s = wave * 4; s < wave * 4 + 4; ++s) {
-    float m[9], mx = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { m[k] = mb[(size_t)(k * 64 + s) * N]; mx = fmaxf(mx, m[k]); }
-    float den = 0.f;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { m[k] = expf(m[k] - mx); den += m[k]; }
-    float acc[9];
-#pragma unroll
-    for (int c = 0; c < 9; ++c) acc[c] = 0.f;
+  if (x < w) {
+    float nb[9][9];  // 6 twist components | 3 confidence channels of the 9 neighbours
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-      const float wk = m[k] / den;
+      const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+      const bool in = (unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w;
+      V3 tau = V3{0, 0, 0}, phi = V3{0, 0, 0};
+      if (in) { const SE3T Tn = se3_load(T + ((size_t)b * N + yy * w + xx) * 7); se3_log(Tn, &tau, &phi); }
+      nb[k][0] = tau.x; nb[k][1] = tau.y; nb[k][2] = tau.z; nb[k][3] = phi.x; nb[k][4] = phi.y; nb[k][5] = phi.z;
 #pragma unroll
-      for (int c = 0; c < 9; ++c) acc[c] += wk * nb[k][c];
+      for (int c = 0; c < 3; ++c) nb[k][6 + c] = in ? wgt[((size_t)b * 3 + c) * N + yy * w + xx] : 0.f;
     }
-    const int oy = 8 * y + (s >> 3), ox = 8 * x + (s & 7);
-    const SE3T To = se3_exp(V3{acc[0], acc[1], acc[2]}, V3{acc[3], acc[4], acc[5]});
-    se3_store(Tout + ((size_t)b * H8 * W8 + (size_t)oy * W8 + ox) * 7, To);
+    const float* mb = mask + (size_t)b * 576 * N + (size_t)y * w + x;
+    for (int s = wave * 4; s < wave * 4 + 4; ++s) {
+      float m[9], mx = -INFINITY;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) wout[((size_t)b * 3 + c) * H8 * W8 + (size_t)oy * W8 + ox] = acc[6 + c];
+      for (int k = 0; k < 9; ++k) { m[k] = mb[(size_t)(k * 64 + s) * N]; mx = fmaxf(mx, m[k]); }
+      float den = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { m[k] = expf(m[k] - mx); den += m[k]; }
+      float acc[9];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) acc[c] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const float wk = m[k] / den;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) acc[c] += wk * nb[k][c];
+      }
+      const int row = (s >> 3) - 2 * q, j = s & 7;
+      const SE3T To = se3_exp(V3{acc[0], acc[1], acc[2]}, V3{acc[3], acc[4], acc[5]});
+      se3_store(&sT[row][xl * CVX_TS + j * 7], To);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) sW[c][row][xl * CVX_WS + j] = acc[6 + c];
+    }
+  }
+  __syncthreads();
+  const int nv = min(64, w - x0);  // coarse pixels of this segment
+  const int oy0 = 8 * y + 2 * q;
+  // SE3 records: a row segment is nv * 56 contiguous floats (16-byte aligned: 224 bytes per coarse pixel)
+  for (int i = threadIdx.x; i < 2 * nv * 14; i += 256) {
+    const int row = i / (nv * 14), q4 = i - row * (nv * 14), p = q4 / 14, k = q4 - p * 14;
+    const float* src = &sT[row][p * CVX_TS + 4 * k];
+    *(f32x4*)(Tout + ((size_t)b * H8 * W8 + (size_t)(oy0 + row) * W8 + 8 * x0) * 7 + 4 * q4) = f32x4{src[0], src[1], src[2], src[3]};
+  }
+  // confidence planes: nv * 8 contiguous floats per (channel, row)
+  for (int i = threadIdx.x; i < 6 * nv * 2; i += 256) {
+    const int cr = i / (nv * 2), q4 = i - cr * (nv * 2), c = cr >> 1, row = cr & 1, p = q4 >> 1, k = q4 & 1;
+    const float* src = &sW[c][row][p * CVX_WS + 4 * k];
+    *(f32x4*)(wout + ((size_t)b * 3 + c) * H8 * W8 + (size_t)(oy0 + row) * W8 + 8 * x0 + 4 * q4) = f32x4{src[0], src[1], src[2], src[3]};
   }
 }
 

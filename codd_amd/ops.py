@@ -303,8 +303,13 @@ _B_INST = ((2, 2, 5, 2, 1), (4, 1, 4, 4, 1), (4, 1, 4, 2, 1), (4, 1, 4, 1, 1), (
            (4, 1, 2, 1, 1), (4, 1, 3, 4, 1), (4, 1, 3, 2, 1),
            # 8 consumer waves (two per SIMD): k-split pairs (ks = 2) and 4x2 wave grids that split the tile
            (2, 2, 5, 2, 2), (4, 1, 4, 2, 2), (4, 1, 3, 2, 2), (4, 1, 3, 4, 2), (4, 2, 4, 2, 1), (4, 2, 3, 2, 1),
-           (8, 1, 4, 4, 1))
-_B_TILES = {5: ((9, 1), (10, 1), (5, 2)), 4: ((8, 2), (16, 1)), 8: ((16, 2),), 2: ((4, 2), (8, 1)), 3: ((12, 1), (6, 2))}
+           (8, 1, 4, 4, 1),
+           # round 6 (split-bf16 operands only): 96-channel groups and 20-unit tiles for the 384- / 768-channel layers of the
+           # update block, whose 64-channel x 12-unit grid is 288 workgroups = two dispatch rounds on 256 CUs
+           (4, 2, 3, 3, 1), (4, 2, 5, 2, 1), (2, 2, 5, 3, 1))
+# tiles (rows, 16-pixel units per row) by pixel units of a workgroup (= pgw * a)
+_B_TILES = {10: ((9, 1), (10, 1), (5, 2)), 16: ((8, 2), (16, 1)), 32: ((16, 2),), 8: ((4, 2), (8, 1)), 12: ((12, 1), (6, 2)),
+            20: ((10, 2), (18, 1), (20, 1))}
 
 
 def _bf16_candidates(pc, Hout, Wout, B, taps, terms):
@@ -316,7 +321,7 @@ def _bf16_candidates(pc, Hout, Wout, B, taps, terms):
         mb = b * cgw
         if mb > 1 and mb // 2 >= nblk:  # a channel group at least twice as wide as the layer
             continue
-        for (th, xb) in _B_TILES[a * pgw // 4 if pgw == 8 else a]:  # (tiles are listed by pixel units per 4 waves)
+        for (th, xb) in _B_TILES[pgw * a]:
             grid = -(-Hout // th) * -(-Wout // (16 * xb)) * -(-pc.cout_eff // (16 * mb)) * B
             rounds = -(-grid // 256)
             cost = rounds * (pgw * a) * mb
@@ -346,8 +351,8 @@ class SplitTensor:
 
 def _split_rows(H):
     """Image rows of a shared split tensor: enough for the row overhang of EVERY instantiated tile height
-    (4, 5, 6, 8, 9, 10, 12, 16 rows: ceil(H / th) * th <= H + th - 1)."""
-    return max(-(-H // th) * th for th in (4, 5, 6, 8, 9, 10, 12, 16))
+    (4 ... 20 rows: ceil(H / th) * th <= H + th - 1)."""
+    return max(-(-H // th) * th for th in (4, 5, 6, 8, 9, 10, 12, 16, 18, 20))
 
 
 def split_input(x, x2=None, border=0, c8=None, hp=None, wp=None, out=None):
@@ -866,6 +871,10 @@ def _autotune_b(lib, p, pc, cands, xsl, x2):
         if first is None:
             first = (c, t)
             continue
+        if AUTOTUNE_TRACE is not None:
+            xb_, th_, mb_ = c[0], c[1], c[3]
+            AUTOTUNE_TRACE.append(("b%d g%d k%dx%d d%d/%d %d->%d out %dx%d" % (p.terms, p.gate, pc.kh, pc.kw, p.dil_y, p.dil2, pc.cin, pc.cout, p.Hout, p.Wout), c,
+                                   -(-p.Hout // th_) * -(-p.Wout // (16 * xb_)) * -(-pc.cout_eff // (16 * mb_)) * p.B, t * 1e3))
         if t < best_t * 0.97 or best is None:
             best, best_t = c, t
     p.out = real_out
@@ -892,6 +901,7 @@ def _autotune_b(lib, p, pc, cands, xsl, x2):
 
 _AUTOTUNE = bool(int(_os.environ.get("CODD_AUTOTUNE", "0")))
 AUTOTUNE_LOG = []  # (layer description, heuristic cfg, us, chosen cfg, us) of every tuned launch shape
+AUTOTUNE_TRACE = None  # dev (tools/sweep_update_block.py): a list collects (layer description, cfg, grid, us) of EVERY candidate timed
 
 
 TUNE_DB = {}  # layer signature "cout,cin,kh,kw,mb,deconv|launch shape" -> (npb, nw, ck)

@@ -75,7 +75,15 @@ with open(os.path.join(DST, RT + "_pmc_counters.md"), "w") as f:
             f"`{RT}_kernel_stats_serial.csv`.\n\n")
     f.write(f"## Convolution families\n\nAll `conv_bf16_kernel<*>` (split-bf16) launches: FETCH {conv_f/conv_n:.0f} KiB + WRITE {conv_w/conv_n:.0f} KiB per launch "
             f"-> L2-miss-side traffic {(traffic_per_launch)/1e6:.2f} MB per launch ({conv_n} launches in the pass).\n\n")
-    f.write("| instantiation <NW,NPB,MB,WREG,IREG|QREG> | launches in pass | MFMA busy cycles/launch | MFMA pipe utilisation | FETCH KiB/launch | WRITE KiB/launch |\n|---|---|---|---|---|---|\n")
+    # which layer(s) an instantiation of conv_bf16_kernel<PGW, CGW, A, B, TERMS, OUTF, KS> serves: bench.py's roofline.instantiations
+    inst_layers = ((bench_line("serial").get("roofline") or {}).get("instantiations")) or {}
+
+    def layers_of(k):
+        for inst, ls in inst_layers.items():
+            if "conv_bf16_kernel" + inst in k.replace("void ", ""):
+                return "; ".join(f"{l['layer']} x{l['launches_per_frame']} ({l['workgroups']} workgroups, {l['us_per_launch']} us by HIP events)" for l in ls)
+        return ""
+    f.write("| instantiation <NW,NPB,MB,WREG,IREG|QREG> / <PGW,CGW,A,B,TERMS,OUTF,KS> | launches in pass | MFMA busy cycles/launch | MFMA pipe utilisation | FETCH KiB/launch | WRITE KiB/launch | layers of one frame (split-bf16 family) |\n|---|---|---|---|---|---|---|\n")
     for k in kernels:
         if "conv_mfma" not in k and "conv_quad" not in k and "conv_bf16" not in k:
             continue
@@ -83,7 +91,7 @@ with open(os.path.join(DST, RT + "_pmc_counters.md"), "w") as f:
         act, _ = mf.get((k, "GRBM_GUI_ACTIVE"), (0, 1))
         util = busy / (act / 8.0 * 1024.0) if act else float("nan")
         f.write(f"| `{k.replace('void ', '').replace('(ConvK)', '').replace('(ConvB)', '')}` | {n} | {busy/n:.3g} | {util:.3f} | {fetch[(k,'FETCH_SIZE')][0]/fetch[(k,'FETCH_SIZE')][1]:.0f} | "
-                f"{write.get((k,'WRITE_SIZE'),(0,1))[0]/write.get((k,'WRITE_SIZE'),(0,1))[1]:.0f} |\n")
+                f"{write.get((k,'WRITE_SIZE'),(0,1))[0]/write.get((k,'WRITE_SIZE'),(0,1))[1]:.0f} | {layers_of(k)} |\n")
     f.write("\n`util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCD x 1024 SIMD)`.\n\n## Other kernels (HBM / latency bound)\n\n")
     f.write("| kernel | launches in pass | avg us (serial) | FETCH KiB/launch | WRITE KiB/launch | traffic MB/launch (2F+W) | GB/s at the serial duration |\n|---|---|---|---|---|---|---|\n")
     for k in kernels:

@@ -19,7 +19,7 @@ ref = torch.einsum("dn,dm->nm", f1[0].reshape(D, N).double(), f2[0].reshape(D, N
 res = []
 for pgw, cgw, a, b, ks in ops._B_INST:
     mb = b * cgw
-    for th, xb in ops._B_TILES[a]:
+    for th, xb in ops._B_TILES[pgw * a]:
         for ck in (32, 64, 128, 16):
             c = (xb, th, ck, mb, 2, pgw, cgw, 3, ks)
             p = _abi.ConvParams()
