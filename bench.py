@@ -115,7 +115,9 @@ def parse():
                          "operands / fp32 accumulate for RAFT3D and exact fp32 for HITNet / context network / Fusion (default, parity-"
                          "tested at 1e-3 px); fp32 = exact-fp32 kernels everywhere; bf16 = bf16 operands / fp32 "
                          "accumulate everywhere (BASELINE.json configs[4]); bf16mix = bf16 operands for RAFT3D's feature encoder "
-                         "and update block only, exact fp32 for HITNet / context network / Fusion")
+                         "and update block only, exact fp32 for HITNet / context network / Fusion; fp16mix = the same policy on IEEE fp16 "
+                         "operands (the reference's auto_fp16 grade); fp16 / split16 = fp16 / hi|lo-fp16 operands in EVERY stage -- "
+                         "fp16's range applies there (|x| > 65504 -> inf; HITNet's channels carry raw disparities): dev modes")
     ap.add_argument("--stereo-only", action="store_true")
     ap.add_argument("--fp32-steps", type=int, default=30,
                     help="after the timed region (rank 0, N = 1, split precision only): time this many steady-state frames "

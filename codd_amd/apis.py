@@ -168,7 +168,8 @@ def load_checkpoint(model, filename, map_location="cpu", strict=False, log=print
     reference, so those 600-odd names were never compared with a real checkpoint (tests/golden/state_dict_keys.json
     pins everything else against the imported reference).  If a published ``.pth`` reports them under
     ``missing`` / ``unexpected``, pass the remap instead of editing the module tree, e.g.
-    ``key_map=[(r"^motion\\.raft3d\\.cnet\\.0\\.stage(\\d)\\.", r"motion.raft3d.cnet.0.stage\\1.")]``."""
+    ``key_map=[(r"^backbone\\.", "motion.raft3d.cnet.0."), (r"\\.norm(\\d)\\.", r".bn\\1.")]`` (a checkpoint whose context network sits
+    under ``backbone.`` and names its BatchNorm layers ``norm1 / norm2``)."""
     ckpt = torch.load(filename, map_location=map_location)
     sd = ckpt.get("state_dict", ckpt) if isinstance(ckpt, dict) else ckpt
     sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}

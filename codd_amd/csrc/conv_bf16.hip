@@ -4,7 +4,6 @@
 #include <stdlib.h>
 
 CONVB_ALL(CONVB_DECLARE)
-CONVB_T3_ALL(CONVB_DECLARE3)
 
 static inline int nk_of(int ntaps, int ck) { return cdiv((long long)ntaps * (ck >> 3), 4); }
 
@@ -91,13 +90,6 @@ int codd_conv2d_bf16(const codd_conv_params* pp, void* stream, int dry_run) {
                                                   : launch_b<PGW, CGW, A, B, 1, 0, KS>(k, lds, (int)grid, s));
   CONVB_ALL(X)
 #undef X
-#define X3(PGW, CGW, A, B, KS)                                                                   \
-  if (p.pgw == PGW && p.cgw == CGW && a == A && bb == B && ks == KS && p.terms == 3)             \
-    return dry_run ? CODD_OK                                                                     \
-           : (p.xso || p.gate) ? launch_b<PGW, CGW, A, B, 3, 1, KS>(k, lds, (int)grid, s)        \
-                               : launch_b<PGW, CGW, A, B, 3, 0, KS>(k, lds, (int)grid, s);
-  CONVB_T3_ALL(X3)
-#undef X3
   return CODD_EUNSUPPORTED;
 }
 

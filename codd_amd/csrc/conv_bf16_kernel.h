@@ -672,18 +672,6 @@ __global__ __launch_bounds__((PGW * CGW * KS + CONVB_NWP) * 64) void conv_bf16_k
 #define CONVB_ALL(X)                                                                                   \
   CONVB_GROUP_A(X) CONVB_GROUP_B(X) CONVB_GROUP_C(X) CONVB_GROUP_D(X) CONVB_GROUP_E(X) CONVB_GROUP_F(X) \
   CONVB_GROUP_G(X) CONVB_GROUP_H(X) CONVB_GROUP_I(X) CONVB_GROUP_J(X) CONVB_GROUP_K(X) CONVB_GROUP_L(X)
-//   round 6, split-bf16 operands (TERMS = 3) only: (4,2,3,3) = 12-unit tiles x 96 channels, (4,2,5,2) = 20-unit tiles x 64
-//   channels, (2,2,5,3) = 10-unit tiles x 96 channels -- single-round grids for the 384- / 768-channel update-block layers
-#define CONVB_GROUP_M(X) X(4, 2, 3, 3, 1)
-#define CONVB_GROUP_N(X) X(4, 2, 5, 2, 1)
-#define CONVB_GROUP_O(X) X(2, 2, 5, 3, 1)
-#define CONVB_T3_ALL(X) CONVB_GROUP_M(X) CONVB_GROUP_N(X) CONVB_GROUP_O(X)
-#define CONVB_DECLARE3(PGW, CGW, A, B, KS)                                                       \
-  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 0, KS>(const ConvB);      \
-  extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 1, KS>(const ConvB);
-#define CONVB_DEFINE3(PGW, CGW, A, B, KS)                                                        \
-  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 0, KS>(const ConvB);             \
-  template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 1, KS>(const ConvB);
 #define CONVB_DECLARE(PGW, CGW, A, B, KS)                                                        \
   extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 1, 0, KS>(const ConvB);      \
   extern template __global__ void conv_bf16_kernel<PGW, CGW, A, B, 3, 0, KS>(const ConvB);      \

@@ -228,7 +228,11 @@ def _split_terms():
 
 
 def set_conv_precision(mode):
-    """-> the previous mode (pass it back to restore).  "bf16mix" / "fp16mix" = "bf16" / "fp16" + the stage policy."""
+    """-> the previous mode (pass it back to restore).  "bf16mix" / "fp16mix" = "bf16" / "fp16" + the stage policy.
+    Range caveat of the fp16 formats ("fp16", "split16", "fp16mix"): IEEE fp16 records saturate to +-inf above 65504 and lo parts
+    below ~6e-8 flush to zero; plain "fp16" / "split16" apply to EVERY stage including HITNet (whose channels carry raw
+    disparities), "fp16mix" only to RAFT3D's feature encoder and update block (O(1) activations) -- the supported use.  Nothing
+    guards against overflow at run time except ``FrameRunner(check_finite=True)`` (debug) and the parity tests."""
     global CONV_PRECISION, BF16_STAGE_POLICY
     if mode not in _MODES:
         raise ValueError("conv precision must be one of %s" % (_MODES,))
@@ -303,13 +307,14 @@ _B_INST = ((2, 2, 5, 2, 1), (4, 1, 4, 4, 1), (4, 1, 4, 2, 1), (4, 1, 4, 1, 1), (
            (4, 1, 2, 1, 1), (4, 1, 3, 4, 1), (4, 1, 3, 2, 1),
            # 8 consumer waves (two per SIMD): k-split pairs (ks = 2) and 4x2 wave grids that split the tile
            (2, 2, 5, 2, 2), (4, 1, 4, 2, 2), (4, 1, 3, 2, 2), (4, 1, 3, 4, 2), (4, 2, 4, 2, 1), (4, 2, 3, 2, 1),
-           (8, 1, 4, 4, 1),
-           # round 6 (split-bf16 operands only): 96-channel groups and 20-unit tiles for the 384- / 768-channel layers of the
-           # update block, whose 64-channel x 12-unit grid is 288 workgroups = two dispatch rounds on 256 CUs
-           (4, 2, 3, 3, 1), (4, 2, 5, 2, 1), (2, 2, 5, 3, 1))
+           (8, 1, 4, 4, 1))
 # tiles (rows, 16-pixel units per row) by pixel units of a workgroup (= pgw * a)
-_B_TILES = {10: ((9, 1), (10, 1), (5, 2)), 16: ((8, 2), (16, 1)), 32: ((16, 2),), 8: ((4, 2), (8, 1)), 12: ((12, 1), (6, 2)),
-            20: ((10, 2), (18, 1), (20, 1))}
+_B_TILES = {10: ((9, 1), (10, 1), (5, 2)), 16: ((8, 2), (16, 1)), 32: ((16, 2),), 8: ((4, 2), (8, 1)), 12: ((12, 1), (6, 2))}
+# (round 6 added 96-channel groups (4,2,3,3) / (2,2,5,3) and 20-unit tiles (4,2,5,2) so that the 384-channel gate-input convolution
+# -- 288 workgroups = 1.12 dispatch rounds on its 64-channel x 12-unit grid -- could run as ONE round: every single-round
+# configuration is SLOWER (33.8 us at 192 / 216 / 240 workgroups against 29.8 us at 288: tools/sweep_update_block.py,
+# profiles/r06_sweep_update_block.log), the shipped picks are the optimum of the extended space on all seven update-block
+# layers, and the instantiations were removed again.)
 
 
 def _bf16_candidates(pc, Hout, Wout, B, taps, terms):
@@ -351,8 +356,8 @@ class SplitTensor:
 
 def _split_rows(H):
     """Image rows of a shared split tensor: enough for the row overhang of EVERY instantiated tile height
-    (4 ... 20 rows: ceil(H / th) * th <= H + th - 1)."""
-    return max(-(-H // th) * th for th in (4, 5, 6, 8, 9, 10, 12, 16, 18, 20))
+    (4, 5, 6, 8, 9, 10, 12, 16 rows: ceil(H / th) * th <= H + th - 1)."""
+    return max(-(-H // th) * th for th in (4, 5, 6, 8, 9, 10, 12, 16))
 
 
 def split_input(x, x2=None, border=0, c8=None, hp=None, wp=None, out=None):

@@ -16,10 +16,13 @@ from . import ops
 class FrameRunner:
     """Runs ConsistentOnlineDynamicDepth frame by frame on one GPU, eagerly or by graph replay."""
 
-    def __init__(self, estimator, img_metas, use_graph=True):
+    def __init__(self, estimator, img_metas, use_graph=True, check_finite=False):
         self.est = estimator
         self.metas = img_metas
         self.use_graph = use_graph
+        # debug aid (ADVICE r5): a host-synchronising isfinite check of every frame's output -- the fp16 operand formats
+        # (--precision fp16 | split16 | fp16mix) saturate to +-inf above 65504 and nothing else guards against it at run time
+        self.check_finite = check_finite
         self.last = {}  # per-frame side outputs of the last step (e.g. "Ts", the SE3 field: scene-flow evaluation)
         self.state = {}
         self.graph = None
@@ -139,4 +142,6 @@ class FrameRunner:
         self.graph.replay()
         self.state = {"memory": True}  # state now lives in the static buffers
         self.last = st.get("last", {})
+        if self.check_finite and not bool(torch.isfinite(st["out"]).all()):
+            raise FloatingPointError(f"frame {self.frames}: non-finite disparity (conv precision {ops.CONV_PRECISION})")
         return st["out"]

@@ -50,7 +50,8 @@ def main():
         MF = min(MF, int(os.environ.get("CODD_GOLDEN_FRAMES", MF)))
         key = name + ("@" + VARIANT if VARIANT else "")
         state, f0 = {}, 0
-        resume = OUT + f".{key}.state.pt"
+        # (CODD_GOLDEN_STATE_DIR: keep the ~200 MB resume files out of gpurun_out/ on the GPU box -- its merge-back limit is 64 MiB)
+        resume = os.path.join(os.environ.get("CODD_GOLDEN_STATE_DIR", os.path.dirname(OUT)), os.path.basename(OUT) + f".{key}.state.pt")
         if os.path.exists(resume):
             ck = torch.load(resume)
             if all(f"{key}_f{q}" in arrays for q in range(ck["f"] + 1)):

@@ -57,7 +57,10 @@ __global__ __launch_bounds__(256) void barrier_kernel(Ctl* c, unsigned* halo, in
   const unsigned long long t0 = wall_clock64();
   for (int r = 1; r <= rounds; ++r) {
     // 1 KB halo record of this round
-    halo[gid * 256 + threadIdx.x] = (unsigned)r * 1000u + gid;
+    // (double-buffered by round parity: a workgroup that is already in round r + 1 writes the OTHER buffer, so a mismatch
+    // below can only mean that the neighbour's round-r record was not visible yet)
+    unsigned* hb = halo + (size_t)(r & 1) * 8 * 64 * 256;
+    hb[gid * 256 + threadIdx.x] = (unsigned)r * 1000u + gid;
     if (MODE == 1) __threadfence_system();
     else if (MODE == 3) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // wait for the stores, no cache maintenance
     else __threadfence();  // release: the record before the arrival
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256) void barrier_kernel(Ctl* c, unsigned* halo, in
     }
     __syncthreads();
     if (__hip_atomic_load(&c->stale, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x80000000u) break;
-    const unsigned v = __hip_atomic_load(&halo[nb * 256 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned v = __hip_atomic_load(&hb[nb * 256 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     stale += v != (unsigned)r * 1000u + nb;
   }
   const unsigned long long t1 = wall_clock64();
@@ -92,8 +95,8 @@ __global__ __launch_bounds__(256) void barrier_kernel(Ctl* c, unsigned* halo, in
 template <int MODE>
 static void run(const char* tag, int rounds) {
   Ctl* c; unsigned* halo; unsigned long long* ticks;
-  CK(hipMalloc(&c, sizeof(Ctl))); CK(hipMalloc(&halo, 8 * 64 * 256 * 4)); CK(hipMalloc(&ticks, 256 * 8));
-  CK(hipMemset(c, 0, sizeof(Ctl))); CK(hipMemset(halo, 0, 8 * 64 * 256 * 4));
+  CK(hipMalloc(&c, sizeof(Ctl))); CK(hipMalloc(&halo, 2 * 8 * 64 * 256 * 4)); CK(hipMalloc(&ticks, 256 * 8));
+  CK(hipMemset(c, 0, sizeof(Ctl))); CK(hipMemset(halo, 0, 2 * 8 * 64 * 256 * 4));
   CK(hipFuncSetAttribute((const void*)barrier_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   CK(hipEventRecord(e0));
