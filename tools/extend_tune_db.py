@@ -11,8 +11,13 @@ from codd_amd.runtime import FrameRunner
 
 ops.enable_autotune(True, shipped=True)
 before = dict(ops.TUNE_DB)
-for name, (H, W, intr, img_shape, stereo_only, MF) in T.CASES.items():
-    for prec in (("split", "bf16mix", "fp16mix") if not stereo_only else ("split",)):
+# B = 2: bench.py's fps_two_videos_batched pass and tests/test_gpu_headline_parity.py::test_two_videos_in_lock_step; fp32: bench.py's
+# fp32_exact_fps pass -- with their signatures shipped a default bench.py run times nothing on the fly
+RUNS = [(name, prec, 1) for name, c in T.CASES.items() for prec in (("split", "bf16mix", "fp16mix", "fp32") if not c[4] else ("split",))]
+RUNS += [("cfg3_codd_960x576", "split", 2), ("cfg5_tartanair_640x512", "split", 2)]
+for name, prec, Bn in RUNS:
+    H, W, intr, img_shape, stereo_only, MF = T.CASES[name]
+    if True:
         prev = ops.set_conv_precision(prec)
         try:
             est = T._build(stereo_only)[0].to("cuda:0")
@@ -20,11 +25,11 @@ for name, (H, W, intr, img_shape, stereo_only, MF) in T.CASES.items():
             metas = synth.default_metas(H, W, img_shape=img_shape, intrinsics=intr)
             runner = FrameRunner(est, metas[0], use_graph=False)
             for f in range(3):
-                runner.step(img[:, f].to("cuda:0").contiguous(), r_img[:, f].to("cuda:0").contiguous())
+                runner.step(img[:, f].repeat(Bn, 1, 1, 1).to("cuda:0").contiguous(), r_img[:, f].repeat(Bn, 1, 1, 1).to("cuda:0").contiguous())
             torch.cuda.synchronize()
         finally:
             ops.set_conv_precision(prev)
-        print(name, prec, "db entries:", len(ops.TUNE_DB), flush=True)
+        print(name, prec, "B =", Bn, "db entries:", len(ops.TUNE_DB), flush=True)
 new = {k: v for k, v in ops.TUNE_DB.items() if k not in before}
 print("new signatures:", len(new))
 for k, v in sorted(new.items()):
