@@ -5,8 +5,6 @@
 #include <stdlib.h>
 #include "se3.h"
 
-#define MIN_DEPTH 0.05f  // reference projective_ops.py:7
-#define PEPS 1e-5f       // reference projective_ops.py:8
 
 // ------------------------------------------------------------------------------------------------
 // InstanceNorm2d (affine = False, eps = 1e-5, biased variance) + residual + ReLU.
@@ -204,8 +202,6 @@ struct LookupGeom {  // coords == NULL: the projected coordinates are computed h
   float *xyz, *minfo;
   codd_xs_view cxs, mxs;  // XS mode: correlation features / motion info written as split-bf16 records instead
 };
-__device__ __forceinline__ V3 inv_project(float depth, int x, int y, float fx, float fy, float cx, float cy);
-__device__ __forceinline__ V3 project(V3 X, float fx, float fy, float cx, float cy);
 __device__ __forceinline__ void raft_geometry_pixel(const float* __restrict__ T, const float* __restrict__ d1,
                                                     const float* __restrict__ d2, int b, int pix, int h, int w,
                                                     float fx, float fy, float cx, float cy, float* __restrict__ xyz,
@@ -358,13 +354,6 @@ extern "C" int codd_raft_geometry_lookup_xs(const float* T, const float* depth1,
 // ------------------------------------------------------------------------------------------------
 // Per-iteration geometry (reference raft3d.py:225-240).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ V3 inv_project(float depth, int x, int y, float fx, float fy, float cx, float cy) {
-  return V3{depth * (((float)x - cx) / fx), depth * (((float)y - cy) / fy), depth};
-}
-__device__ __forceinline__ V3 project(V3 X, float fx, float fy, float cx, float cy) {
-  const float Z = X.z + PEPS;
-  return V3{fx * (X.x / Z) + cx, fy * (X.y / Z) + cy, 1.f / Z};
-}
 
 // full per-pixel geometry of pixel n (batch b): writes xyz[n] and the 9 motion-info channels
 __device__ __forceinline__ void raft_geometry_pixel(const float* __restrict__ T, const float* __restrict__ d1,
@@ -1738,80 +1727,6 @@ __global__ void se3_identity_kernel(float* T, long long n) {
 extern "C" int codd_se3_identity(float* T, long long npix, void* stream) {
   if (!T) return CODD_EINVAL;
   se3_identity_kernel<<<cdiv(npix * 7, 256), 256, 0, (hipStream_t)stream>>>(T, npix * 7);
-  CODD_LAUNCH_CHECK();
-  return CODD_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Scene-flow metric columns (reference model/codd.py:519-575; utils/misc.py:12-36): over the crop [0,h) x [0,w) and
-// the mask  lo < gt_disp_prev < hi  &  |gt_flow_prev| < bf  &  |gt_disp_change| < bf  (& not occluded, when `occ`)
-//   depth1 = clip(bf / pred_disp_prev, 0, bf);   est = project(Ts * X0) - project(X0), X0 = inv_project(depth1),
-//   est.z *= bf   (inverse depth -> disparity);   gt = (flow_x, flow_y, disp_change)
-//   meters[0] += #mask, [1] += sum |est - gt|_2 (3-D), [2] += sum |est - gt|_2 (2-D), [3] += #(3-D < 1), [4] += #(2-D < 1)
-// Block partials in fp64, single-block finish in a fixed order: deterministic, no host sync.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sceneflow_partial_kernel(
-    const float* __restrict__ Ts, const float* __restrict__ pred_prev, const float* __restrict__ gt_prev,
-    const float* __restrict__ flow, const float* __restrict__ dchange, const unsigned char* __restrict__ occ, int W,
-    int h, int w, float lo, float hi, float bf, float fx, float fy, float cx, float cy, long long HW,
-    double* __restrict__ partial) {
-  __shared__ double red[5][4];
-  const int b = blockIdx.y;
-  const long long n = (long long)h * w;
-  double s[5] = {0, 0, 0, 0, 0};
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
-    const int y = (int)(e / w), x = (int)(e - (long long)y * w);
-    const size_t idx = (size_t)b * HW + (size_t)y * W + x;
-    const float gp = gt_prev[idx];
-    const float fu = flow[(size_t)b * 2 * HW + (size_t)y * W + x], fv = flow[(size_t)b * 2 * HW + HW + (size_t)y * W + x];
-    const float dc = dchange[idx];
-    if (!(gp > lo && gp < hi && sqrtf(fu * fu + fv * fv) < bf && fabsf(dc) < bf)) continue;
-    if (occ && occ[idx]) continue;
-    const float d1 = fminf(fmaxf(bf / pred_prev[idx], 0.f), bf);  // bf / 0 = inf -> bf
-    const V3 X0 = inv_project(d1, x, y, fx, fy, cx, cy);
-    const V3 X1 = se3_act(se3_load(Ts + idx * 7), X0);
-    const V3 a = project(X1, fx, fy, cx, cy), c = project(X0, fx, fy, cx, cy);
-    const float ex = (a.x - c.x) - fu, ey = (a.y - c.y) - fv, ez = (a.z - c.z) * bf - dc;
-    const float e2 = sqrtf(ex * ex + ey * ey), e3 = sqrtf(ex * ex + ey * ey + ez * ez);
-    s[0] += 1.0; s[1] += (double)e3; s[2] += (double)e2; s[3] += e3 < 1.f ? 1.0 : 0.0; s[4] += e2 < 1.f ? 1.0 : 0.0;
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < 5; ++k) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s[k] += __shfl_xor(s[k], o, 64);
-    if (lane == 0) red[k][wave] = s[k];
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double* p = partial + ((size_t)b * gridDim.x + blockIdx.x) * 5;
-    for (int k = 0; k < 5; ++k) p[k] = red[k][0] + red[k][1] + red[k][2] + red[k][3];
-  }
-}
-__global__ void sceneflow_finish_kernel(const double* __restrict__ partial, int n, double* __restrict__ meters) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  for (int k = 0; k < 5; ++k) {
-    double a = 0.0;
-    for (int i = 0; i < n; ++i) a += partial[(size_t)i * 5 + k];
-    meters[k] += a;
-  }
-}
-
-extern "C" int codd_sceneflow_metrics(const float* Ts, const float* pred_prev, const float* gt_disp_prev,
-                                      const float* gt_flow_prev, const float* gt_disp_change,
-                                      const unsigned char* gt_flow_occ, int B, int H, int W, int h, int w, float lo,
-                                      float hi, float bf, float fx, float fy, float cx, float cy, double* scratch,
-                                      double* meters, void* stream) {
-  if (!Ts || !pred_prev || !gt_disp_prev || !gt_flow_prev || !gt_disp_change || !scratch || !meters || h > H || w > W ||
-      h < 1 || w < 1 || B < 1)
-    return CODD_EINVAL;
-  const int nblk = 128;
-  hipStream_t s = (hipStream_t)stream;
-  sceneflow_partial_kernel<<<dim3(nblk, B), 256, 0, s>>>(Ts, pred_prev, gt_disp_prev, gt_flow_prev, gt_disp_change,
-                                                         gt_flow_occ, W, h, w, lo, hi, bf, fx, fy, cx, cy,
-                                                         (long long)H * W, scratch);
-  CODD_LAUNCH_CHECK();
-  sceneflow_finish_kernel<<<1, 64, 0, s>>>(scratch, nblk * B, meters);
   CODD_LAUNCH_CHECK();
   return CODD_OK;
 }

@@ -91,3 +91,14 @@ __device__ __forceinline__ void se3_log(const SE3T& T, V3* tau, V3* phi) {
   *phi = so3_log(T.q);
   *tau = left_jac_apply(*phi, T.t, true);
 }
+
+// pinhole geometry of RAFT3D (reference model/motion/raft3d/projective_ops.py:7-52): integer pixel centres
+#define MIN_DEPTH 0.05f  // projective_ops.py:7
+#define PEPS 1e-5f       // projective_ops.py:8
+__device__ __forceinline__ V3 inv_project(float depth, int x, int y, float fx, float fy, float cx, float cy) {
+  return V3{depth * (((float)x - cx) / fx), depth * (((float)y - cy) / fy), depth};
+}
+__device__ __forceinline__ V3 project(V3 X, float fx, float fy, float cx, float cy) {
+  const float Z = X.z + PEPS;
+  return V3{fx * (X.x / Z) + cx, fy * (X.y / Z) + cy, 1.f / Z};
+}
