@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: ran on the tree BEFORE the prune -- the CODD_HR_FUSE_* / CODD_CONVB_RING2 / CODD_GN_Q4 switches it sets were deleted afterwards)
 # GPU box, round 6 call 1: does the product meet rule (1) on the conditioned cfg5_16c golden -- by default and with the
 # re-ordering switches that the ill-conditioned goldens vetoed?  + same-lease A/B of their frame rate.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06_call1; mkdir -p $O; cd $R
