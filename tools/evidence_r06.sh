@@ -5,8 +5,11 @@
 # captured three kernel commits before the final tree.
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/ev_r06; mkdir -p $O; cd $R
 git_head=$(cat $R/.evidence_head 2>/dev/null); echo "tree: ${git_head:-unknown}; library $(sha256sum codd_amd/csrc/libcodd_hip.so | cut -c1-16)" > $O/tree.txt
-python -m pytest tests -m gpu -q 2>&1 | tail -8 > $O/gpu_tests.log
-python -m pytest tests/test_gpu_headline_parity.py -q -s 2>&1 | grep -v "^$" | grep "frame\|worst\|per-frame\|passed\|failed\|golden\|held\|meet\|oracle-vs-oracle" | cut -c1-400 > $O/headline_parity.log
+# the GPU suite in two halves (every test exactly once): the headline / recurrence / conditioned parity file with its per-frame log, then the rest
+python -m pytest tests/test_gpu_headline_parity.py -m gpu -q -s > $O/headline_parity_full.log 2>&1
+grep -v "^$" $O/headline_parity_full.log | grep "frame\|worst\|per-frame\|passed\|failed\|golden\|held\|meet\|oracle-vs-oracle" | cut -c1-400 > $O/headline_parity.log
+{ tail -3 $O/headline_parity_full.log; python -m pytest tests -m gpu -q --ignore tests/test_gpu_headline_parity.py 2>&1 | tail -8; } > $O/gpu_tests.log
+rm -f $O/headline_parity_full.log
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python -m torch.distributed.run --standalone --local-addr 127.0.0.1 --nnodes=1 --nproc-per-node 1 bench.py --gpus 1 --steps 200 --warmup 5 --no-cpu-baseline 2>/dev/null | grep "^{" > $O/bench_torchrun_n1.json
 python bench.py --stereo-only --no-cpu-baseline --steps 100 2>/dev/null > $O/bench_stereo_only.json
