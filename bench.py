@@ -566,7 +566,7 @@ def main():
         return img[:, k].contiguous(), r_img[:, k].contiguous(), gt[:, k]
 
     tune_note = None
-    if use_dist and world > 1 and not args.no_autotune:
+    if use_dist and not args.no_autotune:  # (also at N = 1 under torch.distributed.run: the RCCL object broadcast is exercised wherever a launcher is)
         def settle():  # rank 0 meets every layer shape of the steady-state frame in two eager frames
             r0 = FrameRunner(est, metas[0], use_graph=False)
             for i in range(2):
