@@ -4,7 +4,6 @@ The reference's "fusion" has no GRU: it is key projection,
 correlation cues, two small conv heads and a blend.  The cue tensors are produced by two fused
 kernels (csrc/fusion.hip); the heads run on the MFMA conv family.
 """
-import os
 
 import torch
 import torch.nn as nn
@@ -14,8 +13,8 @@ from .ops import Slice
 from .registry import build_loss, register
 from .stereo import cv
 
-PREFETCH_KEY = os.environ.get("CODD_PREFETCH_KEY", "1") == "1"  # (A/B switch; Fusion.prefetch_key)
-FUSE_FORGET = os.environ.get("CODD_FUSE_FORGET", "1") == "1"  # (A/B switch: Fusion.memory_query forget branch)
+PREFETCH_KEY = True  # (A/B switch; Fusion.prefetch_key)
+FUSE_FORGET = True  # (A/B switch: Fusion.memory_query forget branch)
 
 
 class BasicBlock(nn.Module):

@@ -9,7 +9,6 @@ Per-iteration schedule (16x per frame): geometry -> pyramid lookup -> flow/corr 
 ConvGRU (z|r as one 256-channel conv pair, q) -> one 1024-channel head conv + four 1x1 heads ->
 Gauss-Newton step.  Attribute names equal the reference's, so checkpoints load by key.
 """
-import os
 
 import numpy as np
 import torch
@@ -22,21 +21,21 @@ from .registry import MODELS, build_backbone, build_loss, register
 from .stereo import cv, packed
 
 BF_DEFAULT = 1050 * 0.2  # reference motion.py:45
-MERGE_ENC_HEADS = os.environ.get("CODD_MERGE_ENC_HEADS", "1") == "1"  # (A/B switch; see BasicUpdateBlock.run)
-FUSE_NORM_RECORDS = os.environ.get("CODD_FUSE_NORM_RECORDS", "1") == "1"  # (A/B switch; see ResidualBlock.run)
+MERGE_ENC_HEADS = True  # (A/B switch; see BasicUpdateBlock.run)
+FUSE_NORM_RECORDS = True  # (A/B switch; see ResidualBlock.run)
 # ConvGRU gates as convolution epilogues + each conv*1 / conv*2 pair as ONE dual-tap-set launch (BasicUpdateBlock.run)
-FUSE_GATES = os.environ.get("CODD_FUSE_GATES", "1") == "1"
+FUSE_GATES = True
 # the feature encoder runs on a side stream beside the stereo network: small-footprint launch configurations (A/B)
-FNET_CORESIDENT = os.environ.get("CODD_FNET_CORESIDENT", "0") == "1"
+FNET_CORESIDENT = False
 # the state-only launches in front of the first update (RAFT3D._preloop) on the fnet side stream behind the pyramid
-PRELOOP_SIDE = os.environ.get("CODD_PRELOOP_SIDE", "1") == "1"
+PRELOOP_SIDE = True
 # the flow encoder's 7x7 convolution beside the correlation encoder's first 3x3: 1 = small-footprint configurations for
 # the former, 2 = for both (A/B)
-ENC_CORESIDENT = int(os.environ.get("CODD_ENC_CORESIDENT", "1"))
+ENC_CORESIDENT = 1
 # side streams inside the update block (A/B switches): the flow encoder / mask head beside the correlation encoder, and
 # the next update's z|r convolution beside the Gauss-Newton step
-LOOP_FORK_ENC = os.environ.get("CODD_LOOP_FORK_ENC", "1") == "1"
-LOOP_FORK_ZR = os.environ.get("CODD_LOOP_FORK_ZR", "1") == "1"
+LOOP_FORK_ENC = True
+LOOP_FORK_ZR = True
 
 def packed_cat(mods):
     """One PackedConv whose output channels are the concatenation of several same-shape convs; cached on the first

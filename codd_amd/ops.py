@@ -135,10 +135,10 @@ def _launch_conv(lib, p, stream):
 
 
 import os as _os
-_FORCE_NPB = int(_os.environ.get("CODD_NPB", "0"))
-_FORCE_MB = int(_os.environ.get("CODD_MB", "0"))
-_FORCE_CK = int(_os.environ.get("CODD_CK", "0"))
-_FORCE_NW = int(_os.environ.get("CODD_NW", "0"))
+_FORCE_NPB = 0
+_FORCE_MB = 0
+_FORCE_CK = 0
+_FORCE_NW = 0
 
 
 def _wrow(mb):
@@ -207,8 +207,8 @@ def _conv_cfg(pc, Hout, Wout, B, sy, sx, dy, dx, pl):
 #                      "split" (16-bit operands, 2^-17); fp16's range applies (|x| <= 65504)
 #   "fp16"             IEEE fp16 operands (v_mfma_f32_16x16x32_f16), fp32 accumulate: the reference's own reduced
 #                      precision (auto_fp16 IS .half(), model/codd.py:37,128): 11 mantissa bits at bf16's MFMA rate
-CONV_PRECISION = _os.environ.get("CODD_CONV_PRECISION", "split")
-ALLPAIRS_SPLIT = _os.environ.get("CODD_ALLPAIRS_SPLIT", "1") == "1"  # (A/B switch of allpairs_corr)
+CONV_PRECISION = "split"  # set through set_conv_precision() / bench.py --precision, never through the environment
+ALLPAIRS_SPLIT = True  # (A/B switch of allpairs_corr)
 _TERMS = dict(split=3, bf16=1, fp16=16, split16=48)  # codd_conv_params.terms (CODD_TERMS_*)
 
 
@@ -252,8 +252,8 @@ def set_conv_precision(mode):
 # |pred_warp - pred_curr| (up to 250 px with the synthetic weights, whose weight-head logits saturate the sigmoid): from
 # frame 6 on isolated 4x4 blocks take the other side of a 0 | 1 fusion weight and the all-pixel mean leaves the 1e-3 px
 # budget (6.6e-3 ... 1.5e-2 px); with Fusion's ~10 quarter-resolution layers on the exact-fp32 kernels frames 0-13 stay
-# at <= 1e-4 px (profiles/r04_sequence_divergence.log).  CODD_FUSION_PRECISION=split restores the round-3 policy.
-_STAGE_PRECISION = dict(stereo="fp32", context="fp32", fusion=_os.environ.get("CODD_FUSION_PRECISION", "fp32"))
+# at <= 1e-4 px (profiles/r04_sequence_divergence.log).  (`_STAGE_PRECISION["fusion"] = "split"` restores the round-3 policy.)
+_STAGE_PRECISION = dict(stereo="fp32", context="fp32", fusion="fp32")
 
 
 class stage:
@@ -605,9 +605,9 @@ def _db_cfg_ok(lib, p, c, sig):
     return True
 
 
-MULTI_CONV = _os.environ.get("CODD_MULTI_CONV", "1") == "1"  # (A/B switch of conv2d_multi)
-MULTI_DEEP_FIRST = _os.environ.get("CODD_MULTI_DEEP_FIRST", "1") == "1"  # (A/B: job order inside a multi-job launch)
-MULTI_MB = int(_os.environ.get("CODD_MULTI_MB", "1"))  # 16-channel blocks per workgroup of a multi-job launch (1 | 2)
+MULTI_CONV = True  # (A/B switch of conv2d_multi)
+MULTI_DEEP_FIRST = True  # (A/B: job order inside a multi-job launch)
+MULTI_MB = 1  # 16-channel blocks per workgroup of a multi-job launch (1 | 2)
 
 _DEFERRED = None
 
@@ -778,8 +778,6 @@ def conv_gate(pc, xs, gate, pad=0, dil=1, dil2=0, out=None, out_coff=0, res1=Non
         p.xso_bt, p.xso_bl, p.xso_o8, p.xso_terms = xs_out.bt, xs_out.bl, 0, xs_out.terms
     key = ("gate", gate, H, W, B, pad, dil, dil2, terms)
     cfg = pc.tuned.get(key)
-    if cfg is None and _os.environ.get("CODD_GATE%d_CFG" % gate):  # dev override: "xb,th,ck,mb,2,pgw,cgw,terms,ks"
-        cfg = pc.tuned[key] = tuple(int(v) for v in _os.environ["CODD_GATE%d_CFG" % gate].split(","))
     if cfg is None:
         sig = "g%d,b%d|%d,%d,%d,%d|%d,%d,%d,%d,%d,%d" % (gate, terms, pc.cout, pc.cin, pc.kh, pc.kw, H, W, B, pad, dil, dil2)
         capturing = torch.cuda.is_current_stream_capturing()
@@ -904,7 +902,7 @@ def _autotune_b(lib, p, pc, cands, xsl, x2):
     return best, best_t + t_split
 
 
-_AUTOTUNE = bool(int(_os.environ.get("CODD_AUTOTUNE", "0")))
+_AUTOTUNE = False  # enable_autotune()
 AUTOTUNE_LOG = []  # (layer description, heuristic cfg, us, chosen cfg, us) of every tuned launch shape
 AUTOTUNE_TRACE = None  # dev (tools/sweep_update_block.py): a list collects (layer description, cfg, grid, us) of EVERY candidate timed
 
@@ -1004,14 +1002,14 @@ def _autotune(lib, p, pc, default, with_time=False):
 
 # ---------------------------------------------------------------------------- rolling-window convolutions
 # (csrc/conv_roll.hip, include/codd_hip.h codd_conv_roll): one 3x3, a pair of 3x3 (BasicBlock / merge tail) or a
-# 1x1 -> 3x3 pair per launch for HITNet's large 16- / 32-channel maps.  A/B switch CODD_ROLL (default on), maps of at
+# 1x1 -> 3x3 pair per launch for HITNet's large 16- / 32-channel maps.  `USE_ROLL` (default on), maps of at
 # least ROLL_MIN_PIXELS pixels (below that a 64-column strip grid cannot fill the chip and the tile kernels win).
-USE_ROLL = _os.environ.get("CODD_ROLL", "1") == "1"
-ROLL_MIN_PIXELS = int(_os.environ.get("CODD_ROLL_MIN_PIXELS", str(2 * 288 * 480)))
-ROLL_RH = int(_os.environ.get("CODD_ROLL_RH", "0"))  # dev override of the rows per workgroup
+USE_ROLL = True
+ROLL_MIN_PIXELS = 2 * 288 * 480
+ROLL_RH = 0  # dev override of the rows per workgroup
 
 
-ROLL_C32 = _os.environ.get("CODD_ROLL_C32", "0") == "1"  # (dev: the 32-channel instantiations lose to the tile kernels)
+ROLL_C32 = False  # (dev: the 32-channel instantiations lose to the tile kernels)
 
 
 def use_roll(C, B, Cin_unused, H, W):

@@ -12,7 +12,6 @@ Differences from the reference's op schedule (results identical up to fp32 round
   * the tile cost volume is never materialised (fused arg-min), TileWarping's three offsets,
     the PixelUnshuffle and the ||fea_l||_1 feature are one kernel, for both hypothesis sets.
 """
-import os
 
 import torch
 import torch.nn as nn
@@ -148,14 +147,14 @@ class HITUNet(nn.Module):
 _LEVELS = ("16x", "8x", "4x", "2x", "1x")
 
 
-FORK_INIT_LEVELS = os.environ.get("CODD_FORK_INIT", "0") == "1"  # (A/B switch; TileInitialization.forward)
-STEREO_PIPE = os.environ.get("CODD_STEREO_PIPE", "1") == "1"
+FORK_INIT_LEVELS = False  # (A/B switch; TileInitialization.forward)
+STEREO_PIPE = True
 # initialisation of scales 1/2 (>= 1) and 1/4 (>= 2) on the decoder's side stream, right behind the decoder stage that
 # produces their features, instead of on the caller's stream in front of the propagation step that consumes them: the
 # caller's stream (the long pole: ~60 dependent small launches) sheds 12 of them.  Same launches, same bits.  Round 4,
 # three alternating runs each: stereo-only 441 -> 460 -> 472 frames/s (0 / 1 / 2), full frame 97.1 -> 97.6 -> 97.7.
-PIPE_INIT_SIDE = int(os.environ.get("CODD_PIPE_INIT_SIDE", "2"))  # (A/B: HITNetMF._stereo_matching_pipelined)
-FORK_INIT_FINE = int(os.environ.get("CODD_FORK_INIT_FINE", "3"))  # (A/B: this many of the finest scales on ONE side stream)
+PIPE_INIT_SIDE = 2  # (A/B: HITNetMF._stereo_matching_pipelined)
+FORK_INIT_FINE = 3  # (A/B: this many of the finest scales on ONE side stream)
 
 
 @register
